@@ -1,0 +1,404 @@
+"""
+ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Runs ONLY in the build container.
+
+Generates the golden vectors under tests/golden/ by importing the REAL reference
+(/root/reference/src/v1t, read-only, never copied) with stub modules for its missing third-party
+imports, loading the deterministic weights of `oracle/weights.py` through
+`load_state_dict`, and running its `Model` / `Recorder` / `attention_rollouts` on the synthetic
+inputs of the same module. While generating, every vector is also compared against the CPU
+restatement `oracle/v1t_oracle.py` in fp32 and fp64 — the script aborts if they disagree, which
+is what pins the oracle to the reference.
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz
+
+Fixtures hold data only (inputs are regenerated from seeds; expected outputs / gradient samples
+are stored). Large tensors are stored as deterministic strided samples (`sample()` below).
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import types
+import typing as t
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import v1t_oracle as O  # noqa: E402
+from oracle import weights as W  # noqa: E402
+
+MAX_SAMPLE = 4096
+
+
+def sample(x: torch.Tensor) -> np.ndarray:
+    """Deterministic strided sample of a tensor: flat[::stride][:MAX_SAMPLE]."""
+    f = x.detach().reshape(-1)
+    stride = max(1, -(-f.numel() // MAX_SAMPLE))
+    return f[::stride][:MAX_SAMPLE].to(torch.float32).numpy().copy()
+
+
+# --------------------------------------------------------------------------------------
+# reference import with stubs
+# --------------------------------------------------------------------------------------
+def import_reference():
+    if "v1t" in sys.modules:
+        return
+    sys.path.insert(0, os.path.join(REF, "src"))
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    stub("torchinfo", summary=lambda *a, **k: None)
+    stub("wandb")
+
+    class Resize:
+        def __init__(self, size, antialias=False):
+            self.size = size
+
+        def __call__(self, x):
+            return F.interpolate(x, size=self.size, mode="bilinear", align_corners=False, antialias=False)
+
+    def resize(img, size, antialias=False):
+        return F.interpolate(img[None], size=tuple(size), mode="bilinear", align_corners=False, antialias=False)[0]
+
+    tv = stub("torchvision")
+    tvt = stub("torchvision.transforms", Resize=Resize)
+    tvf = stub("torchvision.transforms.functional", resize=resize)
+    tv.transforms = tvt
+    tvt.functional = tvf
+    tb = stub("v1t.utils.tensorboard", Summary=object)
+    import v1t.utils  # noqa: F401
+
+    sys.modules["v1t.utils"].tensorboard = tb
+
+
+class FakeDS:
+    """What the reference constructors read from a DataLoader (readout.py:36, gaussian2d.py:186, losses.py:107-111)."""
+
+    def __init__(self, coords: np.ndarray, n: int, size: int = 4500):
+        self.dataset = SimpleNamespace(
+            coordinates=coords,
+            response_stats={"mean": np.abs(np.ones(n, np.float32)), "std": np.ones(n, np.float32)},
+        )
+        self._size = size
+
+
+def ref_args(cfg: O.Config, ds_name="sensorium"):
+    return SimpleNamespace(
+        core="vit", readout="gaussian2d", behavior_mode=cfg.behavior_mode, shift_mode=cfg.shift_mode,
+        center_crop=1.0, resize_image=0, ds_name=ds_name, patch_size=cfg.patch_size, patch_mode=cfg.patch_mode,
+        patch_stride=cfg.patch_stride, num_blocks=cfg.num_blocks, num_heads=cfg.num_heads, emb_dim=cfg.emb_dim,
+        mlp_dim=cfg.mlp_dim, p_dropout=cfg.p_dropout, t_dropout=cfg.t_dropout, drop_path=0.0, use_lsa=cfg.use_lsa,
+        disable_bias=cfg.disable_bias, core_reg_scale=cfg.core_reg_scale,
+        disable_grid_predictor=cfg.disable_grid_predictor, grid_predictor_dim=cfg.grid_predictor_dim,
+        bias_mode=cfg.bias_mode, readout_reg_scale=cfg.readout_reg_scale, shifter_reg_scale=cfg.shifter_reg_scale,
+        cropper_reg_scale=0.0, device=torch.device("cpu"), verbose=0, grad_checkpointing=0,
+        input_shape=cfg.input_shape, output_shapes={m: (cfg.num_neurons[m],) for m in cfg.mouse_ids}, ds_scale=1,
+    )
+
+
+def build_reference_model(cfg: O.Config, sd: O.SD, seed: int):
+    import_reference()
+    from v1t.models.model import Model
+
+    ds = {m: FakeDS(W.make_coordinates(seed, m, cfg.num_neurons[m]), cfg.num_neurons[m]) for m in cfg.mouse_ids}
+    model = Model(ref_args(cfg), ds=ds)
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert set(res.missing_keys) <= {"image_cropper.grid", "elu1.one"}, res.missing_keys
+    return model
+
+
+def check(name: str, ref: torch.Tensor, got: torch.Tensor, rtol: float, atol: float):
+    ref = ref.detach().to(torch.float64)
+    got = got.detach().to(torch.float64)
+    err = (ref - got).abs()
+    bound = atol + rtol * ref.abs()
+    worst = float((err / bound).max())
+    if not (worst <= 1.0):
+        raise SystemExit(f"ORACLE != REFERENCE at {name}: max err {float(err.max()):.3e} (x{worst:.2f} of bound)")
+    return float(err.max())
+
+
+def oracle_grads(cfg, sd, batch, mouse_id, ds_size, eps=None, dtype=torch.float32):
+    sdd = {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    b = {k: v.to(dtype) for k, v in batch.items()}
+    loss, reg, y = O.total_loss(cfg, sdd, b, mouse_id, ds_size, eps=None if eps is None else eps.to(dtype))
+    (loss + reg).backward()
+    keys = O.core_param_keys(sd) + O.readout_param_keys(sd, mouse_id) + O.shifter_param_keys(sd, mouse_id)
+    # a parameter the restatement never touches (sigma in eval mode) has an all-zero gradient in the reference
+    return loss.detach(), reg.detach(), y.detach(), {k: (sdd[k].grad if sdd[k].grad is not None else torch.zeros_like(sdd[k])) for k in keys}
+
+
+def ref_forward_backward(model, cfg, batch, mouse_id, ds_size, train_eps_seed=None):
+    """Reference fwd (+ Poisson loss + regulariser, train.py:59-73) and backward. eval mode unless
+    train_eps_seed is given (then train mode with dropout 0 configured by cfg, eps drawn from that seed)."""
+    from v1t.losses import PoissonLoss
+
+    crit = PoissonLoss(SimpleNamespace(ds_scale=1), ds={m: SimpleNamespace(dataset=range(int(ds_size))) for m in cfg.mouse_ids})
+    model.zero_grad(set_to_none=True)
+    model.train(train_eps_seed is not None)
+    taps = {}
+    hooks = []
+    core = model.core
+    hooks.append(core.patch_embedding.register_forward_hook(lambda m, i, o: taps.__setitem__("patch_embed", o.detach().clone())))
+    if train_eps_seed is not None:
+        torch.manual_seed(train_eps_seed)
+    y, _, _ = model(inputs=batch["image"], mouse_id=mouse_id, behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
+    for h in hooks:
+        h.remove()
+    loss = crit(y_true=batch["response"], y_pred=y, mouse_id=mouse_id, batch_size=batch["image"].shape[0])
+    reg = model.regularizer(mouse_id)
+    (loss + reg).backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    return loss.detach(), reg.detach(), y.detach(), grads, taps
+
+
+def ref_core_taps(model, batch, mouse_id):
+    """Core output + per-block residual stream captured by hooks (eval)."""
+    model.train(False)
+    taps = {}
+    hs = []
+    for k, blk in enumerate(model.core.transformer.blocks):
+        hs.append(blk["mha"].register_forward_hook(lambda m, i, o, k=k: taps.__setitem__(f"mha{k}", (o + i[0]).detach().clone())))
+        hs.append(blk["mlp"].register_forward_hook(lambda m, i, o, k=k: taps.__setitem__(f"mlp{k}", (o + i[0]).detach().clone())))
+    with torch.no_grad():
+        z = model.core(inputs=batch["image"], mouse_id=mouse_id, behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
+    for h in hs:
+        h.remove()
+    taps["core"] = z
+    return taps
+
+
+# --------------------------------------------------------------------------------------
+# fixtures
+# --------------------------------------------------------------------------------------
+def gen_train_fixture(name: str, cfg: O.Config, batch_size: int, seed: int, out: dict, train: bool = False, log=print):
+    """G1/G2/G4: outputs, loss, reg and gradient samples for one mouse-batch."""
+    mouse = cfg.mouse_ids[0]
+    sd = W.make_state_dict(cfg, seed)
+    batch = W.make_batch(cfg, mouse, batch_size, seed)
+    model = build_reference_model(cfg, sd, seed)
+    ds_size = 4500.0
+    eps = None
+    eps_seed = None
+    if train:
+        eps_seed = 4321
+        torch.manual_seed(eps_seed)
+        eps = torch.empty(batch_size, cfg.num_neurons[mouse], 1, 2).normal_().reshape(batch_size, -1, 2)
+    loss, reg, y, grads, taps = ref_forward_backward(model, cfg, batch, mouse, ds_size, train_eps_seed=eps_seed)
+    # --- pin the oracle
+    for dt, rt, at in ((torch.float32, 2e-4, 2e-5), (torch.float64, 2e-5, 2e-6)):
+        ol, orr, oy, og = oracle_grads(cfg, sd, batch, mouse, ds_size, eps=eps, dtype=dt)
+        e1 = check(f"{name}.y[{dt}]", y, oy, rt, at)
+        check(f"{name}.loss[{dt}]", loss, ol, rt, at)
+        check(f"{name}.reg[{dt}]", reg, orr, rt, at)
+        eg = 0.0
+        for k, g in grads.items():
+            scale = float(g.abs().max()) + 1e-12
+            eg = max(eg, check(f"{name}.grad[{k}][{dt}]", g, og[k], rt * 5, at * 5 + rt * scale) / scale)
+        assert set(grads) == set(og), set(grads) ^ set(og)
+        log(f"  {name}: oracle[{str(dt)[6:]}] vs reference: y err {e1:.2e}, worst grad err/scale {eg:.2e}")
+    if not train:
+        rt = ref_core_taps(model, batch, mouse)
+        otaps = {}
+        with torch.no_grad():
+            O.model_forward(cfg, sd, batch["image"], mouse, batch["behavior"], batch["pupil_center"], taps=otaps)
+        for k in rt:
+            check(f"{name}.tap[{k}]", rt[k], otaps[k], 2e-4, 2e-5)
+            out[f"{name}/tap/{k}"] = sample(rt[k])
+        check(f"{name}.tap[patch_embed]", taps["patch_embed"], otaps["patch_embed"], 2e-4, 2e-5)
+        out[f"{name}/tap/patch_embed"] = sample(taps["patch_embed"])
+    else:
+        out[f"{name}/eps"] = eps.numpy()
+    out[f"{name}/y"] = y.numpy()
+    out[f"{name}/loss"] = np.float64(loss.item())
+    out[f"{name}/reg"] = np.float64(reg.item())
+    for k, g in grads.items():
+        out[f"{name}/grad/{k}"] = sample(g)
+        out[f"{name}/gradnorm/{k}"] = np.float64(g.double().norm().item())
+
+
+def gen_variants(out: dict, log=print):
+    """G3: outputs only for the constructor variants the reference supports on this path."""
+    base = dict(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 200, "B": 123})
+    variants = {
+        "beh0": dict(behavior_mode=0),
+        "beh2": dict(behavior_mode=2),
+        "beh4": dict(behavior_mode=4),
+        "franke": dict(input_shape=(2, 36, 64)),
+        "nogridpred": dict(disable_grid_predictor=True),
+        "grid3": dict(grid_predictor_dim=3),
+        "lsa": dict(use_lsa=True),
+        "nobias": dict(disable_bias=True),
+        "patch1": dict(patch_mode=1),
+        "patch2": dict(patch_mode=2),
+        "patch3": dict(patch_mode=3),
+        "stride2": dict(patch_stride=2),
+        "noshift": dict(shift_mode=0),
+        "heads3_d40": dict(num_heads=3, emb_dim=40, mlp_dim=72),
+    }
+    for vn, kw in variants.items():
+        cfg = O.Config(**{**base, **kw})
+        seed = 77
+        sd = W.make_state_dict(cfg, seed)
+        model = build_reference_model(cfg, sd, seed)
+        model.train(False)
+        for mouse in ("A", "B"):
+            batch = W.make_batch(cfg, mouse, 2, seed)
+            with torch.no_grad():
+                y, _, _ = model(inputs=batch["image"], mouse_id=mouse, behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
+                oy = O.model_forward(cfg, sd, batch["image"], mouse, batch["behavior"], batch["pupil_center"])
+            e = check(f"variant.{vn}.{mouse}", y, oy, 2e-4, 2e-5)
+            out[f"variant/{vn}/{mouse}/y"] = y.numpy()
+        log(f"  variant {vn}: ok (last err {e:.2e})")
+
+
+def gen_rollout(out: dict, log=print):
+    """G5: Recorder + attention_rollouts (attention_rollout.py) on a 2-block D=64 model, B=2."""
+    import_reference()
+    from v1t.utils.attention_rollout import Recorder, attention_rollouts
+
+    cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 64})
+    seed = 99
+    sd = W.make_state_dict(cfg, seed)
+    model = build_reference_model(cfg, sd, seed)
+    model.train(False)
+    batch = W.make_batch(cfg, "A", 2, seed)
+    rec = Recorder(model.core)
+    with torch.no_grad():
+        _, attn = rec(images=batch["image"], behaviors=batch["behavior"], pupil_centers=batch["pupil_center"], mouse_id="A")
+        heat = attention_rollouts(attn, image_shape=list(batch["image"].shape[2:]))
+    rec.eject()
+    record: t.List[torch.Tensor] = []
+    with torch.no_grad():
+        O.vit_tokens(cfg, sd, batch["image"], "A", batch["behavior"], batch["pupil_center"], record=record)
+    oattn = torch.stack(record, dim=1)
+    check("rollout.attn", attn, oattn, 2e-4, 1e-7)
+    rows = []
+    for i in range(2):
+        row = O.attention_rollout_row(oattn[i])
+        # reference pre-normalisation row, recomputed from the reference's recorded attention
+        a = attn[i].max(dim=1).values + torch.eye(attn.shape[-1])
+        a = a / a.sum(-1, keepdim=True)
+        j = a[0]
+        for n in range(1, a.shape[0]):
+            j = a[n] @ j
+        check(f"rollout.row{i}", j[0, 1:], row, 1e-4, 1e-9)
+        oh = O.attention_rollout(oattn[i], tuple(batch["image"].shape[2:]))
+        check(f"rollout.heat{i}", heat[i], oh, 1e-3, 2e-4)
+        rows.append(j[0, 1:].numpy())
+    out["rollout/row"] = np.stack(rows)
+    out["rollout/heatmap"] = heat.numpy()
+    out["rollout/attn_sample"] = sample(attn)
+    log("  rollout: ok")
+
+
+def gen_step(out: dict, log=print):
+    """G6: one optimizer step = sum of 2 mice (train.py:97-111), AdamW (train.py:216-223), dropout 0,
+    eval-style readout (sample=False is not reachable through Model.forward, so eps is drawn from a seed)."""
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 200, "B": 123},
+                   p_dropout=0.0, t_dropout=0.0)
+    seed = 55
+    sd = W.make_state_dict(cfg, seed)
+    model = build_reference_model(cfg, sd, seed)
+    from v1t.losses import PoissonLoss
+
+    ds_size = 4500.0
+    crit = PoissonLoss(SimpleNamespace(ds_scale=1), ds={m: SimpleNamespace(dataset=range(int(ds_size))) for m in cfg.mouse_ids})
+    lr = 1.647e-3
+    opt = torch.optim.AdamW(model.get_parameters(core_lr=lr), lr=lr, betas=(0.9, 0.9999), eps=1e-8, weight_decay=0)
+    model.train(True)
+    opt.zero_grad()
+    eps_all = {}
+    for i, mouse in enumerate(cfg.mouse_ids):
+        batch = W.make_batch(cfg, mouse, 4, seed)
+        torch.manual_seed(1000 + i)
+        eps_all[mouse] = torch.empty(4, cfg.num_neurons[mouse], 1, 2).normal_().reshape(4, -1, 2)
+        torch.manual_seed(1000 + i)
+        y, _, _ = model(inputs=batch["image"], mouse_id=mouse, behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
+        loss = crit(y_true=batch["response"], y_pred=y, mouse_id=mouse, batch_size=4)
+        (loss + model.regularizer(mouse)).backward()
+    opt.step()
+    new = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    # oracle step
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    for mouse in cfg.mouse_ids:
+        batch = W.make_batch(cfg, mouse, 4, seed)
+        l, r, _ = O.total_loss(cfg, osd, batch, mouse, ds_size, eps=eps_all[mouse])
+        (l + r).backward()
+    pkeys = O.core_param_keys(sd)
+    for m in cfg.mouse_ids:
+        pkeys += O.readout_param_keys(sd, m) + O.shifter_param_keys(sd, m)
+    assert set(pkeys) == {k for k, _ in model.named_parameters()}
+    params = {k: osd[k].detach() for k in pkeys}
+    O.adamw_step(params, {k: osd[k].grad for k in pkeys}, {}, step=1, lr=lr)
+    for k in pkeys:
+        check(f"step.{k}", new[k], params[k], 1e-4, 1e-6)
+        out[f"step/param/{k}"] = sample(new[k])
+    for m in cfg.mouse_ids:
+        out[f"step/eps/{m}"] = eps_all[m].numpy()
+    log(f"  step: ok ({len(pkeys)} params)")
+
+
+def gen_resize(out: dict, log=print):
+    """Pins the (stub-dependent) 144x256 -> 36x64 bilinear resize of the cropper stage separately."""
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 1, 144, 256)).astype(np.float32))
+    ref = F.interpolate(x, size=(36, 64), mode="bilinear", align_corners=False, antialias=False)
+    check("resize", ref, O.resize_bilinear(x, (36, 64)), 1e-5, 1e-6)
+    out["resize/out_sample"] = sample(ref)
+    log("  resize: ok")
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    torch.manual_seed(0)
+
+    def save(fname, d):
+        path = os.path.join(ROOT, "tests", "golden", fname)
+        np.savez_compressed(path, **d)
+        print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB, {len(d)} arrays")
+
+    d = {}
+    print("G1 (C1: 1 block, D=64, 256 neurons, B=2, eval)")
+    gen_train_fixture("g1", W.config_c1(), 2, 1234, d)
+    print("G4 (C1, train-mode readout sampling with injected eps, dropout 0)")
+    c = W.config_c1()
+    c.p_dropout = 0.0
+    c.t_dropout = 0.0
+    gen_train_fixture("g4", c, 2, 1234, d, train=True)
+    save("g1_g4_c1.npz", d)
+
+    d = {}
+    print("G2 (C2 default V1T, mouse A x 8000 neurons, B=2, eval)")
+    gen_train_fixture("g2", W.config_c2({"A": 8000}), 2, 1234, d)
+    print("G2b (C4 Franke-shaped, 2 channels, 1121 neurons, B=2, eval)")
+    gen_train_fixture("g2b", W.config_c4(), 2, 1234, d)
+    save("g2_default.npz", d)
+
+    d = {}
+    print("G3 variants")
+    gen_variants(d)
+    print("G5 rollout")
+    gen_rollout(d)
+    print("G6 optimizer step")
+    gen_step(d)
+    gen_resize(d)
+    save("g3_g5_g6.npz", d)
+
+
+if __name__ == "__main__":
+    main()
