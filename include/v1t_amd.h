@@ -1,0 +1,155 @@
+/*
+ * v1t_amd — C-ABI of the MI355X-native V1T hot path (libv1t_amd.so, gfx950).
+ *
+ * The reference (bryanlimy/V1T) has no FFI: its hot path sits behind two Python class
+ * registries, `register("vit")` (src/v1t/models/core/core.py:8-16, used at core/vit.py:365) and
+ * `register("gaussian2d")` (src/v1t/models/readout/readout.py:10-18, used at
+ * readout/gaussian2d.py:13). The entry points below are what a ctypes binding behind those two
+ * registry entries calls (INTEGRATION.md shows the stub); each cites the reference code it replaces.
+ *
+ * Conventions: every pointer is a DEVICE pointer borrowed for the call (except v1t_vit_config and
+ * name/shape out-parameters, which are host memory); nothing is allocated inside a launch function
+ * (workspaces are sized by the *_bytes queries and passed in); all work is enqueued asynchronously
+ * on `stream` (a hipStream_t passed as void*); return value 0 = ok, negative = error code below
+ * (the Python shim raises RuntimeError, which the reference's OOM probe utils/utils.py:460 relies on).
+ * Thread-safe for distinct handles / distinct streams.
+ */
+#ifndef V1T_AMD_H
+#define V1T_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V1T_OK 0
+#define V1T_ERR_ARG -1
+#define V1T_ERR_UNSUPPORTED -2
+#define V1T_ERR_LAUNCH -3
+#define V1T_ERR_WORKSPACE -4
+
+int v1t_abi_version(void);
+const char* v1t_error_string(int code);
+
+/* ---------------------------------------------------------------- ViT core (core/vit.py:365-436) */
+typedef struct v1t_vit_config {
+    int in_channels, in_h, in_w;      /* core input shape = ImageCropper.output_shape (model.py:78) */
+    int patch_size, patch_stride, patch_mode; /* vit.py:384-391; patch_mode 0/1 supported natively */
+    int emb_dim, num_heads, mlp_dim, num_blocks; /* vit.py:392-398; head dim = emb_dim (vit.py:218) */
+    int behavior_mode;                /* 0 none, 2/3 shared B-MLP, 4 per-mouse B-MLP (vit.py:157-202) */
+    int num_mice;                     /* B-MLP instances when behavior_mode == 4, else ignored */
+    int use_lsa, use_bias;            /* vit.py:235-251; --disable_bias => use_bias = 0 */
+    float p_dropout, t_dropout;       /* vit.py:390,398 */
+    float ln_eps;                     /* nn.LayerNorm default 1e-5 */
+} v1t_vit_config;
+
+typedef struct v1t_vit v1t_vit;       /* opaque plan: dims, arena/shadow/workspace layout, pack table */
+
+int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out);
+void v1t_vit_destroy(v1t_vit* h);
+
+/* Parameter arena: ONE flat fp32 buffer; tensors keep the reference's natural shapes and state-dict
+ * names so checkpoints stay compatible. Entries [0, param_count) are
+ * nn.Parameters (what ViTCore.regularizer vit.py:419-421 and the optimizer see); entries after that
+ * are buffers (`mha.scale` without LSA). `name` is relative to the core module
+ * ("transformer.blocks.0.mha.to_qkv.weight"); per-mouse B-MLPs use "models.@<i>". */
+long long v1t_vit_arena_floats(const v1t_vit* h);
+long long v1t_vit_param_floats(const v1t_vit* h);
+int v1t_vit_num_tensors(const v1t_vit* h);
+int v1t_vit_tensor_info(const v1t_vit* h, int idx, char* name, int name_cap, long long* offset,
+                        int* ndim, long long* shape4, int* is_param);
+int v1t_vit_tokens(const v1t_vit* h);      /* T = patches + 1 */
+int v1t_vit_padded_dim(const v1t_vit* h);  /* DP: row stride of the token-major output */
+int v1t_vit_grid_h(const v1t_vit* h);      /* latent (h, w) = find_shape(T-1), vit.py:411-417 */
+int v1t_vit_grid_w(const v1t_vit* h);
+
+long long v1t_vit_shadow_bytes(const v1t_vit* h);                 /* bf16 padded/transposed weight shadow */
+long long v1t_vit_workspace_bytes(const v1t_vit* h, int batch, int save_for_backward);
+long long v1t_vit_scratch_bytes(const v1t_vit* h, int batch);     /* backward-only scratch */
+/* byte offset of a named intermediate inside the forward workspace (tests / rollout): names
+ * "x0","xa","xm","z1","qkv","o","lse2","z2","hpre","hact","beta"; returns <0 if unknown */
+long long v1t_vit_workspace_offset(const v1t_vit* h, int batch, int save_for_backward, const char* name, int block);
+
+/* refresh the shadow from the fp32 arena (after an optimizer step / load_state_dict) */
+int v1t_vit_pack(const v1t_vit* h, const float* arena, void* shadow, void* stream);
+
+/* ViTCore.forward vit.py:423-436. images (B,C,H,W) fp32; behaviors (B,IN) fp32 already
+ * concatenated with pupil centers for behavior_mode 3/4 (vit.py:431-432), NULL for mode 0.
+ * out: token-major residual stream (B, T, DP) fp32, CLS at t = 0, columns >= emb_dim are 0; the
+ * reference's (B, C', h, w) output is the strided view out[:, 1:, :emb_dim] (vit.py:434-435).
+ * training != 0 enables the three dropouts with the counter-based mask keyed by `seed`. */
+int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, const float* images,
+                    const float* behaviors, int mouse_idx, int batch, void* workspace,
+                    long long workspace_bytes, int save_for_backward, int training, uint64_t seed,
+                    float* out, void* stream);
+
+/* Backward of the above: gout (B,T,DP) fp32 = dL/d out; accumulates (+=) into grads, a flat fp32
+ * buffer with the arena's layout (gradient accumulation over mice, train.py:97-111, is free). */
+int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, const float* images,
+                     const float* behaviors, int mouse_idx, int batch, const void* workspace,
+                     void* scratch, long long scratch_bytes, int training, uint64_t seed,
+                     const float* gout, float* grads, void* stream);
+
+/* keep-mask of one dropout stream, for replaying the exact mask in a CPU check.
+ * stream ids: 8*block + {0: attention P (rows B*H*T, cols T), 1: proj out, 2: fc1 out, 3: fc2 out}
+ * (rows B*T, cols = feature index), 0xFFFF: patch embedding. out: rows*cols bytes (1 = keep). */
+int v1t_dropout_mask(uint64_t seed, uint32_t stream_id, float p, long long rows, long long cols,
+                     uint8_t* out, void* stream);
+
+/* ------------------------------------------------ Gaussian2d readout (readout/gaussian2d.py:237-278) */
+/* z: core map, element (b, cell, c) at z[b*zsb + cell*zsc + c] (cell = y*W + x, channel stride 1);
+ * grid (B,N,2) sample positions (x,y) incl. shifts (gaussian2d.py:265-268); feat (N,FS) neuron-major
+ * feature weights (the (1,C,1,N) parameter viewed transposed); bias (N) or NULL; out (B,N). */
+int v1t_gaussian2d_forward(const float* z, long long zsb, long long zsc, int B, int C, int H, int W,
+                           int N, const float* grid, const float* feat, int FS, const float* bias,
+                           float* out, void* stream);
+/* gout (B,N). dz (same addressing as z, += via atomics; must be zero-initialised by the caller),
+ * dgrid (B,N,2) overwritten, dfeat (N,FS) +=, dbias (N) +=. Any of dz/dgrid/dfeat/dbias may be NULL. */
+int v1t_gaussian2d_backward(const float* z, long long zsb, long long zsc, int B, int C, int H, int W,
+                            int N, const float* grid, const float* feat, int FS, const float* gout,
+                            float* dz, long long dzsb, long long dzsc, float* dgrid, float* dfeat,
+                            float* dbias, void* stream);
+
+/* ELU1 (models/utils.py:109-118) + PoissonLoss (losses.py:153-166, scale_ds :114-119).
+ * yhat/du/loss may be NULL; y may be NULL (inference: only yhat). loss is += (zero it first). */
+int v1t_elu1_poisson(const float* u, const float* y, long long n, float loss_scale, float gscale,
+                     float* yhat, float* du, float* loss, void* stream);
+
+/* ------------------------------------------------------------------ optimiser-side HBM kernels */
+/* torch.optim.AdamW step (train.py:216-223) over a flat arena, with the L1 regulariser's gradient
+ * l1 * sign(p) folded in (vit.py:419-421, gaussian2d.py:99-100) and optional fused zero_grad. */
+int v1t_adamw_step(float* p, float* g, float* m, float* v, long long n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float l1, int zero_grad,
+                   void* stream);
+int v1t_l1_sum(const float* p, long long n, float scale, float* out_accum, void* stream);   /* out += scale*sum|p| */
+int v1t_l1_grad(const float* p, float* g, long long n, float scale, void* stream);          /* g += scale*sign(p) */
+
+/* ------------------------------------------------------------- building blocks (parity tests) */
+/* C[M][N] (bf16 or fp32) = A[M][K] . B[N][K]^T, bf16 inputs, fp32 accumulate */
+int v1t_gemm_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C, int ldc,
+                int out_f32, void* stream);
+/* dW[n][k] (fp32, +=) = sum_m Y[m][n] X[m][k], bf16 inputs */
+int v1t_gemm_tn(const void* Y, int ldy, const void* X, int ldx, int M, int NY, int NX, float* dW,
+                int ldw, int m_chunk, void* stream);
+/* qkv (B*T, 3*H*DP) bf16 -> o (B*T, H*DP) bf16, lse2 (B,H,T) */
+int v1t_attention_forward(const void* qkv, int B, int H, int T, int DP, const float* scale,
+                          int scale_per_head, int mask_diag, float dropout_p, uint64_t seed,
+                          uint32_t stream_id, void* o, float* lse2, void* stream);
+int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const float* lse2, int B,
+                           int H, int T, int DP, const float* scale, int scale_per_head, int mask_diag,
+                           float dropout_p, uint64_t seed, uint32_t stream_id, float* delta_ws,
+                           void* dqkv, float* dscale, void* stream);
+
+/* LayerNorm (vit.py:220,145) forward: z bf16 (rows, DP) = LN(x (+ inject[b])) ; backward: see
+ * csrc/elementwise.h LnBwdArgs (gout = gin + dLN; optional token-sum, next-branch cast + bias colsum) */
+int v1t_layernorm_forward(const float* x, const float* inject, float* xout, const float* gamma,
+                          const float* beta, void* z, float* mean, float* rstd, int B, int T, int D,
+                          int DP, float eps, void* stream);
+int v1t_layernorm_backward(const float* dz, const float* x, const float* mean, const float* rstd,
+                           const float* gamma, const float* gin, float* gout, float* dgamma,
+                           float* dbeta, float* dinject, void* dy_next, float* dbias_next, int B,
+                           int T, int D, int DP, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

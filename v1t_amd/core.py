@@ -1,0 +1,356 @@
+"""Core plugin registry + the MI355X-native "vit" core.
+
+Host-side mirror of the reference's core interface for this hot path:
+  - `register(name)` / `get_core(args)` / `Core`   <- src/v1t/models/core/core.py:8-16, 62-65, 19-59
+  - `ViTCore(args, input_shape)` registered as "vit" <- src/v1t/models/core/vit.py:365-436
+Same names, constructor/forward signatures, attributes (`input_shape`, `output_shape`, `frozen`,
+`regularizer()`), state-dict keys and error behaviour, so that `get_core(args)(args, input_shape=...)`
+and checkpoints of the reference work unchanged. The compute is NOT torch: `forward` is one
+autograd node around `v1t_vit_forward` / `v1t_vit_backward` of libv1t_amd.so (hand-written gfx950
+kernels). Without the library, or on a CPU tensor, it raises RuntimeError — there is no fallback.
+
+If the reference package `v1t` is importable, `install_into_reference()` overwrites its registry
+entries with these classes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import typing as t
+
+import torch
+from torch import nn
+
+from . import lib as L
+from .flat import FlatArena, Slot
+
+_CORES: t.Dict[str, t.Any] = dict()
+
+
+def register(name: str):
+    """Decorator filling the core registry (reference core/core.py:8-16)."""
+
+    def add_to_dict(fn):
+        _CORES[name] = fn
+        return fn
+
+    return add_to_dict
+
+
+def get_core(args):
+    """reference core/core.py:62-65"""
+    if args.core not in _CORES.keys():
+        raise NotImplementedError(f"Core {args.core} has not been implemented.")
+    return _CORES[args.core]
+
+
+class Core(nn.Module):
+    """Base class (reference core/core.py:19-59)."""
+
+    def __init__(self, args: t.Any, input_shape: t.Tuple[int, int, int], name: str = "Core"):
+        super().__init__()
+        self.input_shape = input_shape
+        self.name = name
+        self.behavior_mode = args.behavior_mode
+        if args.core != "vit":
+            assert self.behavior_mode != 2
+        self.frozen = False
+        self.verbose = getattr(args, "verbose", 0)
+
+    def freeze(self):
+        for param in self.parameters():
+            param.requires_grad_(False)
+        self.frozen = True
+
+    def unfreeze(self):
+        for param in self.parameters():
+            param.requires_grad_(True)
+        self.frozen = False
+
+    def regularizer(self):
+        raise NotImplementedError("regularizer function has not been implemented")
+
+    def forward(self, inputs, mouse_id, behaviors, pupil_centers):
+        raise NotImplementedError("forward function has not been implemented")
+
+
+def find_shape(num_patches: int) -> t.Tuple[int, int]:
+    """reference vit.py:411-417"""
+    dim1 = math.ceil(math.sqrt(num_patches))
+    while num_patches % dim1 != 0 and dim1 > 0:
+        dim1 -= 1
+    return dim1, num_patches // dim1
+
+
+class _VitFn(torch.autograd.Function):
+    """One autograd node for the whole core. `anchor` is a dummy leaf that requires grad iff the core
+    is trainable; parameter gradients are accumulated in place into the core's gradient arena
+    (their .grad views), so the node returns no gradients."""
+
+    @staticmethod
+    def forward(ctx, core: "ViTCore", images, behaviors, mouse_idx: int, anchor, need_bwd: bool):
+        # need_bwd is decided by the caller: grad mode is always off inside Function.forward
+        B = images.shape[0]
+        training = core.training
+        seed = core._next_seed() if training else 0
+        lib = L.load()
+        ws_bytes = lib.v1t_vit_workspace_bytes(core._plan, B, int(need_bwd))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=images.device)
+        out = torch.empty((B, core.num_tokens, core.padded_dim), dtype=torch.float32, device=images.device)
+        L.check(
+            lib.v1t_vit_forward(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), images.data_ptr(),
+                                L.ptr(behaviors), mouse_idx, B, ws.data_ptr(), ws_bytes, int(need_bwd), int(training), seed,
+                                out.data_ptr(), L.stream()),
+            "vit_forward",
+        )
+        ctx.core, ctx.ws, ctx.images, ctx.behaviors = core, ws, images, behaviors
+        ctx.mouse_idx, ctx.seed, ctx.training, ctx.B = mouse_idx, seed, training, B
+        core._last_ws = (ws, B, bool(need_bwd))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        core = ctx.core
+        lib = L.load()
+        gout = gout.contiguous()
+        core._arena.attach_grads()
+        sb = lib.v1t_vit_scratch_bytes(core._plan, ctx.B)
+        scratch = torch.empty(sb, dtype=torch.uint8, device=gout.device)
+        L.check(
+            lib.v1t_vit_backward(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), ctx.images.data_ptr(),
+                                 L.ptr(ctx.behaviors), ctx.mouse_idx, ctx.B, ctx.ws.data_ptr(), scratch.data_ptr(), sb,
+                                 int(ctx.training), ctx.seed, gout.data_ptr(), core._arena.grad.data_ptr(), L.stream()),
+            "vit_backward",
+        )
+        ctx.ws = None
+        return None, None, None, None, None, None
+
+
+class _L1Fn(torch.autograd.Function):
+    """scale * sum|p| over a flat arena; backward adds scale * sign(p) into the gradient arena."""
+
+    @staticmethod
+    def forward(ctx, arena: FlatArena, start: int, n: int, scale: float, anchor):
+        out = torch.zeros((), dtype=torch.float32, device=arena.data.device)
+        L.check(L.load().v1t_l1_sum(arena.data.data_ptr() + 4 * start, n, scale, out.data_ptr(), L.stream()), "l1_sum")
+        ctx.arena, ctx.start, ctx.n, ctx.scale = arena, start, n, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a = ctx.arena
+        a.attach_grads()
+        # g is a 0-dim tensor; the usual case is exactly 1 (or B_micro/B_full) — read it on the host only if needed
+        gs = float(g) if g.numel() == 1 else 1.0
+        L.check(L.load().v1t_l1_grad(a.data.data_ptr() + 4 * ctx.start, a.grad.data_ptr() + 4 * ctx.start, ctx.n, ctx.scale * gs, L.stream()), "l1_grad")
+        return None, None, None, None, None
+
+
+def _seq(*mods: nn.Module) -> nn.Sequential:
+    return nn.Sequential(*mods)
+
+
+class _ParamBag(nn.Module):
+    """Container whose only job is to hold parameters / sub-containers under the reference's names."""
+
+
+@register("vit")
+class ViTCore(Core):
+    """MI355X-native drop-in for the reference ViTCore (vit.py:365-436).
+
+    Reads the same `args` fields (vit.py:374-405): core_reg_scale, behavior_mode, patch_mode,
+    patch_size, patch_stride, emb_dim, p_dropout, num_blocks, num_heads, mlp_dim, t_dropout, use_lsa,
+    drop_path, disable_bias, output_shapes (mouse ids for behavior_mode 4). `grad_checkpointing` is
+    accepted and ignored: the fused attention never materialises (B,H,T,T), so there is nothing to
+    recompute (vit.py:277-284)."""
+
+    def __init__(self, args, input_shape: t.Tuple[int, int, int], name: str = "ViTCore"):
+        super().__init__(args, input_shape=input_shape, name=name)
+        self.register_buffer("reg_scale", torch.tensor(float(args.core_reg_scale)))
+        if not hasattr(args, "grad_checkpointing"):
+            args.grad_checkpointing = False
+        if args.patch_mode not in (0, 1, 2, 3):
+            raise NotImplementedError(f"--patch_mode {args.patch_mode} not implemented.")
+        if args.patch_mode in (2, 3):
+            raise NotImplementedError(f"--patch_mode {args.patch_mode} (SPT / dual PatchNorm) has no gfx950 kernel yet.")
+        if float(getattr(args, "drop_path", 0.0)) != 0.0:
+            raise NotImplementedError("drop_path > 0 has no gfx950 kernel yet (reference default is 0).")
+        assert 1 <= args.patch_stride <= args.patch_size
+        c, h, w = input_shape
+        self.mouse_ids = list(args.output_shapes.keys())
+        cfg = L.VitConfig(
+            in_channels=c, in_h=h, in_w=w, patch_size=args.patch_size, patch_stride=args.patch_stride,
+            patch_mode=args.patch_mode, emb_dim=args.emb_dim, num_heads=args.num_heads, mlp_dim=int(args.mlp_dim),
+            num_blocks=args.num_blocks, behavior_mode=self.behavior_mode if self.behavior_mode in (2, 3, 4) else 0,
+            num_mice=len(self.mouse_ids), use_lsa=int(bool(args.use_lsa)), use_bias=int(not args.disable_bias),
+            p_dropout=float(args.p_dropout), t_dropout=float(args.t_dropout), ln_eps=1e-5,
+        )
+        self._cfg = cfg
+        lib = L.load()
+        plan = C.c_void_p()
+        L.check(lib.v1t_vit_create(C.byref(cfg), C.byref(plan)), "vit_create")
+        self._plan = plan
+        self.num_tokens = lib.v1t_vit_tokens(plan)
+        self.padded_dim = lib.v1t_vit_padded_dim(plan)
+        self.emb_dim = args.emb_dim
+        gh, gw = lib.v1t_vit_grid_h(plan), lib.v1t_vit_grid_w(plan)
+        assert (gh, gw) == find_shape(self.num_tokens - 1)
+        self.output_shape = (args.emb_dim, gh, gw)
+
+        self._build_modules(args, c)
+        self._arena = self._make_arena()
+        self._shadow: t.Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._anchor = torch.zeros((), requires_grad=True)
+        self._seed_state = int(getattr(args, "seed", 1234)) * 1000003 + 12345
+        self._last_ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None):
+                L.load().v1t_vit_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def _build_modules(self, args, c: int) -> None:
+        D, H, M, P = args.emb_dim, args.num_heads, int(args.mlp_dim), args.patch_size
+        bias = not args.disable_bias
+        T = self.num_tokens
+        pe = _ParamBag()
+        if args.patch_mode == 0:
+            pe.projection = _seq(nn.Identity(), nn.Identity(), nn.Linear(c * P * P, D))  # key projection.2.* (vit.py:68-72)
+        else:
+            conv = nn.Conv2d(c, D, kernel_size=P, stride=args.patch_stride)  # key projection.0.* (vit.py:74-82)
+            nn.init.kaiming_normal_(conv.weight)
+            pe.projection = _seq(conv, nn.Identity())
+        pe.cls_token = nn.Parameter(torch.randn(1, 1, D))
+        pe.pos_embedding = nn.Parameter(torch.randn(T, D))
+        self.patch_embedding = pe
+
+        def lin(i, o, b=True):
+            m = nn.Linear(i, o, bias=b)
+            nn.init.trunc_normal_(m.weight, std=0.02)  # Transformer.init_weight vit.py:338-346
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+            return m
+
+        tr = _ParamBag()
+        tr.blocks = nn.ModuleList()
+        in_dim = 3 if self.behavior_mode == 2 else 5
+        for _ in range(args.num_blocks):
+            mha = _ParamBag()
+            mha.layer_norm = nn.LayerNorm(D)
+            mha.to_qkv = lin(D, 3 * H * D, False)
+            mha.projection = _seq(lin(H * D, D, bias), nn.Identity())
+            scale = D ** -0.5
+            if args.use_lsa:
+                mha.scale = nn.Parameter(torch.full((H,), scale))
+                mha.register_buffer("mask", torch.nonzero(torch.eye(T, T) == 1, as_tuple=False))
+                mha.register_buffer("max_value", torch.tensor(torch.finfo(torch.get_default_dtype()).max))
+            else:
+                mha.register_buffer("scale", torch.tensor(scale))
+            mlp = _ParamBag()
+            mlp.model = _seq(nn.LayerNorm(D), lin(D, M, bias), nn.Identity(), nn.Identity(), lin(M, D, bias), nn.Identity())
+            block = nn.ModuleDict({"mha": mha, "mlp": mlp})
+            if self.behavior_mode in (2, 3, 4):
+                bm = _ParamBag()
+                ids = self.mouse_ids if self.behavior_mode == 4 else ["share"]
+                bm.models = nn.ModuleDict(
+                    {m: _seq(lin(in_dim, D // 2, bias), nn.Identity(), nn.Identity(), lin(D // 2, D, bias), nn.Identity()) for m in ids}
+                )
+                block["b-mlp"] = bm
+            tr.blocks.append(block)
+        dp = _ParamBag()
+        dp.register_buffer("keep_prop", torch.tensor(1.0 - float(getattr(args, "drop_path", 0.0))))
+        tr.drop_path = dp
+        self.transformer = tr
+
+    def _make_arena(self) -> FlatArena:
+        lib = L.load()
+        n = lib.v1t_vit_num_tensors(self._plan)
+        named = dict(self.named_parameters())
+        named.update(dict(self.named_buffers()))
+        slots = []
+        name_buf = C.create_string_buffer(256)
+        off, nd, isp = C.c_longlong(), C.c_int(), C.c_int()
+        shape = (C.c_longlong * 4)()
+        for i in range(n):
+            L.check(lib.v1t_vit_tensor_info(self._plan, i, name_buf, 256, C.byref(off), C.byref(nd), shape, C.byref(isp)), "tensor_info")
+            key = name_buf.value.decode()
+            if "@" in key:  # per-mouse B-MLP: "models.@<i>" -> mouse id
+                pre, rest = key.split("@", 1)
+                idx, rest = rest.split(".", 1)
+                key = f"{pre}{self.mouse_ids[int(idx)]}.{rest}"
+            tns = named[key]
+            shp = tuple(shape[j] for j in range(nd.value))
+            assert tuple(tns.shape) == shp, (key, tuple(tns.shape), shp)
+            slots.append(Slot(tns, off.value, tns.numel(), (lambda st, s=shp: st.view(s)), bool(isp.value)))
+        assert {id(s.tensor) for s in slots if s.is_param} == {id(p) for p in self.parameters()}
+        return FlatArena(slots, lib.v1t_vit_arena_floats(self._plan), lib.v1t_vit_param_floats(self._plan))
+
+    def _next_seed(self) -> int:
+        self._seed_state = (self._seed_state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return self._seed_state
+
+    def prepare(self) -> None:
+        """Make sure parameters live in the flat arena on their current device and the bf16 weight
+        shadow matches their current values (after .to(), load_state_dict, or an optimizer step)."""
+        a = self._arena
+        a.ensure()
+        if self._anchor.device != a.data.device:
+            self._anchor = torch.zeros((), device=a.data.device, requires_grad=True)
+        key = (a.generation, a.version())
+        if self._shadow is None or self._shadow.device != a.data.device:
+            self._shadow = torch.empty(L.load().v1t_vit_shadow_bytes(self._plan), dtype=torch.uint8, device=a.data.device)
+            self._packed_key = None
+        if key != self._packed_key:
+            L.check(L.load().v1t_vit_pack(self._plan, a.data.data_ptr(), self._shadow.data_ptr(), L.stream()), "vit_pack")
+            self._packed_key = key
+
+    def mark_updated(self) -> None:
+        """Call after parameters were changed through raw pointers (fused optimizer)."""
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ reference interface
+    def regularizer(self):
+        """L1 over ALL core parameters (vit.py:419-421), computed by a HIP reduction over the arena."""
+        self.prepare()
+        a = self._arena
+        return _L1Fn.apply(a, 0, a.param_floats, float(self.reg_scale), self._anchor)
+
+    def forward_tokens(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor) -> torch.Tensor:
+        """Token-major residual stream (B, T, DP) fp32 (CLS at t=0, columns >= emb_dim are zero)."""
+        L.require_cuda(inputs, "ViTCore.forward")
+        if inputs.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the core input (image shifter, shift_mode 1/3/4) has no gfx950 kernel yet")
+        self.prepare()
+        inputs = inputs.to(torch.float32).contiguous()
+        if tuple(inputs.shape[1:]) != tuple(self.input_shape):
+            raise RuntimeError(f"ViTCore: expected input (B, {self.input_shape}), got {tuple(inputs.shape)}")
+        beh = None
+        if self.behavior_mode in (3, 4):
+            beh = torch.cat((behaviors, pupil_centers), dim=-1).to(torch.float32).contiguous()
+        elif self.behavior_mode == 2:
+            beh = behaviors.to(torch.float32).contiguous()
+        midx = self.mouse_ids.index(mouse_id) if self.behavior_mode == 4 else 0
+        self._anchor.requires_grad_(any(p.requires_grad for p in (self.patch_embedding.cls_token,)) and not self.frozen)
+        need_bwd = torch.is_grad_enabled() and self._anchor.requires_grad
+        return _VitFn.apply(self, inputs, beh, midx, self._anchor, need_bwd)
+
+    def forward(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor):
+        tokens = self.forward_tokens(inputs, mouse_id, behaviors, pupil_centers)
+        c, h, w = self.output_shape
+        # (B, C', h, w) exactly like vit.py:434-435, as a zero-copy strided view of the token-major buffer
+        out = tokens[:, 1:, :c].unflatten(1, (h, w)).permute(0, 3, 1, 2)
+        out._v1t_tokens = tokens  # lets the native readout skip the view chain (and its backward kernels)
+        return out
+
+    def workspace_tensor(self, name: str, block: int = 0) -> torch.Tensor:
+        """Debug / test access to an intermediate of the LAST forward (see v1t_vit_workspace_offset)."""
+        ws, B, save = self._last_ws
+        off = L.load().v1t_vit_workspace_offset(self._plan, B, int(save), name.encode(), block)
+        if off < 0:
+            raise KeyError(name)
+        return ws[off:]

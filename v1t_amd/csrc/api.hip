@@ -1,0 +1,698 @@
+// v1t_amd — C-ABI implementation: plan (dims, arena / shadow / workspace layouts) and the launch
+// sequences of the ViT core forward/backward. See include/v1t_amd.h for the contract.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/v1t_amd.h"
+#include "attention.h"
+#include "elementwise.h"
+#include "gemm.h"
+#include "readout.h"
+
+namespace {
+
+struct TensorInfo {
+    std::string name;
+    long long off;
+    int ndim;
+    long long shape[4];
+    bool is_param;
+    long long numel() const {
+        long long n = 1;
+        for (int i = 0; i < ndim; ++i) n *= shape[i];
+        return n;
+    }
+};
+
+struct BmlpOff {
+    long long w1, b1, w3, b3;
+};
+struct BlockOff {
+    long long ln1w, ln1b, qkv, proj, projb, scale, ln2w, ln2b, fc1, fc1b, fc2, fc2b;
+    std::vector<BmlpOff> bmlp;
+    // shadow (bytes)
+    long long s_qkv, s_qkv_t, s_proj, s_proj_t, s_fc1, s_fc1_t, s_fc2, s_fc2_t, s_projb, s_fc1b, s_fc2b;
+};
+
+inline long long align_up(long long x, long long a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct v1t_vit {
+    v1t_vit_config c;
+    int C, IH, IW, P, S, NH, NW, L, T, D, DP, H, HD, HDP, M, MP, NB, IN, J, PD;
+    int gh, gw;
+    bool inject;
+    int nbmlp;
+    std::vector<TensorInfo> tensors;
+    long long arena_floats, param_floats;
+    long long o_cls, o_pos, o_pw, o_pb;
+    std::vector<BlockOff> blk;
+    long long shadow_bytes;
+    std::vector<PackDesc> pack;
+    mutable PackDesc* d_pack;  // uploaded lazily by the first v1t_vit_pack (create works without a GPU)
+
+    long long add(const std::string& name, std::initializer_list<long long> shape, bool is_param, long long& cursor) {
+        TensorInfo t;
+        t.name = name;
+        t.off = cursor;
+        t.ndim = (int)shape.size();
+        int i = 0;
+        for (auto s : shape) t.shape[i++] = s;
+        for (; i < 4; ++i) t.shape[i] = 1;
+        t.is_param = is_param;
+        cursor += t.numel();
+        tensors.push_back(t);
+        return t.off;
+    }
+};
+
+namespace {
+
+// -------------------------------------------------------------------------- workspace layout
+struct WsLayout {
+    long long x0, beta, hid;
+    // per block
+    long long blk_stride, xa, xm, xo, z1, qkv, o, lse2, mean1, rstd1, z2, mean2, rstd2, hpre, hact;
+    long long total;
+};
+
+WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
+    WsLayout w;
+    const long long R = (long long)B * h->T;
+    long long cur = 0;
+    auto take = [&](long long bytes) {
+        const long long o = cur;
+        cur = align_up(cur + bytes, 256);
+        return o;
+    };
+    w.x0 = take(R * h->DP * 4);
+    w.beta = take((long long)h->NB * B * h->DP * 4);
+    w.hid = take((long long)h->NB * B * std::max(h->J, 1) * 4);
+    const long long b0 = cur;
+    w.xa = take(R * h->DP * 4) - b0;
+    w.xm = take(R * h->DP * 4) - b0;
+    w.xo = take(R * h->DP * 4) - b0;
+    w.z1 = take(R * h->DP * 2) - b0;
+    w.qkv = take(R * 3 * h->HDP * 2) - b0;
+    w.o = take(R * h->HDP * 2) - b0;
+    w.lse2 = take((long long)B * h->H * h->T * 4) - b0;
+    w.mean1 = take(R * 4) - b0;
+    w.rstd1 = take(R * 4) - b0;
+    w.z2 = take(R * h->DP * 2) - b0;
+    w.mean2 = take(R * 4) - b0;
+    w.rstd2 = take(R * 4) - b0;
+    w.hpre = take(R * h->MP * 2) - b0;
+    w.hact = take(R * h->MP * 2) - b0;
+    w.blk_stride = cur - b0;
+    w.total = b0 + (save ? (long long)h->NB : 1LL) * w.blk_stride;
+    w.xa += b0; w.xm += b0; w.xo += b0; w.z1 += b0; w.qkv += b0; w.o += b0; w.lse2 += b0;
+    w.mean1 += b0; w.rstd1 += b0; w.z2 += b0; w.mean2 += b0; w.rstd2 += b0; w.hpre += b0; w.hact += b0;
+    return w;
+}
+
+struct ScratchLayout {
+    long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, total;
+};
+ScratchLayout scratch_layout(const v1t_vit* h, int B) {
+    ScratchLayout s;
+    const long long R = (long long)B * h->T;
+    long long cur = 0;
+    auto take = [&](long long bytes) {
+        const long long o = cur;
+        cur = align_up(cur + bytes, 256);
+        return o;
+    };
+    s.G = take(R * h->DP * 4);
+    s.dy = take(R * h->DP * 2);
+    s.dhpre = take(R * h->MP * 2);
+    s.dz = take(R * h->DP * 4);
+    s.dO = take(R * h->HDP * 2);
+    s.delta = take((long long)B * h->H * h->T * 4);
+    s.dqkv = take(R * 3 * h->HDP * 2);
+    s.dbeta = take((long long)h->NB * B * h->DP * 4);
+    s.total = cur;
+    return s;
+}
+
+DropCfg make_drop(bool training, float p, uint64_t seed, uint32_t stream) {
+    DropCfg d;
+    d.key = drop_key(seed, stream);
+    d.thresh = 0;
+    d.inv_keep = 1.f;
+    if (training && p > 0.f) {
+        double t = std::floor((double)p * 4294967296.0 + 0.5);
+        if (t > 4294967295.0) t = 4294967295.0;
+        d.thresh = (uint32_t)t;
+        if (d.thresh == 0) d.thresh = 1;
+        d.inv_keep = (float)(1.0 / (1.0 - (double)p));
+    }
+    return d;
+}
+
+// V1T_DEBUG_SYNC=1: print the launch about to be made and synchronise after it (fault localisation).
+static const bool g_debug_sync = std::getenv("V1T_DEBUG_SYNC") != nullptr;
+#define CHECK(x)                                                                      \
+    do {                                                                              \
+        if (g_debug_sync) { std::fprintf(stderr, "[v1t] %s:%d %s\n", __func__, __LINE__, #x); std::fflush(stderr); } \
+        const int _e = (x);                                                           \
+        if (_e != V1T_OK) return _e;                                                  \
+        if (g_debug_sync && hipDeviceSynchronize() != hipSuccess) { std::fprintf(stderr, "[v1t] FAILED after %s\n", #x); return V1T_ERR_LAUNCH; } \
+    } while (0)
+
+int find_shape(int n, int* h, int* w) {
+    int d1 = (int)std::ceil(std::sqrt((double)n));
+    while (d1 > 0 && n % d1 != 0) --d1;
+    *h = d1;
+    *w = n / d1;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int v1t_abi_version(void) { return 1; }
+
+const char* v1t_error_string(int code) {
+    switch (code) {
+        case V1T_OK: return "ok";
+        case V1T_ERR_ARG: return "invalid argument";
+        case V1T_ERR_UNSUPPORTED: return "configuration not supported by the gfx950 kernels";
+        case V1T_ERR_LAUNCH: return "HIP kernel launch failed";
+        case V1T_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}
+
+int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
+    if (!cfg || !out) return V1T_ERR_ARG;
+    if (cfg->patch_mode != 0 && cfg->patch_mode != 1) return V1T_ERR_UNSUPPORTED;
+    if (cfg->patch_stride < 1 || cfg->patch_stride > cfg->patch_size) return V1T_ERR_ARG;
+    if (cfg->behavior_mode != 0 && cfg->behavior_mode != 2 && cfg->behavior_mode != 3 && cfg->behavior_mode != 4) return V1T_ERR_ARG;
+    v1t_vit* h = new v1t_vit();
+    h->c = *cfg;
+    h->C = cfg->in_channels; h->IH = cfg->in_h; h->IW = cfg->in_w; h->P = cfg->patch_size; h->S = cfg->patch_stride;
+    h->NH = (h->IH - h->P) / h->S + 1;
+    h->NW = (h->IW - h->P) / h->S + 1;
+    if (h->NH < 1 || h->NW < 1) { delete h; return V1T_ERR_ARG; }
+    h->L = h->NH * h->NW; h->T = h->L + 1;
+    h->D = cfg->emb_dim; h->DP = round_up(h->D, 32);
+    h->H = cfg->num_heads; h->HD = h->H * h->D; h->HDP = h->H * h->DP;
+    h->M = cfg->mlp_dim; h->MP = round_up(h->M, 32);
+    h->NB = cfg->num_blocks;
+    h->inject = cfg->behavior_mode == 2 || cfg->behavior_mode == 3 || cfg->behavior_mode == 4;
+    h->IN = cfg->behavior_mode == 2 ? 3 : 5;
+    h->J = h->D / 2;
+    h->PD = h->C * h->P * h->P;
+    h->nbmlp = cfg->behavior_mode == 4 ? std::max(cfg->num_mice, 1) : 1;
+    if (h->DP > 160 || (h->DP != 32 && h->DP != 64 && h->DP != 96 && h->DP != 128 && h->DP != 160)) { delete h; return V1T_ERR_UNSUPPORTED; }
+    find_shape(h->L, &h->gh, &h->gw);
+
+    // ---- parameter arena (natural shapes, reference state-dict names)
+    long long cur = 0;
+    const bool bias = cfg->use_bias != 0;
+    h->o_cls = h->add("patch_embedding.cls_token", {1, 1, h->D}, true, cur);
+    h->o_pos = h->add("patch_embedding.pos_embedding", {h->T, h->D}, true, cur);
+    if (cfg->patch_mode == 0) {
+        h->o_pw = h->add("patch_embedding.projection.2.weight", {h->D, h->PD}, true, cur);
+        h->o_pb = h->add("patch_embedding.projection.2.bias", {h->D}, true, cur);
+    } else {
+        h->o_pw = h->add("patch_embedding.projection.0.weight", {h->D, h->C, h->P, h->P}, true, cur);
+        h->o_pb = h->add("patch_embedding.projection.0.bias", {h->D}, true, cur);
+    }
+    h->blk.resize(h->NB);
+    for (int k = 0; k < h->NB; ++k) {
+        BlockOff& b = h->blk[k];
+        const std::string p = "transformer.blocks." + std::to_string(k) + ".";
+        b.ln1w = h->add(p + "mha.layer_norm.weight", {h->D}, true, cur);
+        b.ln1b = h->add(p + "mha.layer_norm.bias", {h->D}, true, cur);
+        b.qkv = h->add(p + "mha.to_qkv.weight", {3LL * h->HD, h->D}, true, cur);
+        b.proj = h->add(p + "mha.projection.0.weight", {h->D, h->HD}, true, cur);
+        b.projb = bias ? h->add(p + "mha.projection.0.bias", {h->D}, true, cur) : -1;
+        b.scale = cfg->use_lsa ? h->add(p + "mha.scale", {h->H}, true, cur) : -1;
+        b.ln2w = h->add(p + "mlp.model.0.weight", {h->D}, true, cur);
+        b.ln2b = h->add(p + "mlp.model.0.bias", {h->D}, true, cur);
+        b.fc1 = h->add(p + "mlp.model.1.weight", {h->M, h->D}, true, cur);
+        b.fc1b = bias ? h->add(p + "mlp.model.1.bias", {h->M}, true, cur) : -1;
+        b.fc2 = h->add(p + "mlp.model.4.weight", {h->D, h->M}, true, cur);
+        b.fc2b = bias ? h->add(p + "mlp.model.4.bias", {h->D}, true, cur) : -1;
+        if (h->inject) {
+            b.bmlp.resize(h->nbmlp);
+            for (int m = 0; m < h->nbmlp; ++m) {
+                const std::string q = p + "b-mlp.models." + (cfg->behavior_mode == 4 ? "@" + std::to_string(m) : std::string("share")) + ".";
+                b.bmlp[m].w1 = h->add(q + "0.weight", {h->J, h->IN}, true, cur);
+                b.bmlp[m].b1 = bias ? h->add(q + "0.bias", {h->J}, true, cur) : -1;
+                b.bmlp[m].w3 = h->add(q + "3.weight", {h->D, h->J}, true, cur);
+                b.bmlp[m].b3 = bias ? h->add(q + "3.bias", {h->D}, true, cur) : -1;
+            }
+        }
+    }
+    h->param_floats = cur;
+    if (!cfg->use_lsa)
+        for (int k = 0; k < h->NB; ++k)
+            h->blk[k].scale = h->add("transformer.blocks." + std::to_string(k) + ".mha.scale", {}, false, cur);
+    h->arena_floats = cur;
+
+    // ---- shadow layout + pack table
+    long long sc = 0;
+    auto stake = [&](long long bytes) {
+        const long long o = sc;
+        sc = align_up(sc + bytes, 256);
+        return o;
+    };
+    auto desc = [&](long long src, int src_ld, long long dst, int drows, int dcols, int rp, int rv, int cp, int cv, int tr, int f32) {
+        PackDesc d;
+        d.src_off = src; d.dst_off = dst; d.src_ld = src_ld; d.drows = drows; d.dcols = dcols;
+        d.rseg_pad = rp; d.rseg_valid = rv; d.cseg_pad = cp; d.cseg_valid = cv; d.transpose = tr; d.out_f32 = f32;
+        h->pack.push_back(d);
+    };
+    for (int k = 0; k < h->NB; ++k) {
+        BlockOff& b = h->blk[k];
+        const int DP = h->DP, D = h->D, MP = h->MP, M = h->M, HDP = h->HDP;
+        b.s_qkv = stake(3LL * HDP * DP * 2);   desc(b.qkv, D, b.s_qkv, 3 * HDP, DP, DP, D, DP, D, 0, 0);
+        b.s_qkv_t = stake(3LL * HDP * DP * 2); desc(b.qkv, D, b.s_qkv_t, DP, 3 * HDP, DP, D, DP, D, 1, 0);
+        b.s_proj = stake((long long)DP * HDP * 2);   desc(b.proj, h->HD, b.s_proj, DP, HDP, DP, D, DP, D, 0, 0);
+        b.s_proj_t = stake((long long)DP * HDP * 2); desc(b.proj, h->HD, b.s_proj_t, HDP, DP, DP, D, DP, D, 1, 0);
+        b.s_fc1 = stake((long long)MP * DP * 2);   desc(b.fc1, D, b.s_fc1, MP, DP, MP, M, DP, D, 0, 0);
+        b.s_fc1_t = stake((long long)MP * DP * 2); desc(b.fc1, D, b.s_fc1_t, DP, MP, MP, M, DP, D, 1, 0);
+        b.s_fc2 = stake((long long)DP * MP * 2);   desc(b.fc2, M, b.s_fc2, DP, MP, DP, D, MP, M, 0, 0);
+        b.s_fc2_t = stake((long long)DP * MP * 2); desc(b.fc2, M, b.s_fc2_t, MP, DP, DP, D, MP, M, 1, 0);
+        b.s_projb = b.s_fc1b = b.s_fc2b = -1;
+        if (bias) {
+            b.s_projb = stake(DP * 4); desc(b.projb, D, b.s_projb, 1, DP, 1, 1, DP, D, 0, 1);
+            b.s_fc1b = stake(MP * 4);  desc(b.fc1b, M, b.s_fc1b, 1, MP, 1, 1, MP, M, 0, 1);
+            b.s_fc2b = stake(DP * 4);  desc(b.fc2b, D, b.s_fc2b, 1, DP, 1, 1, DP, D, 0, 1);
+        }
+    }
+    h->shadow_bytes = std::max<long long>(sc, 256);
+    h->d_pack = nullptr;
+    *out = h;
+    return V1T_OK;
+}
+
+void v1t_vit_destroy(v1t_vit* h) {
+    if (!h) return;
+    if (h->d_pack) (void)hipFree(h->d_pack);
+    delete h;
+}
+
+long long v1t_vit_arena_floats(const v1t_vit* h) { return h->arena_floats; }
+long long v1t_vit_param_floats(const v1t_vit* h) { return h->param_floats; }
+int v1t_vit_num_tensors(const v1t_vit* h) { return (int)h->tensors.size(); }
+int v1t_vit_tensor_info(const v1t_vit* h, int idx, char* name, int name_cap, long long* offset, int* ndim, long long* shape4, int* is_param) {
+    if (idx < 0 || idx >= (int)h->tensors.size()) return V1T_ERR_ARG;
+    const TensorInfo& t = h->tensors[idx];
+    if (name && name_cap > 0) {
+        std::strncpy(name, t.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (offset) *offset = t.off;
+    if (ndim) *ndim = t.ndim;
+    if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = t.shape[i];
+    if (is_param) *is_param = t.is_param ? 1 : 0;
+    return V1T_OK;
+}
+int v1t_vit_tokens(const v1t_vit* h) { return h->T; }
+int v1t_vit_padded_dim(const v1t_vit* h) { return h->DP; }
+int v1t_vit_grid_h(const v1t_vit* h) { return h->gh; }
+int v1t_vit_grid_w(const v1t_vit* h) { return h->gw; }
+long long v1t_vit_shadow_bytes(const v1t_vit* h) { return h->shadow_bytes; }
+long long v1t_vit_workspace_bytes(const v1t_vit* h, int batch, int save) { return ws_layout(h, batch, save != 0).total; }
+long long v1t_vit_scratch_bytes(const v1t_vit* h, int batch) { return scratch_layout(h, batch).total; }
+
+long long v1t_vit_workspace_offset(const v1t_vit* h, int batch, int save, const char* name, int block) {
+    const WsLayout w = ws_layout(h, batch, save != 0);
+    const long long bo = (save ? block : 0) * w.blk_stride;
+    const std::string n(name);
+    if (n == "x0") return w.x0;
+    if (n == "beta") return w.beta + (long long)block * batch * h->DP * 4;
+    if (n == "xa") return w.xa + bo;
+    if (n == "xm") return w.xm + bo;
+    if (n == "xo") return w.xo + bo;
+    if (n == "z1") return w.z1 + bo;
+    if (n == "qkv") return w.qkv + bo;
+    if (n == "o") return w.o + bo;
+    if (n == "lse2") return w.lse2 + bo;
+    if (n == "z2") return w.z2 + bo;
+    if (n == "hpre") return w.hpre + bo;
+    if (n == "hact") return w.hact + bo;
+    return -1;
+}
+
+int v1t_vit_pack(const v1t_vit* h, const float* arena, void* shadow, void* stream) {
+    if (!h || !arena || !shadow) return V1T_ERR_ARG;
+    if (!h->d_pack && !h->pack.empty()) {  // one-time upload of the pack table (setup path, never inside a graph capture)
+        PackDesc* d = nullptr;
+        if (hipMalloc((void**)&d, sizeof(PackDesc) * h->pack.size()) != hipSuccess) return V1T_ERR_LAUNCH;
+        if (hipMemcpy(d, h->pack.data(), sizeof(PackDesc) * h->pack.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return V1T_ERR_LAUNCH;
+        }
+        h->d_pack = d;
+    }
+    return launch_pack(arena, shadow, h->d_pack, (int)h->pack.size(), (hipStream_t)stream);
+}
+
+int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, const float* images, const float* behaviors,
+                    int mouse_idx, int B, void* workspace, long long ws_bytes, int save, int training, uint64_t seed,
+                    float* out, void* stream) {
+    if (!h || !arena || !shadow || !images || !workspace || !out || B <= 0) return V1T_ERR_ARG;
+    if (h->inject && !behaviors) return V1T_ERR_ARG;
+    const WsLayout w = ws_layout(h, B, save != 0);
+    if (ws_bytes < w.total) return V1T_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const char* sh = (const char*)shadow;
+    const int R = B * h->T, DP = h->DP, D = h->D, HDP = h->HDP, MP = h->MP;
+    const bool train = training != 0;
+    const int bm = (h->c.behavior_mode == 4) ? mouse_idx : 0;
+    if (bm < 0 || bm >= h->nbmlp) return V1T_ERR_ARG;
+
+    // patch embedding -> x0
+    PatchArgs pa{};
+    pa.img = images; pa.B = B; pa.C = h->C; pa.IH = h->IH; pa.IW = h->IW; pa.P = h->P; pa.stride = h->S; pa.NH = h->NH; pa.NW = h->NW;
+    pa.D = D; pa.DP = DP; pa.W = arena + h->o_pw; pa.bias = arena + h->o_pb; pa.cls = arena + h->o_cls; pa.pos = arena + h->o_pos;
+    float* xcur = (h->NB == 0) ? out : (float*)(ws + w.x0);
+    pa.x = xcur;
+    pa.drop = make_drop(train, h->c.p_dropout, seed, 0xFFFFu);
+    CHECK(launch_patch_embed_fwd(pa, s));
+
+    if (h->inject)
+        for (int k = 0; k < h->NB; ++k) {
+            const BmlpOff& bo = h->blk[k].bmlp[bm];
+            BmlpArgs ba{};
+            ba.v = behaviors; ba.B = B; ba.IN = h->IN; ba.J = h->J; ba.D = D; ba.DP = DP;
+            ba.W1 = arena + bo.w1; ba.b1 = bo.b1 >= 0 ? arena + bo.b1 : nullptr;
+            ba.W3 = arena + bo.w3; ba.b3 = bo.b3 >= 0 ? arena + bo.b3 : nullptr;
+            ba.hid = (float*)(ws + w.hid) + (size_t)k * B * h->J;
+            ba.out = (float*)(ws + w.beta) + (size_t)k * B * DP;
+            CHECK(launch_bmlp_fwd(ba, s));
+        }
+
+    for (int k = 0; k < h->NB; ++k) {
+        const BlockOff& b = h->blk[k];
+        char* wb = ws + (save ? k : 0) * w.blk_stride;
+        float* xa = h->inject ? (float*)(wb + w.xa) : xcur;
+        float* xm = (float*)(wb + w.xm);
+        float* xo = (k == h->NB - 1) ? out : (float*)(wb + w.xo);
+        bf16_t* z1 = (bf16_t*)(wb + w.z1);
+        bf16_t* qkv = (bf16_t*)(wb + w.qkv);
+        bf16_t* o = (bf16_t*)(wb + w.o);
+        bf16_t* z2 = (bf16_t*)(wb + w.z2);
+        bf16_t* hpre = (bf16_t*)(wb + w.hpre);
+        bf16_t* hact = (bf16_t*)(wb + w.hact);
+
+        LnFwdArgs l1{};
+        l1.x = xcur; l1.inject = h->inject ? (float*)(ws + w.beta) + (size_t)k * B * DP : nullptr; l1.xout = xa;
+        l1.gamma = arena + b.ln1w; l1.beta = arena + b.ln1b; l1.z = z1;
+        l1.mean = (float*)(wb + w.mean1); l1.rstd = (float*)(wb + w.rstd1);
+        l1.rows = R; l1.T = h->T; l1.D = D; l1.DP = DP; l1.eps = h->c.ln_eps;
+        CHECK(launch_ln_fwd(l1, s));
+
+        GemmNTArgs g{};
+        g.A = z1; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_qkv); g.ldb = DP; g.M = R; g.N = 3 * HDP; g.K = DP; g.C = qkv; g.ldc = 3 * HDP;
+        CHECK(launch_gemm_nt(g, EPI_BF16, s));
+
+        AttnArgs at{};
+        at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = o; at.ldo = HDP; at.lse2 = (float*)(wb + w.lse2);
+        at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
+        at.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 0);
+        CHECK(launch_attn_fwd(at, DP, s));
+
+        g = GemmNTArgs{};
+        g.A = o; g.lda = HDP; g.B = (const bf16_t*)(sh + b.s_proj); g.ldb = HDP; g.M = R; g.N = DP; g.K = HDP; g.C = xm; g.ldc = DP;
+        g.bias = b.s_projb >= 0 ? (const float*)(sh + b.s_projb) : nullptr; g.res = xa; g.ldres = DP;
+        g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 1);
+        CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));
+
+        LnFwdArgs l2{};
+        l2.x = xm; l2.inject = nullptr; l2.xout = nullptr; l2.gamma = arena + b.ln2w; l2.beta = arena + b.ln2b; l2.z = z2;
+        l2.mean = (float*)(wb + w.mean2); l2.rstd = (float*)(wb + w.rstd2);
+        l2.rows = R; l2.T = h->T; l2.D = D; l2.DP = DP; l2.eps = h->c.ln_eps;
+        CHECK(launch_ln_fwd(l2, s));
+
+        g = GemmNTArgs{};
+        g.A = z2; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_fc1); g.ldb = DP; g.M = R; g.N = MP; g.K = DP; g.C = hpre; g.ldc = MP;
+        g.C2 = hact; g.ldc2 = MP; g.bias = b.s_fc1b >= 0 ? (const float*)(sh + b.s_fc1b) : nullptr;
+        g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
+        CHECK(launch_gemm_nt(g, EPI_BIAS_GELU, s));
+
+        g = GemmNTArgs{};
+        g.A = hact; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc2); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = xo; g.ldc = DP;
+        g.bias = b.s_fc2b >= 0 ? (const float*)(sh + b.s_fc2b) : nullptr; g.res = xm; g.ldres = DP;
+        g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 3);
+        CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));
+        xcur = xo;
+    }
+    return V1T_OK;
+}
+
+int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, const float* images, const float* behaviors,
+                     int mouse_idx, int B, const void* workspace, void* scratch, long long scratch_bytes, int training,
+                     uint64_t seed, const float* gout, float* grads, void* stream) {
+    if (!h || !arena || !shadow || !images || !workspace || !scratch || !gout || !grads || B <= 0) return V1T_ERR_ARG;
+    const WsLayout w = ws_layout(h, B, true);
+    const ScratchLayout sl = scratch_layout(h, B);
+    if (scratch_bytes < sl.total) return V1T_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const char* ws = (const char*)workspace;
+    char* sc = (char*)scratch;
+    const char* sh = (const char*)shadow;
+    const int R = B * h->T, DP = h->DP, D = h->D, HDP = h->HDP, MP = h->MP, M = h->M;
+    const bool train = training != 0;
+    const int bm = (h->c.behavior_mode == 4) ? mouse_idx : 0;
+    if (bm < 0 || bm >= h->nbmlp) return V1T_ERR_ARG;
+
+    float* G = (float*)(sc + sl.G);
+    bf16_t* dy = (bf16_t*)(sc + sl.dy);
+    bf16_t* dhpre = (bf16_t*)(sc + sl.dhpre);
+    float* dz = (float*)(sc + sl.dz);
+    bf16_t* dO = (bf16_t*)(sc + sl.dO);
+    float* delta = (float*)(sc + sl.delta);
+    bf16_t* dqkv = (bf16_t*)(sc + sl.dqkv);
+    float* dbeta = (float*)(sc + sl.dbeta);
+    if (h->inject && hipMemsetAsync(dbeta, 0, (size_t)h->NB * B * DP * 4, s) != hipSuccess) return V1T_ERR_LAUNCH;
+    // contraction rows per workgroup of the weight-gradient GEMMs: aim at >= ~512 workgroups
+    auto mchunk = [&](int tiles) {
+        int want = std::max(1, 512 / std::max(tiles, 1));
+        int mc = round_up((R + want - 1) / want, 32);
+        return std::max(mc, 128);
+    };
+
+    const float* gin = gout;
+    if (h->NB > 0) {
+        // entry of the last block's MLP branch: dy = dropout_bwd(gout) (bf16), db2 += colsum
+        const BlockOff& b = h->blk[h->NB - 1];
+        CastArgs ca{};
+        ca.g = gout; ca.dy = dy; ca.dbias = b.fc2b >= 0 ? grads + b.fc2b : nullptr;
+        ca.drop = make_drop(train, h->c.t_dropout, seed, 8 * (h->NB - 1) + 3);
+        ca.rows = R; ca.D = D; ca.DP = DP;
+        CHECK(launch_drop_cast(ca, s));
+    }
+    for (int k = h->NB - 1; k >= 0; --k) {
+        const BlockOff& b = h->blk[k];
+        const char* wb = ws + (long long)k * w.blk_stride;
+        const float* xa = h->inject ? (const float*)(wb + w.xa) : (k == 0 ? (const float*)(ws + w.x0) : (const float*)(ws + (long long)(k - 1) * w.blk_stride + w.xo));
+        const float* xm = (const float*)(wb + w.xm);
+        const bf16_t* z1 = (const bf16_t*)(wb + w.z1);
+        const bf16_t* qkv = (const bf16_t*)(wb + w.qkv);
+        const bf16_t* o = (const bf16_t*)(wb + w.o);
+        const bf16_t* z2 = (const bf16_t*)(wb + w.z2);
+        const bf16_t* hpre = (const bf16_t*)(wb + w.hpre);
+        const bf16_t* hact = (const bf16_t*)(wb + w.hact);
+
+        // ---- MLP branch: dW2 += dy^T hact
+        GemmTNArgs t{};
+        t.Y = dy; t.ldy = DP; t.X = hact; t.ldx = MP; t.M = R; t.NY = DP; t.NX = MP; t.dW = grads + b.fc2; t.ldw = M;
+        t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = MP; t.xseg_valid = M; t.alpha = 1.f;
+        t.m_chunk = mchunk(((DP + 127) / 128) * (MP / 128 > 0 ? MP / 128 : 1));
+        CHECK(launch_gemm_tn(t, s));
+        // d_hpre = (dy . W2) * mask * gelu'(hpre); db1 += colsum
+        GemmNTArgs g{};
+        g.A = dy; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_fc2_t); g.ldb = DP; g.M = R; g.N = MP; g.K = DP; g.C = dhpre; g.ldc = MP;
+        g.aux = hpre; g.ldaux = MP; g.colsum = b.fc1b >= 0 ? grads + b.fc1b : nullptr; g.n_valid = M;
+        g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
+        CHECK(launch_gemm_nt(g, EPI_DGELU, s));
+        // dW1 += d_hpre^T z2
+        t = GemmTNArgs{};
+        t.Y = dhpre; t.ldy = MP; t.X = z2; t.ldx = DP; t.M = R; t.NY = MP; t.NX = DP; t.dW = grads + b.fc1; t.ldw = D;
+        t.yseg_pad = MP; t.yseg_valid = M; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
+        t.m_chunk = mchunk((MP + 127) / 128);
+        CHECK(launch_gemm_tn(t, s));
+        // dz2 = d_hpre . W1
+        g = GemmNTArgs{};
+        g.A = dhpre; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc1_t); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = dz; g.ldc = DP;
+        CHECK(launch_gemm_nt(g, EPI_F32, s));
+        // LN2 backward: G = gin + dx; dy = dropout_bwd(G) for the projection output; dbo += colsum
+        LnBwdArgs lb{};
+        lb.dz = dz; lb.x = xm; lb.mean = (const float*)(wb + w.mean2); lb.rstd = (const float*)(wb + w.rstd2); lb.gamma = arena + b.ln2w;
+        lb.gin = gin; lb.gout = G; lb.dgamma = grads + b.ln2w; lb.dbeta = grads + b.ln2b; lb.dinject = nullptr;
+        lb.dy_next = dy; lb.dbias_next = b.projb >= 0 ? grads + b.projb : nullptr;
+        lb.drop_next = make_drop(train, h->c.t_dropout, seed, 8 * k + 1);
+        lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
+        CHECK(launch_ln_bwd(lb, s));
+        gin = G;
+
+        // ---- attention branch: dWo += dy^T o
+        t = GemmTNArgs{};
+        t.Y = dy; t.ldy = DP; t.X = o; t.ldx = HDP; t.M = R; t.NY = DP; t.NX = HDP; t.dW = grads + b.proj; t.ldw = h->HD;
+        t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
+        t.m_chunk = mchunk(((DP + 127) / 128) * h->H);
+        CHECK(launch_gemm_tn(t, s));
+        // dO = dy . Wo
+        g = GemmNTArgs{};
+        g.A = dy; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_proj_t); g.ldb = DP; g.M = R; g.N = HDP; g.K = DP; g.C = dO; g.ldc = HDP;
+        CHECK(launch_gemm_nt(g, EPI_BF16, s));
+        AttnArgs at{};
+        at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = (bf16_t*)o; at.ldo = HDP; at.lse2 = (float*)(wb + w.lse2);
+        at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
+        at.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 0);
+        at.dO = dO; at.lddo = HDP; at.delta = delta; at.dqkv = dqkv; at.lddqkv = 3 * HDP;
+        at.dscale = h->c.use_lsa ? grads + b.scale : nullptr;
+        CHECK(launch_attn_delta(at, DP, delta, s));
+        CHECK(launch_attn_bwd(at, DP, s));
+        // dWqkv += dqkv^T z1
+        t = GemmTNArgs{};
+        t.Y = dqkv; t.ldy = 3 * HDP; t.X = z1; t.ldx = DP; t.M = R; t.NY = 3 * HDP; t.NX = DP; t.dW = grads + b.qkv; t.ldw = D;
+        t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
+        t.m_chunk = mchunk((3 * HDP + 127) / 128);
+        CHECK(launch_gemm_tn(t, s));
+        // dz1 = dqkv . Wqkv
+        g = GemmNTArgs{};
+        g.A = dqkv; g.lda = 3 * HDP; g.B = (const bf16_t*)(sh + b.s_qkv_t); g.ldb = 3 * HDP; g.M = R; g.N = DP; g.K = 3 * HDP; g.C = dz; g.ldc = DP;
+        CHECK(launch_gemm_nt(g, EPI_F32, s));
+        // LN1 backward: G = G + dx; d(beta_k) = token sums; dy for block k-1's FC2 output
+        lb = LnBwdArgs{};
+        lb.dz = dz; lb.x = xa; lb.mean = (const float*)(wb + w.mean1); lb.rstd = (const float*)(wb + w.rstd1); lb.gamma = arena + b.ln1w;
+        lb.gin = G; lb.gout = G; lb.dgamma = grads + b.ln1w; lb.dbeta = grads + b.ln1b;
+        lb.dinject = h->inject ? dbeta + (size_t)k * B * DP : nullptr;
+        if (k > 0) {
+            lb.dy_next = dy;
+            lb.dbias_next = h->blk[k - 1].fc2b >= 0 ? grads + h->blk[k - 1].fc2b : nullptr;
+            lb.drop_next = make_drop(train, h->c.t_dropout, seed, 8 * (k - 1) + 3);
+        }
+        lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
+        CHECK(launch_ln_bwd(lb, s));
+    }
+    // ---- patch embedding backward (gin = grad wrt x0)
+    PatchArgs pa{};
+    pa.img = images; pa.B = B; pa.C = h->C; pa.IH = h->IH; pa.IW = h->IW; pa.P = h->P; pa.stride = h->S; pa.NH = h->NH; pa.NW = h->NW;
+    pa.D = D; pa.DP = DP; pa.x = (float*)gin;
+    pa.drop = make_drop(train, h->c.p_dropout, seed, 0xFFFFu);
+    pa.dW = grads + h->o_pw; pa.dbias = grads + h->o_pb; pa.dcls = grads + h->o_cls; pa.dpos = grads + h->o_pos;
+    CHECK(launch_patch_embed_bwd(pa, s));
+    // ---- BehaviorMLP backward
+    if (h->inject)
+        for (int k = 0; k < h->NB; ++k) {
+            const BmlpOff& bo = h->blk[k].bmlp[bm];
+            BmlpArgs ba{};
+            ba.v = behaviors; ba.B = B; ba.IN = h->IN; ba.J = h->J; ba.D = D; ba.DP = DP;
+            ba.W1 = arena + bo.w1; ba.W3 = arena + bo.w3;
+            ba.hid = (float*)(ws + w.hid) + (size_t)k * B * h->J;
+            ba.out = (float*)(ws + w.beta) + (size_t)k * B * DP;
+            ba.dout = dbeta + (size_t)k * B * DP;
+            ba.dW1 = grads + bo.w1; ba.db1 = bo.b1 >= 0 ? grads + bo.b1 : nullptr;
+            ba.dW3 = grads + bo.w3; ba.db3 = bo.b3 >= 0 ? grads + bo.b3 : nullptr;
+            CHECK(launch_bmlp_bwd(ba, s));
+        }
+    return V1T_OK;
+}
+
+int v1t_dropout_mask(uint64_t seed, uint32_t stream_id, float p, long long rows, long long cols, uint8_t* out, void* stream) {
+    if (!out || rows <= 0 || cols <= 0) return V1T_ERR_ARG;
+    return launch_dropout_mask(out, rows, cols, make_drop(true, p, seed, stream_id), (hipStream_t)stream);
+}
+
+int v1t_gaussian2d_forward(const float* z, long long zsb, long long zsc, int B, int C, int H, int W, int N, const float* grid,
+                           const float* feat, int FS, const float* bias, float* out, void* stream) {
+    if (!z || !grid || !feat || !out) return V1T_ERR_ARG;
+    ReadoutArgs a{};
+    a.z = z; a.zsb = zsb; a.zsc = zsc; a.B = B; a.C = C; a.H = H; a.W = W; a.N = N; a.grid = grid; a.feat = feat; a.FS = FS; a.bias = bias; a.out = out;
+    return launch_readout_fwd(a, (hipStream_t)stream);
+}
+
+int v1t_gaussian2d_backward(const float* z, long long zsb, long long zsc, int B, int C, int H, int W, int N, const float* grid,
+                            const float* feat, int FS, const float* gout, float* dz, long long dzsb, long long dzsc,
+                            float* dgrid, float* dfeat, float* dbias, void* stream) {
+    if (!z || !grid || !feat || !gout) return V1T_ERR_ARG;
+    ReadoutArgs a{};
+    a.z = z; a.zsb = zsb; a.zsc = zsc; a.B = B; a.C = C; a.H = H; a.W = W; a.N = N; a.grid = grid; a.feat = feat; a.FS = FS;
+    a.gout = gout; a.dz = dz; a.dzsb = dzsb; a.dzsc = dzsc; a.dgrid = dgrid; a.dfeat = dfeat; a.dbias = dbias;
+    return launch_readout_bwd(a, (hipStream_t)stream);
+}
+
+int v1t_elu1_poisson(const float* u, const float* y, long long n, float loss_scale, float gscale, float* yhat, float* du,
+                     float* loss, void* stream) {
+    if (!u || n < 0) return V1T_ERR_ARG;
+    LossArgs a{};
+    a.u = u; a.y = y; a.yhat = yhat; a.du = du; a.loss = loss; a.n = n; a.loss_scale = loss_scale; a.gscale = gscale;
+    return launch_elu1_poisson(a, (hipStream_t)stream);
+}
+
+int v1t_adamw_step(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float l1, int zero_grad, void* stream) {
+    if (!p || !g || !m || !v || step < 1) return V1T_ERR_ARG;
+    AdamArgs a{};
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.bc1 = (float)(1.0 - std::pow((double)beta1, step));
+    a.bc2 = (float)(1.0 - std::pow((double)beta2, step));
+    a.l1 = l1; a.zero_grad = zero_grad;
+    return launch_adamw(a, (hipStream_t)stream);
+}
+int v1t_l1_sum(const float* p, long long n, float scale, float* out, void* stream) { return launch_l1_sum(p, n, scale, out, (hipStream_t)stream); }
+int v1t_l1_grad(const float* p, float* g, long long n, float scale, void* stream) { return launch_l1_grad(p, g, n, scale, (hipStream_t)stream); }
+
+int v1t_gemm_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C, int ldc, int out_f32, void* stream) {
+    GemmNTArgs g{};
+    g.A = (const bf16_t*)A; g.lda = lda; g.B = (const bf16_t*)B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
+    return launch_gemm_nt(g, out_f32 ? EPI_F32 : EPI_BF16, (hipStream_t)stream);
+}
+int v1t_gemm_tn(const void* Y, int ldy, const void* X, int ldx, int M, int NY, int NX, float* dW, int ldw, int m_chunk, void* stream) {
+    GemmTNArgs t{};
+    t.Y = (const bf16_t*)Y; t.ldy = ldy; t.X = (const bf16_t*)X; t.ldx = ldx; t.M = M; t.NY = NY; t.NX = NX; t.dW = dW; t.ldw = ldw;
+    t.yseg_pad = NY; t.yseg_valid = NY; t.xseg_pad = NX; t.xseg_valid = NX; t.m_chunk = m_chunk; t.alpha = 1.f;
+    return launch_gemm_tn(t, (hipStream_t)stream);
+}
+int v1t_attention_forward(const void* qkv, int B, int H, int T, int DP, const float* scale, int scale_per_head, int mask_diag,
+                          float dropout_p, uint64_t seed, uint32_t stream_id, void* o, float* lse2, void* stream) {
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.o = (bf16_t*)o; a.ldo = H * DP; a.lse2 = lse2; a.B = B; a.H = H; a.T = T;
+    a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
+    a.drop = make_drop(dropout_p > 0.f, dropout_p, seed, stream_id);
+    return launch_attn_fwd(a, DP, (hipStream_t)stream);
+}
+int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const float* lse2, int B, int H, int T, int DP,
+                           const float* scale, int scale_per_head, int mask_diag, float dropout_p, uint64_t seed,
+                           uint32_t stream_id, float* delta_ws, void* dqkv, float* dscale, void* stream) {
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.o = (bf16_t*)o; a.ldo = H * DP; a.lse2 = (float*)lse2; a.B = B; a.H = H; a.T = T;
+    a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
+    a.drop = make_drop(dropout_p > 0.f, dropout_p, seed, stream_id);
+    a.dO = (const bf16_t*)dO; a.lddo = H * DP; a.delta = delta_ws; a.dqkv = (bf16_t*)dqkv; a.lddqkv = 3 * H * DP; a.dscale = dscale;
+    CHECK(launch_attn_delta(a, DP, delta_ws, (hipStream_t)stream));
+    return launch_attn_bwd(a, DP, (hipStream_t)stream);
+}
+
+int v1t_layernorm_forward(const float* x, const float* inject, float* xout, const float* gamma, const float* beta, void* z,
+                          float* mean, float* rstd, int B, int T, int D, int DP, float eps, void* stream) {
+    LnFwdArgs a{};
+    a.x = x; a.inject = inject; a.xout = xout; a.gamma = gamma; a.beta = beta; a.z = (bf16_t*)z; a.mean = mean; a.rstd = rstd;
+    a.rows = B * T; a.T = T; a.D = D; a.DP = DP; a.eps = eps;
+    return launch_ln_fwd(a, (hipStream_t)stream);
+}
+int v1t_layernorm_backward(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* gin, float* gout, float* dgamma, float* dbeta, float* dinject, void* dy_next,
+                           float* dbias_next, int B, int T, int D, int DP, void* stream) {
+    LnBwdArgs a{};
+    a.dz = dz; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.gin = gin; a.gout = gout; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.dinject = dinject; a.dy_next = (bf16_t*)dy_next; a.dbias_next = dbias_next; a.B = B; a.T = T; a.D = D; a.DP = DP;
+    return launch_ln_bwd(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,27 @@
+// v1t_amd — fused multi-head self-attention (flash-style, bf16 MFMA, fp32 online softmax), gfx950.
+// Replaces Attention.scaled_dot_product_attention (reference vit.py:253-265): head dim = emb dim
+// (vit.py:218), scores scaled by the `scale` buffer (or per-head LSA parameter with the diagonal
+// masked, vit.py:235-261), softmax, dropout on P, P.V. The (B,H,T,T) score tensor is never
+// materialised; the backward recomputes P from Q,K and the saved log2-sum-exp.
+#pragma once
+#include "common.h"
+
+struct AttnArgs {
+    const bf16_t* qkv; int ldqkv;  // [rows][3*H*DP]: q | k | v, each H heads of DP (zero padded) columns
+    bf16_t* o; int ldo;            // [rows][H*DP]
+    float* lse2;                   // [B][H][T]  log2-domain: max + log2(sum)
+    int B, H, T;
+    const float* scale;            // device: 1 value, or H values when scale_per_head
+    int scale_per_head;
+    int mask_diag;                 // LSA: exclude key == query
+    DropCfg drop;
+    // backward only
+    const bf16_t* dO; int lddo;    // [rows][H*DP]
+    const float* delta;            // [B][H][T] rowsum(dO * O)
+    bf16_t* dqkv; int lddqkv;      // [rows][3*H*DP]
+    float* dscale;                 // [H] fp32 atomics or nullptr (LSA scale gradient)
+};
+
+int launch_attn_fwd(const AttnArgs& a, int DP, hipStream_t s);
+int launch_attn_delta(const AttnArgs& a, int DP, float* delta, hipStream_t s);
+int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s);  // dq + dkv kernels

@@ -1,0 +1,133 @@
+// v1t_amd — device-side helpers shared by all gfx950 kernels.
+// Wave = 64 lanes; MFMA = v_mfma_f32_32x32x16_bf16 (A 32x16, B 16x32, C/D 32x32 fp32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define V1T_WAVE 64
+#define DEVFN __device__ __forceinline__
+
+// ---- error codes returned by the C-ABI (mapped to RuntimeError by the Python shim) ----
+#define V1T_OK 0
+#define V1T_ERR_ARG -1
+#define V1T_ERR_UNSUPPORTED -2
+#define V1T_ERR_LAUNCH -3
+#define V1T_ERR_WORKSPACE -4
+
+// ---- MFMA 32x32x16 bf16 -------------------------------------------------------------
+// Lane l (r = l&31, h = l>>5):  A[row r][k = 8h + j],  B[k = 8h + j][col r],  j = 0..7
+// C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5), reg = 0..15.
+DEVFN f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+DEVFN int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// An accumulator tile X (rows in registers, column on the lane) as the B operand of the next
+// MFMA that sums over X's ROW index: k-step s (0,1) takes registers 8s..8s+7; element j of lane
+// half h is row 16s + 8(j>>2) + 4h + (j&3) of X, so the A operand must use the same k order.
+DEVFN bf16x8 acc_to_b(const f32x16& x, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)x[8 * s + j];
+    return r;
+}
+
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-col block of 16-bit elements is delivered
+// column-major: lane 4q+p of the group supplies the address of row q, cols 4p..4p+3; lane i of the
+// group receives column i, rows 0..3. EXEC must be all ones.
+DEVFN bf16x4 lds_tr_read(const bf16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+
+// A operand (32 rows m x 16 k) read TRANSPOSED from an LDS image stored [k][m] (row = k index,
+// m contiguous), in the permuted k order that matches acc_to_b():
+//   element j of lane (m = l&31, h = l>>5)  <-  img[k0 + 16s + 8(j>>2) + 4h + (j&3)][m0 + m]
+// `stride` in elements. k0 already includes 16*s.
+DEVFN bf16x8 lds_tr_frag(const bf16_t* img, int stride, int k0, int m0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int h = g >> 1, q = i >> 2, p = i & 3;
+    const bf16_t* a = img + (k0 + 4 * h + q) * stride + m0 + 16 * (g & 1) + 4 * p;
+    bf16x4 lo = lds_tr_read(a);
+    bf16x4 hi = lds_tr_read(a + 8 * stride);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+// Same transposed read but in NATURAL k order (element j <- img[k0 + 8h + j][m0 + m]); used when
+// the other operand is also read from memory in natural order (TN GEMM).
+DEVFN bf16x8 lds_tr_frag_nat(const bf16_t* img, int stride, int k0, int m0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int h = g >> 1, q = i >> 2, p = i & 3;
+    const bf16_t* a = img + (k0 + 8 * h + q) * stride + m0 + 16 * (g & 1) + 4 * p;
+    bf16x4 lo = lds_tr_read(a);
+    bf16x4 hi = lds_tr_read(a + 4 * stride);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// ---- counter-based dropout ------------------------------------------------------------
+// keep(seed, stream, row, col): stateless 32-bit mix; the SAME function is evaluated by the
+// forward and the backward kernels and is exported through the C-ABI (v1t_dropout_mask) so that
+// the CPU oracle can replay the exact mask. thresh = round(p * 2^32); keep iff hash >= thresh.
+DEVFN uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline uint32_t drop_key(uint64_t seed, uint32_t stream) {
+    uint32_t x = (uint32_t)seed ^ (uint32_t)(seed >> 32) * 0x9E3779B9u;
+    x ^= stream * 0x85EBCA6Bu + 0x165667B1u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+DEVFN uint32_t drop_hash(uint32_t key, uint32_t row, uint32_t col) {
+    return mix32(key + row * 0x9E3779B1u + col * 0x85EBCA77u);
+}
+DEVFN bool drop_keep(uint32_t key, uint32_t row, uint32_t col, uint32_t thresh) {
+    return drop_hash(key, row, col) >= thresh;
+}
+struct DropCfg {
+    uint32_t key;     // drop_key(seed, stream)
+    uint32_t thresh;  // 0 => dropout disabled
+    float inv_keep;   // 1 / (1 - p)
+};
+
+DEVFN float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
+// ---- small math --------------------------------------------------------------------------
+DEVFN float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+DEVFN float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+DEVFN float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+DEVFN float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// XCD-aware bijective block-id remap (8 XCDs; blocks b and b+8 share an XCD's L2): gives each XCD
+// a contiguous chunk of the logical tile space so neighbouring tiles reuse operands in one L2.
+DEVFN int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

@@ -1,0 +1,111 @@
+// v1t_amd — HBM-bound kernels around the MFMA products (gfx950): weight packing, patch embedding,
+// LayerNorm fwd/bwd fused with the BehaviorMLP injection and the next branch's dropout/cast,
+// BehaviorMLP, fused L1 + AdamW, ELU1 + Poisson loss.
+#pragma once
+#include "common.h"
+
+// One entry of the weight-shadow pack table: dst (bf16 or fp32, padded / optionally transposed)
+// <- fp32 master (natural shape). Index maps: padded index i -> natural (i / pad) * valid + i % pad,
+// zero where i % pad >= valid.
+struct PackDesc {
+    long long src_off;  // floats into the parameter arena
+    long long dst_off;  // BYTES into the shadow arena
+    int src_ld;         // natural leading dimension (columns of the natural matrix)
+    int drows, dcols;   // padded dst shape
+    int rseg_pad, rseg_valid, cseg_pad, cseg_valid;  // maps in SOURCE orientation (rows, cols of the natural matrix)
+    int transpose;      // dst[r][c] = src[c][r]
+    int out_f32;
+};
+int launch_pack(const float* params, void* shadow, const PackDesc* d_desc, int ndesc, hipStream_t s);
+
+struct PatchArgs {
+    const float* img;  // [B][C][IH][IW]
+    int B, C, IH, IW, P, stride, NH, NW;  // NH x NW patch grid; L = NH*NW; T = L + 1
+    int D, DP;
+    const float* W;    // [D][C*P*P]
+    const float* bias; // [D]
+    const float* cls;  // [D]
+    const float* pos;  // [T][D]
+    float* x;          // [B*T][DP] fp32 out (fwd) / grad in (bwd)
+    DropCfg drop;
+    // backward accumulators (fp32, natural shapes)
+    float* dW; float* dbias; float* dcls; float* dpos;
+};
+int launch_patch_embed_fwd(const PatchArgs& a, hipStream_t s);
+int launch_patch_embed_bwd(const PatchArgs& a, hipStream_t s);
+
+struct LnFwdArgs {
+    const float* x;      // [rows][DP]
+    const float* inject; // [B][DP] or nullptr: x += inject[b] (written to xout)
+    float* xout;         // [rows][DP] (may alias x when inject == nullptr -> not written)
+    const float* gamma; const float* beta;  // [D] natural
+    bf16_t* z;           // [rows][DP]
+    float* mean; float* rstd;  // [rows]
+    int rows, T, D, DP;
+    float eps;
+};
+int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s);
+
+struct LnBwdArgs {
+    const float* dz;     // [rows][DP] grad wrt LN output (fp32)
+    const float* x;      // LN input
+    const float* mean; const float* rstd;
+    const float* gamma;  // [D]
+    const float* gin;    // [rows][DP] residual-stream grad flowing past the LN
+    float* gout;         // [rows][DP] = gin + dx
+    float* dgamma; float* dbeta;  // [D] atomics
+    float* dinject;      // [B][DP] atomics or nullptr: sum over the image's tokens of gout
+    bf16_t* dy_next;     // [rows][DP] bf16 = dropout_bwd(gout) for the next (earlier) branch, or nullptr
+    float* dbias_next;   // [D] atomics: column sums of dy_next, or nullptr
+    DropCfg drop_next;
+    int B, T, D, DP;
+};
+int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
+
+struct CastArgs {
+    const float* g;      // [rows][DP]
+    bf16_t* dy;          // [rows][DP]
+    float* dbias;        // [D] atomics or nullptr
+    DropCfg drop;
+    int rows, D, DP;
+};
+int launch_drop_cast(const CastArgs& a, hipStream_t s);
+
+struct BmlpArgs {
+    const float* v;      // [B][IN]
+    int B, IN, J, D, DP; // J = D/2 hidden
+    const float* W1; const float* b1;  // [J][IN], [J] (b may be nullptr)
+    const float* W3; const float* b3;  // [D][J], [D]
+    float* hid;          // [B][J]  tanh(hidden), saved
+    float* out;          // [B][DP] tanh(out), saved (pad = 0)
+    const float* dout;   // [B][DP]
+    float* dW1; float* db1; float* dW3; float* db3;
+};
+int launch_bmlp_fwd(const BmlpArgs& a, hipStream_t s);
+int launch_bmlp_bwd(const BmlpArgs& a, hipStream_t s);
+
+struct AdamArgs {
+    float* p; float* g; float* m; float* v;
+    long long n;
+    float lr, beta1, beta2, eps, weight_decay;
+    float bc1, bc2;      // 1 - beta^step
+    float l1;            // adds l1 * sign(p) to the gradient (folded L1 regulariser), 0 = off
+    int zero_grad;       // write 0 to g after use
+};
+int launch_adamw(const AdamArgs& a, hipStream_t s);
+int launch_l1_sum(const float* p, long long n, float scale, float* out_accum, hipStream_t s);
+int launch_l1_grad(const float* p, float* g, long long n, float scale, hipStream_t s);
+
+struct LossArgs {
+    const float* u;      // [B][N] readout pre-activation
+    const float* y;      // [B][N] targets
+    float* yhat;         // [B][N] or nullptr
+    float* du;           // [B][N] or nullptr: dLoss/du * gscale
+    float* loss;         // scalar accumulator (atomic) or nullptr
+    long long n;
+    float loss_scale;    // sqrt(ds_size / batch)
+    float gscale;        // upstream gradient of the loss (1 for plain training)
+};
+int launch_elu1_poisson(const LossArgs& a, hipStream_t s);
+
+int launch_dropout_mask(uint8_t* out, long long rows, long long cols, DropCfg d, hipStream_t s);

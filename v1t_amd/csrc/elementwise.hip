@@ -1,0 +1,563 @@
+// v1t_amd — HBM-bound kernels (gfx950). See elementwise.h.
+#include "elementwise.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+__global__ void pack_kernel(const float* __restrict__ params, char* shadow, const PackDesc* descs) {
+    const PackDesc d = descs[blockIdx.y];
+    const long long total = (long long)d.drows * d.dcols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / d.dcols), c = (int)(i % d.dcols);
+        const int pr = d.transpose ? c : r, pc = d.transpose ? r : c;
+        const int rs = pr / d.rseg_pad, rr = pr % d.rseg_pad;
+        const int cs = pc / d.cseg_pad, cr = pc % d.cseg_pad;
+        float v = 0.f;
+        if (rr < d.rseg_valid && cr < d.cseg_valid)
+            v = params[d.src_off + (long long)(rs * d.rseg_valid + rr) * d.src_ld + cs * d.cseg_valid + cr];
+        if (d.out_f32) ((float*)(shadow + d.dst_off))[i] = v;
+        else ((bf16_t*)(shadow + d.dst_off))[i] = (bf16_t)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Patch embedding (reference vit.py:66-72,122-128): x[b][0] = cls + pos[0];
+// x[b][1+l] = U[b][l] . Wp^T + bp + pos[1+l], U = unfold(k=P, s=stride) in (c,kh,kw) order; dropout.
+// fp32 VALU: 0.03 GFLOP/image, HBM/LDS-bound. Workgroup = 64 patches of one image; thread = output
+// channel d; the image (C*IH*IW floats) and Wp^T ([j][d], conflict-free across d) live in LDS and
+// patch pixels are LDS broadcasts.
+constexpr int PCHUNK = 64;
+
+__global__ __launch_bounds__(256) void patch_fwd_kernel(PatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int PD = a.C * a.P * a.P, L = a.NH * a.NW, T = L + 1;
+    float* sImg = smem;
+    float* sW = smem + a.C * a.IH * a.IW;
+    const int b = blockIdx.y, l0 = blockIdx.x * PCHUNK, tid = threadIdx.x;
+    const float* img = a.img + (size_t)b * a.C * a.IH * a.IW;
+    for (int i = tid; i < a.C * a.IH * a.IW; i += 256) sImg[i] = img[i];
+    for (int i = tid; i < PD * a.D; i += 256) {
+        const int d = i / PD, j = i % PD;  // coalesced read of W[d][j]
+        sW[j * a.D + d] = a.W[i];
+    }
+    __syncthreads();
+    const int d = tid;
+    if (d >= a.DP) return;
+    const bool dval = d < a.D;
+    if (blockIdx.x == 0) {
+        const int row = b * T;
+        float v = dval ? a.cls[d] + a.pos[d] : 0.f;
+        if (a.drop.thresh && dval) v = drop_keep(a.drop.key, row, d, a.drop.thresh) ? v * a.drop.inv_keep : 0.f;
+        a.x[(size_t)row * a.DP + d] = v;
+    }
+    const int np = min(PCHUNK, L - l0);
+    const float bias = dval ? a.bias[d] : 0.f;
+    for (int p0 = 0; p0 < np; p0 += 8) {
+        float acc[8];
+        int base[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[u] = 0.f;
+            const int l = min(l0 + p0 + u, L - 1);
+            base[u] = (l / a.NW) * a.stride * a.IW + (l % a.NW) * a.stride;
+        }
+        if (dval) {
+            int j = 0;
+            for (int c = 0; c < a.C; ++c)
+                for (int kh = 0; kh < a.P; ++kh)
+                    for (int kw = 0; kw < a.P; ++kw, ++j) {
+                        const float w = sW[j * a.D + d];
+                        const int off = (c * a.IH + kh) * a.IW + kw;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc[u] += w * sImg[base[u] + off];
+                    }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int l = l0 + p0 + u;
+            if (l < L && p0 + u < np) {
+                const int row = b * T + 1 + l;
+                float v = dval ? acc[u] + bias + a.pos[(size_t)(1 + l) * a.D + d] : 0.f;
+                if (a.drop.thresh && dval) v = drop_keep(a.drop.key, row, d, a.drop.thresh) ? v * a.drop.inv_keep : 0.f;
+                a.x[(size_t)row * a.DP + d] = v;
+            }
+        }
+    }
+}
+
+// dpos[t][d] += sum_b gd[b][t][d]; dcls[d] += sum_b gd[b][0][d]   (gd = g * mask / keep)
+__global__ void patch_bwd_pos_kernel(PatchArgs a) {
+    const int L = a.NH * a.NW, T = L + 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * a.D) return;
+    const int t = idx / a.D, d = idx % a.D;
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        const int row = b * T + t;
+        float g = a.x[(size_t)row * a.DP + d];
+        if (a.drop.thresh) g = drop_keep(a.drop.key, row, d, a.drop.thresh) ? g * a.drop.inv_keep : 0.f;
+        s += g;
+    }
+    a.dpos[idx] += s;
+    if (t == 0) a.dcls[d] += s;
+}
+
+// dWp[d][j] += sum_{b,l} gd[b][1+l][d] * U[b][l][j]; dbp[d] += sum gd.  Workgroup = 64 patches of one
+// image, thread = d, 16 j's at a time in registers; results are transposed through LDS so each
+// atomic wave-instruction covers 64-B runs instead of 64 different rows.
+__global__ __launch_bounds__(256) void patch_bwd_w_kernel(PatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int PD = a.C * a.P * a.P, L = a.NH * a.NW, T = L + 1;
+    float* sImg = smem;
+    float* sT = smem + a.C * a.IH * a.IW;  // [D][16]
+    const int b = blockIdx.y, l0 = blockIdx.x * PCHUNK, tid = threadIdx.x;
+    const float* img = a.img + (size_t)b * a.C * a.IH * a.IW;
+    for (int i = tid; i < a.C * a.IH * a.IW; i += 256) sImg[i] = img[i];
+    __syncthreads();
+    const int d = tid;
+    const bool dval = d < a.D;
+    const int np = min(PCHUNK, L - l0);
+    const int PP = a.P * a.P;
+    for (int j0 = 0; j0 < PD; j0 += 16) {
+        float acc[16];
+        int off[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            acc[jj] = 0.f;
+            const int j = j0 + jj, c = j / PP, kh = (j % PP) / a.P, kw = j % a.P;
+            off[jj] = (c * a.IH + kh) * a.IW + kw;
+        }
+        float bsum = 0.f;
+        if (dval) {
+            for (int p = 0; p < np; ++p) {
+                const int l = l0 + p, row = b * T + 1 + l;
+                float g = a.x[(size_t)row * a.DP + d];
+                if (a.drop.thresh) g = drop_keep(a.drop.key, row, d, a.drop.thresh) ? g * a.drop.inv_keep : 0.f;
+                bsum += g;
+                const int base = (l / a.NW) * a.stride * a.IW + (l % a.NW) * a.stride;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) acc[jj] += g * sImg[base + off[jj]];
+            }
+            if (j0 == 0) atomicAdd(&a.dbias[d], bsum);
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) sT[d * 16 + jj] = acc[jj];
+        }
+        __syncthreads();
+        for (int e = tid; e < a.D * 16; e += 256) atomicAdd(&a.dW[(size_t)(e >> 4) * PD + j0 + (e & 15)], sT[e]);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm forward (one wave per row) fused with the BehaviorMLP injection x += beta[b] (vit.py:356-359).
+template <int NE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= a.rows) return;
+    const int b = row / a.T;
+    float v[NE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = 0.f;
+        if (c < a.D) {
+            v[i] = a.x[(size_t)row * a.DP + c];
+            if (a.inject) v[i] += a.inject[(size_t)b * a.DP + c];
+        }
+        if (a.inject && c < a.DP) a.xout[(size_t)row * a.DP + c] = v[i];
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / a.D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = lane + 64 * i;
+        const float dlt = (c < a.D) ? v[i] - mean : 0.f;
+        q += dlt * dlt;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / a.D + a.eps);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < a.DP) {
+            const float z = (c < a.D) ? (v[i] - mean) * rstd * a.gamma[c] + a.beta[c] : 0.f;
+            a.z[(size_t)row * a.DP + c] = (bf16_t)z;
+        }
+    }
+    if (lane == 0) {
+        a.mean[row] = mean;
+        a.rstd[row] = rstd;
+    }
+}
+
+// LayerNorm backward + residual add + (optional) token-sum for the injection gradient +
+// (optional) dropout-backward/cast of the result for the next branch and its bias gradient.
+// Workgroup = 64 rows of one image (16 per wave); column partials stay in registers across rows.
+constexpr int LNB_ROWS = 64;
+template <int NE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
+    __shared__ float sred[4][4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * LNB_ROWS;
+    float gam[NE], adg[NE], adb[NE], ainj[NE], abn[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = lane + 64 * i;
+        gam[i] = (c < a.D) ? a.gamma[c] : 0.f;
+        adg[i] = adb[i] = ainj[i] = abn[i] = 0.f;
+    }
+    for (int rr = wave; rr < LNB_ROWS; rr += 4) {
+        const int t = t0 + rr;
+        if (t >= a.T) break;
+        const int row = b * a.T + t;
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        float dz[NE], xh[NE], dy[NE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int c = lane + 64 * i;
+            dz[i] = xh[i] = dy[i] = 0.f;
+            if (c < a.D) {
+                dz[i] = a.dz[(size_t)row * a.DP + c];
+                xh[i] = (a.x[(size_t)row * a.DP + c] - mean) * rstd;
+                dy[i] = dz[i] * gam[i];
+            }
+            s1 += dy[i];
+            s2 += dy[i] * xh[i];
+        }
+        s1 = wave_sum(s1) / a.D;
+        s2 = wave_sum(s2) / a.D;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int c = lane + 64 * i;
+            if (c < a.DP) {
+                float go = 0.f;
+                if (c < a.D) {
+                    go = a.gin[(size_t)row * a.DP + c] + rstd * (dy[i] - s1 - xh[i] * s2);
+                    adg[i] += dz[i] * xh[i];
+                    adb[i] += dz[i];
+                    ainj[i] += go;
+                }
+                a.gout[(size_t)row * a.DP + c] = go;
+                if (a.dy_next) {
+                    float v = go;
+                    if (a.drop_next.thresh && c < a.D)
+                        v = drop_keep(a.drop_next.key, row, c, a.drop_next.thresh) ? v * a.drop_next.inv_keep : 0.f;
+                    const bf16_t vb = (bf16_t)v;
+                    a.dy_next[(size_t)row * a.DP + c] = vb;
+                    abn[i] += (float)vb;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = lane + 64 * i;
+        sred[wave][0][c] = adg[i];
+        sred[wave][1][c] = adb[i];
+        sred[wave][2][c] = ainj[i];
+        sred[wave][3][c] = abn[i];
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < a.D) {
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            r0 += sred[w][0][c];
+            r1 += sred[w][1][c];
+            r2 += sred[w][2][c];
+            r3 += sred[w][3][c];
+        }
+        atomicAdd(&a.dgamma[c], r0);
+        atomicAdd(&a.dbeta[c], r1);
+        if (a.dinject) atomicAdd(&a.dinject[(size_t)b * a.DP + c], r2);
+        if (a.dy_next && a.dbias_next) atomicAdd(&a.dbias_next[c], r3);
+    }
+}
+
+__global__ __launch_bounds__(256) void drop_cast_kernel(CastArgs a) {
+    __shared__ float sred[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * LNB_ROWS;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int rr = wave; rr < LNB_ROWS; rr += 4) {
+        const int row = r0 + rr;
+        if (row >= a.rows) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            if (c < a.DP) {
+                float v = (c < a.D) ? a.g[(size_t)row * a.DP + c] : 0.f;
+                if (a.drop.thresh && c < a.D) v = drop_keep(a.drop.key, row, c, a.drop.thresh) ? v * a.drop.inv_keep : 0.f;
+                const bf16_t vb = (bf16_t)v;
+                a.dy[(size_t)row * a.DP + c] = vb;
+                acc[i] += (float)vb;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sred[wave][lane + 64 * i] = acc[i];
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (a.dbias && c < a.D) atomicAdd(&a.dbias[c], sred[0][c] + sred[1][c] + sred[2][c] + sred[3][c]);
+}
+
+// ------------------------------------------------------------------------------------------
+// BehaviorMLP (vit.py:157-202): out = tanh(W3 . tanh(W1 . v + b1) + b3). One workgroup per sample.
+__global__ __launch_bounds__(256) void bmlp_fwd_kernel(BmlpArgs a) {
+    __shared__ float sv[8];
+    __shared__ float sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < a.IN) sv[tid] = a.v[b * a.IN + tid];
+    __syncthreads();
+    for (int j = tid; j < a.J; j += 256) {
+        float s = a.b1 ? a.b1[j] : 0.f;
+        for (int i = 0; i < a.IN; ++i) s += a.W1[j * a.IN + i] * sv[i];
+        const float h = tanhf(s);
+        sh[j] = h;
+        a.hid[(size_t)b * a.J + j] = h;
+    }
+    __syncthreads();
+    for (int d = tid; d < a.DP; d += 256) {
+        float o = 0.f;
+        if (d < a.D) {
+            float s = a.b3 ? a.b3[d] : 0.f;
+            for (int j = 0; j < a.J; ++j) s += a.W3[(size_t)d * a.J + j] * sh[j];
+            o = tanhf(s);
+        }
+        a.out[(size_t)b * a.DP + d] = o;
+    }
+}
+
+// Single workgroup; all sums over the (small) batch are owned by one thread -> plain += into the
+// gradient arena (launches on one stream are ordered).
+__global__ __launch_bounds__(256) void bmlp_bwd_kernel(BmlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s2 = smem;               // [B][D]
+    float* s1 = smem + a.B * a.D;   // [B][J]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < a.B * a.D; e += 256) {
+        const int b = e / a.D, d = e % a.D;
+        const float o = a.out[(size_t)b * a.DP + d];
+        s2[e] = a.dout[(size_t)b * a.DP + d] * (1.f - o * o);
+    }
+    __syncthreads();
+    for (int e = tid; e < a.D * a.J; e += 256) {
+        const int d = e / a.J, j = e % a.J;
+        float s = 0.f;
+        for (int b = 0; b < a.B; ++b) s += s2[b * a.D + d] * a.hid[(size_t)b * a.J + j];
+        a.dW3[e] += s;
+    }
+    if (a.db3)
+        for (int d = tid; d < a.D; d += 256) {
+            float s = 0.f;
+            for (int b = 0; b < a.B; ++b) s += s2[b * a.D + d];
+            a.db3[d] += s;
+        }
+    for (int e = tid; e < a.B * a.J; e += 256) {
+        const int b = e / a.J, j = e % a.J;
+        float s = 0.f;
+        for (int d = 0; d < a.D; ++d) s += s2[b * a.D + d] * a.W3[(size_t)d * a.J + j];
+        const float h = a.hid[e];
+        s1[e] = s * (1.f - h * h);
+    }
+    __syncthreads();
+    for (int e = tid; e < a.J * a.IN; e += 256) {
+        const int j = e / a.IN, i = e % a.IN;
+        float s = 0.f;
+        for (int b = 0; b < a.B; ++b) s += s1[b * a.J + j] * a.v[b * a.IN + i];
+        a.dW1[e] += s;
+    }
+    if (a.db1)
+        for (int j = tid; j < a.J; j += 256) {
+            float s = 0.f;
+            for (int b = 0; b < a.B; ++b) s += s1[b * a.J + j];
+            a.db1[j] += s;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused L1-sign + AdamW (torch.optim.AdamW semantics, train.py:216-223) over a flat fp32 arena.
+__global__ void adamw_kernel(AdamArgs a) {
+    const float step_size = a.lr / a.bc1;
+    const float inv_sqrt_bc2 = rsqrtf(a.bc2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+        float p = a.p[i], g = a.g[i];
+        if (a.l1 != 0.f) g += a.l1 * ((p > 0.f) ? 1.f : ((p < 0.f) ? -1.f : 0.f));
+        if (a.weight_decay != 0.f) p *= 1.f - a.lr * a.weight_decay;
+        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+        const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
+        a.p[i] = p - step_size * (m / denom);
+        a.m[i] = m;
+        a.v[i] = v;
+        if (a.zero_grad) a.g[i] = 0.f;
+    }
+}
+
+__global__ void l1_sum_kernel(const float* __restrict__ p, long long n, float scale, float* out) {
+    __shared__ float sred[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += fabsf(p[i]);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (sred[0] + sred[1] + sred[2] + sred[3]) * scale);
+}
+
+__global__ void l1_grad_kernel(const float* __restrict__ p, float* g, long long n, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = p[i];
+        g[i] += scale * ((x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f));
+    }
+}
+
+// ELU1 (models/utils.py:109-118) + Poisson loss (losses.py:153-166) forward and dLoss/du.
+__global__ void elu1_poisson_kernel(LossArgs a) {
+    __shared__ float sred[4];
+    const float eps = 1.1920928955078125e-07f;
+    float ls = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+        const float u = a.u[i];
+        const float yh = (u > 0.f) ? u + 1.0f : expm1f(u) + 1.0f;
+        if (a.yhat) a.yhat[i] = yh;
+        if (a.y) {
+            const float yt = a.y[i] + eps, yp = yh + eps;
+            ls += yp - yt * logf(yp);
+            if (a.du) {
+                const float dyh = (u > 0.f) ? 1.f : expf(u);
+                a.du[i] = a.gscale * a.loss_scale * (1.f - yt / yp) * dyh;
+            }
+        }
+    }
+    if (a.loss) {
+        ls = wave_sum(ls);
+        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = ls;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(a.loss, (sred[0] + sred[1] + sred[2] + sred[3]) * a.loss_scale);
+    }
+}
+
+__global__ void dropout_mask_kernel(uint8_t* out, long long rows, long long cols, DropCfg d) {
+    const long long total = rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / cols), c = (uint32_t)(i % cols);
+        out[i] = (d.thresh == 0 || drop_keep(d.key, r, c, d.thresh)) ? 1 : 0;
+    }
+}
+
+inline int ok() { return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH; }
+inline int nblocks(long long n, int cap = 2048) { return (int)std::min<long long>((n + 255) / 256, cap); }
+
+}  // namespace
+
+int launch_pack(const float* params, void* shadow, const PackDesc* d_desc, int ndesc, hipStream_t s) {
+    if (ndesc <= 0) return V1T_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3(64, ndesc), dim3(256), 0, s, params, (char*)shadow, d_desc);
+    return ok();
+}
+
+static size_t patch_smem_fwd(const PatchArgs& a) { return sizeof(float) * ((size_t)a.C * a.IH * a.IW + (size_t)a.C * a.P * a.P * a.D); }
+static size_t patch_smem_bwd(const PatchArgs& a) { return sizeof(float) * ((size_t)a.C * a.IH * a.IW + (size_t)a.D * 16); }
+
+int launch_patch_embed_fwd(const PatchArgs& a, hipStream_t s) {
+    const size_t smem = patch_smem_fwd(a);
+    if (a.DP > 256 || smem > 160 * 1024) return V1T_ERR_UNSUPPORTED;
+    static size_t configured = 0;
+    if (smem > configured) {
+        if (hipFuncSetAttribute((const void*)patch_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return V1T_ERR_LAUNCH;
+        configured = smem;
+    }
+    const int L = a.NH * a.NW;
+    hipLaunchKernelGGL(patch_fwd_kernel, dim3((L + PCHUNK - 1) / PCHUNK, a.B), dim3(256), smem, s, a);
+    return ok();
+}
+
+int launch_patch_embed_bwd(const PatchArgs& a, hipStream_t s) {
+    const int PD = a.C * a.P * a.P, L = a.NH * a.NW, T = L + 1;
+    const size_t smem = patch_smem_bwd(a);
+    if (a.DP > 256 || PD % 16 != 0 || smem > 160 * 1024) return V1T_ERR_UNSUPPORTED;
+    static size_t configured = 0;
+    if (smem > configured) {
+        if (hipFuncSetAttribute((const void*)patch_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return V1T_ERR_LAUNCH;
+        configured = smem;
+    }
+    hipLaunchKernelGGL(patch_bwd_pos_kernel, dim3((T * a.D + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(patch_bwd_w_kernel, dim3((L + PCHUNK - 1) / PCHUNK, a.B), dim3(256), smem, s, a);
+    return ok();
+}
+
+int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
+    if (a.DP > 256) return V1T_ERR_UNSUPPORTED;
+    const dim3 grid((a.rows + 3) / 4);
+    const int ne = (a.DP + 63) / 64;
+    switch (ne) {
+        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
+    }
+    return ok();
+}
+
+int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
+    if (a.DP > 256) return V1T_ERR_UNSUPPORTED;
+    const dim3 grid((a.T + LNB_ROWS - 1) / LNB_ROWS, a.B);
+    const int ne = (a.DP + 63) / 64;
+    switch (ne) {
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, s, a); break;
+    }
+    return ok();
+}
+
+int launch_drop_cast(const CastArgs& a, hipStream_t s) {
+    if (a.DP > 256) return V1T_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(drop_cast_kernel, dim3((a.rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 0, s, a);
+    return ok();
+}
+
+int launch_bmlp_fwd(const BmlpArgs& a, hipStream_t s) {
+    if (a.IN > 8 || a.J > 256) return V1T_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bmlp_fwd_kernel, dim3(a.B), dim3(256), 0, s, a);
+    return ok();
+}
+
+int launch_bmlp_bwd(const BmlpArgs& a, hipStream_t s) {
+    const size_t smem = sizeof(float) * (size_t)a.B * (a.D + a.J);
+    if (smem > 64 * 1024) return V1T_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bmlp_bwd_kernel, dim3(1), dim3(256), smem, s, a);
+    return ok();
+}
+
+int launch_adamw(const AdamArgs& a, hipStream_t s) {
+    if (a.n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(a.n, 4096)), dim3(256), 0, s, a);
+    return ok();
+}
+int launch_l1_sum(const float* p, long long n, float scale, float* out, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(l1_sum_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, n, scale, out);
+    return ok();
+}
+int launch_l1_grad(const float* p, float* g, long long n, float scale, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(l1_grad_kernel, dim3(nblocks(n, 4096)), dim3(256), 0, s, p, g, n, scale);
+    return ok();
+}
+int launch_elu1_poisson(const LossArgs& a, hipStream_t s) {
+    if (a.n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(elu1_poisson_kernel, dim3(nblocks(a.n, 1024)), dim3(256), 0, s, a);
+    return ok();
+}
+int launch_dropout_mask(uint8_t* out, long long rows, long long cols, DropCfg d, hipStream_t s) {
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(nblocks(rows * cols, 4096)), dim3(256), 0, s, out, rows, cols, d);
+    return ok();
+}

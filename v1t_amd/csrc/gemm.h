@@ -1,0 +1,42 @@
+// v1t_amd — bf16 MFMA GEMMs with fused epilogues (gfx950).
+//  gemm_nt : C[M][N]  = A[M][K] . B[N][K]^T   (both operands K-contiguous; forward and dX GEMMs,
+//            the dX form uses the transposed bf16 weight shadow so it is NT as well)
+//  gemm_tn : dW[n][k] += sum_m Y[m][n] . X[m][k]   (weight gradients; both operands are read
+//            transposed from LDS with ds_read_b64_tr_b16; fp32 atomics into the gradient arena)
+#pragma once
+#include "common.h"
+
+enum GemmEpi {
+    EPI_BF16 = 0,       // C bf16 = acc
+    EPI_F32 = 1,        // C fp32 = acc
+    EPI_BIAS_RES = 2,   // C fp32 = res + dropout(acc + bias)                       (proj, FC2)
+    EPI_BIAS_GELU = 3,  // C bf16 = acc + bias (pre-activation); C2 bf16 = dropout(gelu(.)) (FC1)
+    EPI_DGELU = 4,      // C bf16 = acc * mask/keep * gelu'(aux); colsum += column sums  (dX of FC2)
+};
+
+struct GemmNTArgs {
+    const bf16_t* A; int lda;
+    const bf16_t* B; int ldb;
+    int M, N, K;  // M = valid rows (guarded); N % (32*NBLK) == 0; K % 32 == 0
+    void* C; int ldc;
+    const float* bias;            // [N] fp32 (padded with zeros) or nullptr
+    const float* res; int ldres;  // fp32 residual
+    bf16_t* C2; int ldc2;
+    const bf16_t* aux; int ldaux;
+    float* colsum; int n_valid;   // fp32 atomics, natural column index < n_valid
+    DropCfg drop;
+};
+
+struct GemmTNArgs {
+    const bf16_t* Y; int ldy;  // [M][NY]
+    const bf16_t* X; int ldx;  // [M][NX]
+    int M, NY, NX;             // NY % 32 == 0, NX % (32*XBLK) == 0
+    float* dW; int ldw;        // natural (unpadded) row-major fp32 matrix, atomicAdd
+    int yseg_pad, yseg_valid;  // padded row index i -> natural (i / pad) * valid + i % pad, valid iff i % pad < valid
+    int xseg_pad, xseg_valid;
+    int m_chunk;               // contraction rows per workgroup (multiple of 32)
+    float alpha;
+};
+
+int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s);
+int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s);

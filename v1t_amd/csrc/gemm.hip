@@ -1,0 +1,269 @@
+// v1t_amd — bf16 MFMA GEMM kernels (gfx950). See gemm.h.
+//
+// gemm_nt tiling: workgroup = 4 waves = 128 rows x (32*NBLK) cols; wave w owns rows 32w..32w+31 and
+// all NBLK 32-col MFMA blocks (A fragment read once, reused NBLK times). K-tile 32, LDS rows padded
+// by 16 B (80-B stride -> the 16 rows a ds_read_b128 lane group touches land on 16 distinct
+// 16-B slots), double-buffered LDS, next tile's global loads issued before the MFMAs and written
+// to the other buffer after them (one barrier per K-tile).
+#include "gemm.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LS = BK + 8;  // LDS row stride in elements (80 B)
+
+template <int NBLK, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs g) {
+    constexpr int BN = 32 * NBLK;
+    constexpr int B_CHUNKS = BN * 4;                  // 16-B chunks in a B tile
+    constexpr int B_ITERS = (B_CHUNKS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16_t sA[2][BM * LS];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntn = g.N / BN;
+    const int nwg = gridDim.x;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = lid / ntn, tile_n = lid % ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = g.K / BK;
+
+    u32x4 ra[2], rb[B_ITERS];
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            const int gr = m0 + row;
+            ra[i] = (gr < g.M) ? *(const u32x4*)(g.A + (size_t)gr * g.lda + k0 + 8 * kc) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            if (c < B_CHUNKS) rb[i] = *(const u32x4*)(g.B + (size_t)(n0 + row) * g.ldb + k0 + 8 * kc);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            *(u32x4*)(&sA[buf][row * LS + 8 * kc]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            if (c < B_CHUNKS) *(u32x4*)(&sB[buf][row * LS + 8 * kc]) = rb[i];
+        }
+    };
+
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int frag_off = (lane & 31) * LS + 8 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 a = *(const bf16x8*)(&sA[buf][32 * wave * LS + frag_off + 16 * ks]);
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) {
+                const bf16x8 b = *(const bf16x8*)(&sB[buf][32 * nb * LS + frag_off + 16 * ks]);
+                acc[nb] = mfma32(a, b, acc[nb]);
+            }
+        }
+        if (kt + 1 < nk) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: col = n0 + 32nb + (lane&31); row = m0 + 32wave + acc_row(r, lane)
+    const int rbase = m0 + 32 * wave;
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+        const int col = n0 + 32 * nb + (lane & 31);
+        float bias = 0.f;
+        if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU) bias = g.bias ? g.bias[col] : 0.f;
+        float csum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + acc_row(r, lane);
+            const bool ok = row < g.M;
+            float v = acc[nb][r];
+            if constexpr (EPI == EPI_BF16) {
+                if (ok) ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = (bf16_t)v;
+            } else if constexpr (EPI == EPI_F32) {
+                if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = v;
+            } else if constexpr (EPI == EPI_BIAS_RES) {
+                v += bias;
+                if (g.drop.thresh) v = drop_keep(g.drop.key, row, col, g.drop.thresh) ? v * g.drop.inv_keep : 0.f;
+                if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = g.res[(size_t)row * g.ldres + col] + v;
+            } else if constexpr (EPI == EPI_BIAS_GELU) {
+                v += bias;
+                float a = gelu_erf(v);
+                if (g.drop.thresh) a = drop_keep(g.drop.key, row, col, g.drop.thresh) ? a * g.drop.inv_keep : 0.f;
+                if (ok) {
+                    ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = (bf16_t)v;
+                    g.C2[(size_t)row * g.ldc2 + col] = (bf16_t)a;
+                }
+            } else if constexpr (EPI == EPI_DGELU) {
+                float d = 0.f;
+                if (ok) {
+                    const float hp = (float)g.aux[(size_t)row * g.ldaux + col];
+                    d = v * gelu_erf_grad(hp);
+                    if (g.drop.thresh) d = drop_keep(g.drop.key, row, col, g.drop.thresh) ? d * g.drop.inv_keep : 0.f;
+                    const bf16_t db = (bf16_t)d;
+                    ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = db;
+                    d = (float)db;
+                }
+                csum += d;
+            }
+        }
+        if constexpr (EPI == EPI_DGELU) {
+            csum += __shfl_xor(csum, 32);
+            if (g.colsum && lane < 32 && col < g.n_valid) atomicAdd(&g.colsum[col], csum);
+        }
+    }
+}
+
+template <int NBLK>
+int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
+    const int BN = 32 * NBLK;
+    const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
+    if (grid <= 0) return V1T_OK;
+    switch (epi) {
+        case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BF16>), dim3(grid), dim3(256), 0, s, a); break;
+        case EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_F32>), dim3(grid), dim3(256), 0, s, a); break;
+        case EPI_BIAS_RES: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_RES>), dim3(grid), dim3(256), 0, s, a); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, a); break;
+        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_DGELU>), dim3(grid), dim3(256), 0, s, a); break;
+        default: return V1T_ERR_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_tn: workgroup = 4 waves = 128 Y-columns (output rows) x 32*XBLK X-columns (output cols)
+// over one m_chunk of the contraction; m-tile 32 rows, both LDS images stored [m][col] and read
+// with ds_read_b64_tr_b16 (row strides are 64 B x odd so the 4 rows of a transposed read hit
+// 4 distinct 16-bank groups).
+constexpr int TN_YS = 160;  // 128 cols + pad -> 320 B
+
+template <int XBLK>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs g) {
+    constexpr int XW = 32 * XBLK;
+    constexpr int XS = (XW == 64) ? 96 : (XW == 128 ? 160 : (XW == 160 ? 160 : XW + 32));
+    constexpr int X_CHUNKS = 32 * (XW / 8);
+    constexpr int X_ITERS = (X_CHUNKS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16_t sY[2][32 * TN_YS];
+    __shared__ __attribute__((aligned(16))) bf16_t sX[2][32 * XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 128, x0 = blockIdx.y * XW;
+    const int mb = blockIdx.z * g.m_chunk;
+    const int me = min(g.M, mb + g.m_chunk);
+    const int nt = (me - mb + 31) / 32;
+    const bool wave_on = (n0 + 32 * wave) < g.NY;  // wave-uniform
+
+    u32x4 ry[2], rx[X_ITERS];
+    auto gload = [&](int t) {
+        const int mt = mb + 32 * t;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 4, cc = c & 15;
+            const int m = mt + row, col = n0 + 8 * cc;
+            ry[i] = (m < me && col < g.NY) ? *(const u32x4*)(g.Y + (size_t)m * g.ldy + col) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < X_ITERS; ++i) {
+            const int c = tid + 256 * i, row = c / (XW / 8), cc = c % (XW / 8);
+            const int m = mt + row;
+            if (c < X_CHUNKS) rx[i] = (m < me) ? *(const u32x4*)(g.X + (size_t)m * g.ldx + x0 + 8 * cc) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 4, cc = c & 15;
+            *(u32x4*)(&sY[buf][row * TN_YS + 8 * cc]) = ry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < X_ITERS; ++i) {
+            const int c = tid + 256 * i, row = c / (XW / 8), cc = c % (XW / 8);
+            if (c < X_CHUNKS) *(u32x4*)(&sX[buf][row * XS + 8 * cc]) = rx[i];
+        }
+    };
+
+    f32x16 acc[XBLK];
+#pragma unroll
+    for (int xb = 0; xb < XBLK; ++xb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[xb][r] = 0.f;
+
+    if (nt > 0) {
+        gload(0);
+        swrite(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        if (wave_on) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 a = lds_tr_frag_nat(sY[buf], TN_YS, 16 * s, 32 * wave, lane);
+#pragma unroll
+                for (int xb = 0; xb < XBLK; ++xb) {
+                    const bf16x8 b = lds_tr_frag_nat(sX[buf], XS, 16 * s, 32 * xb, lane);
+                    acc[xb] = mfma32(a, b, acc[xb]);
+                }
+            }
+        }
+        if (t + 1 < nt) swrite(buf ^ 1);
+        __syncthreads();
+    }
+    if (!wave_on) return;
+#pragma unroll
+    for (int xb = 0; xb < XBLK; ++xb) {
+        const int xc = x0 + 32 * xb + (lane & 31);
+        const int xs = xc / g.xseg_pad, xr = xc % g.xseg_pad;
+        const bool xok = xr < g.xseg_valid;
+        const int ncol = xs * g.xseg_valid + xr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int yr = n0 + 32 * wave + acc_row(r, lane);
+            const int ys = yr / g.yseg_pad, yy = yr % g.yseg_pad;
+            if (xok && yr < g.NY && yy < g.yseg_valid)
+                atomicAdd(&g.dW[(size_t)(ys * g.yseg_valid + yy) * g.ldw + ncol], acc[xb][r] * g.alpha);
+        }
+    }
+}
+
+}  // namespace
+
+int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s) {
+    if (a.K % BK != 0 || a.N % 32 != 0 || (a.lda % 8) || (a.ldb % 8)) return V1T_ERR_ARG;
+    if (a.N % 160 == 0) return launch_nt_n<5>(a, epi, s);
+    if (a.N % 128 == 0) return launch_nt_n<4>(a, epi, s);
+    if (a.N % 64 == 0) return launch_nt_n<2>(a, epi, s);
+    return launch_nt_n<1>(a, epi, s);
+}
+
+int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s) {
+    if (a.NY % 32 != 0 || a.NX % 32 != 0 || a.m_chunk % 32 != 0 || (a.ldy % 8) || (a.ldx % 8)) return V1T_ERR_ARG;
+    if (a.M <= 0) return V1T_OK;
+    const int gy = (a.NY + 127) / 128, gz = (a.M + a.m_chunk - 1) / a.m_chunk;
+#define TN_LAUNCH(XB)                                                                                       \
+    hipLaunchKernelGGL((gemm_tn_kernel<XB>), dim3(gy, a.NX / (32 * XB), gz), dim3(256), 0, s, a)
+    if (a.NX % 160 == 0) TN_LAUNCH(5);
+    else if (a.NX % 128 == 0) TN_LAUNCH(4);
+    else if (a.NX % 64 == 0) TN_LAUNCH(2);
+    else TN_LAUNCH(1);
+#undef TN_LAUNCH
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}

@@ -1,0 +1,24 @@
+// v1t_amd — Gaussian2d readout (see readout.hip).
+#pragma once
+#include "common.h"
+
+struct ReadoutArgs {
+    const float* z;        // core map: element (b, cell, c) at z[b*zsb + cell*zsc + c]; cell = y*W + x
+    long long zsb, zsc;
+    int B, C, H, W, N;
+    const float* grid;     // [B][N][2] (x, y) in [-1,1] (+shift)
+    const float* feat;     // [N][FS] neuron-major feature weights
+    int FS;
+    const float* bias;     // [N] or nullptr
+    float* out;            // [B][N]
+    // backward
+    const float* gout;     // [B][N]
+    float* dz;             // same addressing as z (dzsb, dzsc), fp32 atomics, or nullptr
+    long long dzsb, dzsc;
+    float* dgrid;          // [B][N][2] (overwritten) or nullptr
+    float* dfeat;          // [N][FS] (+=) or nullptr
+    float* dbias;          // [N] (+=) or nullptr
+};
+
+int launch_readout_fwd(const ReadoutArgs& a, hipStream_t s);
+int launch_readout_bwd(const ReadoutArgs& a, hipStream_t s);

@@ -1,0 +1,105 @@
+"""ctypes binding of libv1t_amd.so (the C-ABI in include/v1t_amd.h).
+
+The product path has NO CPU / eager fallback: if the HIP library is missing or a launch fails,
+the ops raise RuntimeError (the reference's OOM probe, utils/utils.py:460, relies on RuntimeError).
+PyTorch is used only for device memory and streams: tensors are passed as raw device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import typing as t
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libv1t_amd.so")
+
+c_void_p, c_int, c_ll, c_float, c_u64, c_u32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint64, C.c_uint32
+
+
+class VitConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", c_int), ("in_h", c_int), ("in_w", c_int),
+        ("patch_size", c_int), ("patch_stride", c_int), ("patch_mode", c_int),
+        ("emb_dim", c_int), ("num_heads", c_int), ("mlp_dim", c_int), ("num_blocks", c_int),
+        ("behavior_mode", c_int), ("num_mice", c_int), ("use_lsa", c_int), ("use_bias", c_int),
+        ("p_dropout", c_float), ("t_dropout", c_float), ("ln_eps", c_float),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/v1t_amd.h
+SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
+    "v1t_abi_version": (c_int, []),
+    "v1t_error_string": (C.c_char_p, [c_int]),
+    "v1t_vit_create": (c_int, [C.POINTER(VitConfig), C.POINTER(c_void_p)]),
+    "v1t_vit_destroy": (None, [c_void_p]),
+    "v1t_vit_arena_floats": (c_ll, [c_void_p]),
+    "v1t_vit_param_floats": (c_ll, [c_void_p]),
+    "v1t_vit_num_tensors": (c_int, [c_void_p]),
+    "v1t_vit_tensor_info": (c_int, [c_void_p, c_int, C.c_char_p, c_int, C.POINTER(c_ll), C.POINTER(c_int), C.POINTER(c_ll), C.POINTER(c_int)]),
+    "v1t_vit_tokens": (c_int, [c_void_p]),
+    "v1t_vit_padded_dim": (c_int, [c_void_p]),
+    "v1t_vit_grid_h": (c_int, [c_void_p]),
+    "v1t_vit_grid_w": (c_int, [c_void_p]),
+    "v1t_vit_shadow_bytes": (c_ll, [c_void_p]),
+    "v1t_vit_workspace_bytes": (c_ll, [c_void_p, c_int, c_int]),
+    "v1t_vit_scratch_bytes": (c_ll, [c_void_p, c_int]),
+    "v1t_vit_workspace_offset": (c_ll, [c_void_p, c_int, c_int, C.c_char_p, c_int]),
+    "v1t_vit_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "v1t_vit_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_ll, c_int, c_int, c_u64, c_void_p, c_void_p]),
+    "v1t_vit_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_ll, c_int, c_u64, c_void_p, c_void_p, c_void_p]),
+    "v1t_dropout_mask": (c_int, [c_u64, c_u32, c_float, c_ll, c_ll, c_void_p, c_void_p]),
+    "v1t_gaussian2d_forward": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "v1t_gaussian2d_backward": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "v1t_elu1_poisson": (c_int, [c_void_p, c_void_p, c_ll, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "v1t_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
+    "v1t_l1_sum": (c_int, [c_void_p, c_ll, c_float, c_void_p, c_void_p]),
+    "v1t_l1_grad": (c_int, [c_void_p, c_void_p, c_ll, c_float, c_void_p]),
+    "v1t_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "v1t_gemm_tn": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "v1t_attention_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_u64, c_u32, c_void_p, c_void_p, c_void_p]),
+    "v1t_attention_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_u64, c_u32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "v1t_layernorm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "v1t_layernorm_backward": (c_int, [c_void_p] * 12 + [c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+_lib: t.Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"v1t_amd: HIP library {LIB_PATH} not found — build it with `python -m v1t_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().v1t_error_string(code).decode()
+        raise RuntimeError(f"v1t_amd {what}: {msg} (code {code})")
+
+
+def ptr(x: t.Optional[torch.Tensor]) -> t.Optional[int]:
+    return None if x is None else x.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(x: torch.Tensor, what: str) -> None:
+    if not x.is_cuda:
+        raise RuntimeError(f"v1t_amd {what}: tensor is on {x.device}; the HIP path needs a GPU tensor (no CPU fallback).")

@@ -1,0 +1,208 @@
+"""Model assembly around the native core / readout: ImageCropper -> Core -> CoreShifter -> Readouts -> ELU1.
+
+Host-side mirror of src/v1t/models/model.py:50-177 (`Model`), core_shifter.py:7-69, image_cropper.py:50-140
+and models/utils.py:109-118 (`ELU1`) — the thin callers on either side of the hot path (SURVEY.md §8f
+rank 1). Same constructor arguments, attribute names, `forward` / `regularizer` / `get_parameters`
+contracts and state-dict keys. The shifter MLPs (2->5->5->2) and the cropper are O(B) / O(image)
+tensor plumbing and run as torch ops; everything between core input and readout output is HIP.
+"""
+from __future__ import annotations
+
+import typing as t
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import lib as L
+from .core import get_core
+from .flat import FlatArena
+from .readout import Gaussian2DReadout, Readouts
+
+
+class ELU1(nn.Module):
+    """ELU + 1 (reference models/utils.py:109-118). On GPU tensors uses the fused HIP elementwise kernel."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("one", torch.tensor(1.0))
+
+    def forward(self, inputs: torch.Tensor):
+        return _Elu1Fn.apply(inputs)
+
+
+class _Elu1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u):
+        L.require_cuda(u, "ELU1")
+        u = u.contiguous()
+        y = torch.empty_like(u)
+        L.check(L.load().v1t_elu1_poisson(u.data_ptr(), None, u.numel(), 1.0, 1.0, y.data_ptr(), None, None, L.stream()), "elu1")
+        ctx.save_for_backward(u, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        u, y = ctx.saved_tensors
+        return g * torch.where(u > 0, torch.ones_like(u), y)  # d/du (elu(u)+1) = 1 | exp(u) = y (u<=0)
+
+
+class CoreShifter(nn.Module):
+    """reference core_shifter.py:7-40"""
+
+    def __init__(self, args, in_features: int, hidden_features: int, num_layers: int, name: str = "CoreShifter"):
+        super().__init__()
+        self.name = name
+        self.register_buffer("reg_scale", torch.tensor(float(getattr(args, "shifter_reg_scale", 0.0))))
+        out_features = in_features
+        layers = []
+        for _ in range(num_layers - 1):
+            layers.extend([nn.Linear(out_features, hidden_features), nn.Tanh()])
+            out_features = hidden_features
+        layers.extend([nn.Linear(out_features, 2), nn.Tanh()])
+        self.mlp = nn.Sequential(*layers)
+
+    def regularizer(self):
+        return self.reg_scale * sum(p.abs().sum() for p in self.parameters())
+
+    def forward(self, pupil_center: torch.Tensor):
+        return self.mlp(pupil_center)
+
+
+class CoreShifters(nn.ModuleDict):
+    """reference core_shifter.py:43-69"""
+
+    def __init__(self, args, mouse_ids: t.List[str], input_channels: int, hidden_features: int, num_layers: int):
+        super().__init__()
+        for mouse_id in mouse_ids:
+            self.add_module(mouse_id, CoreShifter(args, input_channels, hidden_features, num_layers, name=f"Mouse{mouse_id}CoreShifter"))
+
+    def regularizer(self, mouse_id: str):
+        return self[mouse_id].regularizer()
+
+    def forward(self, pupil_centers: torch.Tensor, mouse_id: str):
+        return self[mouse_id](pupil_centers)
+
+
+class ImageCropper(nn.Module):
+    """reference image_cropper.py:50-140 for shift_mode in (0, 2) (no learned image shifter): identity
+    crop (nearest grid_sample over the identity grid) at center_crop == 1, then bilinear 144x256 -> 36x64
+    (torchvision Resize(antialias=False) == F.interpolate(bilinear, align_corners=False)), optional
+    behaviour-as-channels (behavior_mode 1)."""
+
+    def __init__(self, args, ds: t.Dict[str, t.Any]):
+        super().__init__()
+        self.shift_mode = args.shift_mode
+        self.input_shape = args.input_shape
+        self.behavior_mode = args.behavior_mode
+        if self.shift_mode in (1, 3, 4):
+            raise NotImplementedError("shift_mode 1/3/4 (learned image shifter) is outside the native hot path for now")
+        c, in_h, in_w = args.input_shape
+        out_h, out_w = in_h, in_w
+        if self.behavior_mode == 1:
+            c += 3
+        self.crop_scale = args.center_crop
+        self.crop_h, self.crop_w = in_h, in_w
+        if self.crop_scale < 1:
+            out_h = self.crop_h = int(in_h * self.crop_scale)
+            out_w = self.crop_w = int(in_w * self.crop_scale)
+        h_pixels = torch.linspace(-self.crop_scale, self.crop_scale, self.crop_h)
+        w_pixels = torch.linspace(-self.crop_scale, self.crop_scale, self.crop_w)
+        mesh_y, mesh_x = torch.meshgrid(h_pixels, w_pixels, indexing="ij")
+        self.register_buffer("grid", torch.stack((mesh_x, mesh_y), dim=2).unsqueeze(0))
+        self.image_shifter = None
+        self.resize = None
+        if args.resize_image == 1 and args.ds_name != "franke2022":
+            out_h, out_w = 36, 64
+            self.resize = (out_h, out_w)
+        self.output_shape = (c, out_h, out_w)
+
+    def regularizer(self, mouse_id: str):
+        return 0
+
+    def forward(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor):
+        grid = self.grid.expand(inputs.size(0), -1, -1, -1)
+        outputs = inputs
+        if self.crop_scale < 1:
+            outputs = F.grid_sample(inputs, grid=grid, mode="nearest", align_corners=True)
+        if self.resize is not None:
+            outputs = F.interpolate(outputs, size=self.resize, mode="bilinear", align_corners=False, antialias=False)
+        if self.behavior_mode == 1:
+            h, w = outputs.size(2), outputs.size(3)
+            outputs = torch.concat((outputs, behaviors[:, :, None, None].expand(-1, -1, h, w)), dim=1)
+        return outputs, grid
+
+
+class Model(nn.Module):
+    """reference model.py:50-177"""
+
+    def __init__(self, args: t.Any, ds: t.Dict[str, t.Any], name: str = "Model"):
+        super().__init__()
+        assert isinstance(args.output_shapes, dict), "output_shapes must be a dictionary of mouse_id and output_shape"
+        self.name = name
+        self.input_shape = args.input_shape
+        self.output_shapes = args.output_shapes
+        self.shift_mode = args.shift_mode
+        self.add_module("image_cropper", ImageCropper(args, ds=ds))
+        self.add_module("core", get_core(args)(args, input_shape=self.image_cropper.output_shape))
+        if self.shift_mode in (2, 3, 4):
+            self.add_module("core_shifter", CoreShifters(args, mouse_ids=list(ds.keys()), input_channels=2, hidden_features=5, num_layers=3))
+        else:
+            self.core_shifter = None
+        self.add_module("readouts", Readouts(args, model=args.readout, input_shape=self.core.output_shape, output_shapes=self.output_shapes, ds=ds))
+        self.elu1 = ELU1()
+        self._mouse_arenas: t.Dict[str, FlatArena] = {}
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def get_parameters(self, core_lr: float):
+        """reference model.py:112-139"""
+        params = []
+        if not self.core.frozen:
+            params.append({"params": self.core.parameters(), "lr": core_lr, "name": "core"})
+        params.append({"params": self.readouts.parameters(), "name": "readouts"})
+        if self.core_shifter is not None:
+            params.append({"params": self.core_shifter.parameters(), "name": "core_shifter"})
+        return params
+
+    def regularizer(self, mouse_id: str):
+        """reference model.py:141-149"""
+        reg = 0
+        if not self.core.frozen:
+            reg = reg + self.core.regularizer()
+        reg = reg + self.readouts.regularizer(mouse_id=mouse_id)
+        reg = reg + self.image_cropper.regularizer(mouse_id=mouse_id)
+        if self.core_shifter is not None:
+            reg = reg + self.core_shifter.regularizer(mouse_id=mouse_id)
+        return reg
+
+    def forward(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor, activate: bool = True):
+        images, image_grids = self.image_cropper(inputs, mouse_id=mouse_id, behaviors=behaviors, pupil_centers=pupil_centers)
+        outputs = self.core(images, mouse_id=mouse_id, behaviors=behaviors, pupil_centers=pupil_centers)
+        shifts = None
+        if self.core_shifter is not None:
+            shifts = self.core_shifter(pupil_centers, mouse_id=mouse_id)
+        outputs = self.readouts(outputs, mouse_id=mouse_id, shifts=shifts)
+        if activate:
+            outputs = self.elu1(outputs)
+        return outputs, images, image_grids
+
+    # ------------------------------------------------------------------ flat per-mouse arenas (fused optimizer / DDP)
+    def mouse_arena(self, mouse_id: str) -> FlatArena:
+        """All per-mouse parameters (readout + core shifter) in one flat arena; `features` first, in
+        neuron-major storage, so the L1 term and the feature kernel see one contiguous [N][FS] block."""
+        a = self._mouse_arenas.get(mouse_id)
+        if a is None:
+            ro = self.readouts[mouse_id]
+            params = [ro.features] + [p for p in ro.parameters() if p is not ro.features]
+            if self.core_shifter is not None:
+                params += list(self.core_shifter[mouse_id].parameters())
+            special = {}
+            if isinstance(ro, Gaussian2DReadout):
+                special[id(ro.features)] = (ro.feature_storage_numel(), ro._feature_view)
+            a = FlatArena.from_params(params, special)
+            self._mouse_arenas[mouse_id] = a
+        a.ensure()
+        return a

@@ -1,0 +1,270 @@
+"""Readout plugin registry + the MI355X-native "gaussian2d" readout.
+
+Host-side mirror of the reference's readout interface for this hot path:
+  - `register(name)` / `Readout` / `Readouts`  <- src/v1t/models/readout/readout.py:10-18, 21-49, 52-85
+  - `Gaussian2DReadout(args, input_shape, output_shape, ds, name)` registered as "gaussian2d"
+                                              <- src/v1t/models/readout/gaussian2d.py:13-278
+The per-neuron bilinear sample + feature dot + bias (gaussian2d.py:270-276) and its backward are the
+HIP kernels `v1t_gaussian2d_forward/backward`; the O(N) grid bookkeeping (mu MLP on the cortical
+coordinates, sigma * eps, clamp, + shifts: gaussian2d.py:188-235, 265-268) is a handful of tiny tensor
+ops left to torch autograd (it returns d grid to them).
+
+Memory layout: the `features` parameter keeps the reference's shape (1, C, 1, N) and state-dict key
+but is STORED neuron-major ([N][FS], FS = C rounded up to 32) — the parameter is a strided view of
+that storage — so that a wave reading one neuron's C weights, or adding its C gradient values, touches
+one contiguous row.
+"""
+from __future__ import annotations
+
+import typing as t
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import lib as L
+
+_READOUTS: t.Dict[str, t.Any] = dict()
+
+
+def register(name: str):
+    """reference readout/readout.py:10-18"""
+
+    def add_to_dict(fn):
+        _READOUTS[name] = fn
+        return fn
+
+    return add_to_dict
+
+
+class Readout(nn.Module):
+    """Basic readout module for a single animal (reference readout/readout.py:21-49)."""
+
+    def __init__(self, args: t.Any, input_shape: tuple, output_shape: tuple, ds: t.Any, name: str = None):
+        super().__init__()
+        self.name = "Readout" if name is None else name
+        self.input_shape = input_shape
+        self.output_shape = output_shape
+        self.neuron_coordinates = ds.dataset.coordinates
+        self.register_buffer("reg_scale", torch.tensor(float(args.readout_reg_scale)))
+
+    @property
+    def num_neurons(self):
+        return self.output_shape[-1]
+
+    def initialize(self, *args: t.Any, **kwargs: t.Any):
+        pass
+
+    def regularizer(self, reduction: str):
+        return self.reg_scale * sum(p.abs().sum() for p in self.parameters())
+
+
+class Readouts(nn.ModuleDict):
+    """Mouse ID -> Readout module (reference readout/readout.py:52-85)."""
+
+    def __init__(self, args: t.Any, model: str, input_shape: t.Tuple[int], output_shapes: t.Dict[str, tuple], ds: t.Dict[str, t.Any]):
+        super().__init__()
+        if model not in _READOUTS.keys():
+            raise NotImplementedError(f"Readout {model} has not been implemented.")
+        self.input_shape = input_shape
+        self.output_shapes = output_shapes
+        readout_model = _READOUTS[model]
+        for mouse_id, output_shape in self.output_shapes.items():
+            self.add_module(
+                name=mouse_id,
+                module=readout_model(args, input_shape=input_shape, output_shape=output_shape, ds=ds[mouse_id], name=f"Mouse{mouse_id}Readout"),
+            )
+
+    def regularizer(self, mouse_id: str, reduction: str = "sum"):
+        return self[str(mouse_id)].regularizer(reduction=reduction)
+
+    def forward(self, inputs: torch.Tensor, mouse_id: str, shifts: torch.Tensor = None):
+        return self[mouse_id](inputs, shifts=shifts)
+
+
+class _Gaussian2dFn(torch.autograd.Function):
+    """u[b,n] = sum_c F[n,c] * bilinear(z[b,:,:,c], grid[b,n]) + bias[n]  via the HIP kernels.
+    z is addressed as z[b*zsb + cell*zsc + c] starting `zoff` floats into `zbuf` (token-major core
+    output: zoff skips the CLS row). feat_st is the neuron-major [N][FS] storage."""
+
+    @staticmethod
+    def forward(ctx, zbuf, grid, feat_st, bias, geom, feat_param):
+        zoff, zsb, zsc, B, Cc, H, W, N, FS = geom
+        out = torch.empty((B, N), dtype=torch.float32, device=zbuf.device)
+        grid = grid.contiguous()
+        L.check(
+            L.load().v1t_gaussian2d_forward(zbuf.data_ptr() + 4 * zoff, zsb, zsc, B, Cc, H, W, N, grid.data_ptr(), feat_st.data_ptr(),
+                                            FS, L.ptr(bias), out.data_ptr(), L.stream()),
+            "gaussian2d_forward",
+        )
+        ctx.save_for_backward(zbuf, grid, feat_st, bias)
+        ctx.geom = geom
+        ctx.feat_param = feat_param
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        zbuf, grid, feat_st, bias = ctx.saved_tensors
+        zoff, zsb, zsc, B, Cc, H, W, N, FS = ctx.geom
+        gout = gout.contiguous()
+        need_z, need_grid, _, need_bias = ctx.needs_input_grad[0], ctx.needs_input_grad[1], None, ctx.needs_input_grad[3]
+        dz = torch.zeros_like(zbuf) if need_z else None
+        dgrid = torch.empty_like(grid) if need_grid else None
+        need_feat = ctx.needs_input_grad[2]
+        dfeat = torch.zeros_like(feat_st) if need_feat else None
+        dbias = torch.zeros_like(bias) if (bias is not None and need_bias) else None
+        L.check(
+            L.load().v1t_gaussian2d_backward(zbuf.data_ptr() + 4 * zoff, zsb, zsc, B, Cc, H, W, N, grid.data_ptr(), feat_st.data_ptr(), FS,
+                                             gout.data_ptr(), (dz.data_ptr() + 4 * zoff) if need_z else None, zsb, zsc,
+                                             L.ptr(dgrid), L.ptr(dfeat), L.ptr(dbias), L.stream()),
+            "gaussian2d_backward",
+        )
+        # d features is returned through the storage-shaped tensor; the parameter is a view of it
+        return dz, dgrid, dfeat, dbias, None, None
+
+
+@register("gaussian2d")
+class Gaussian2DReadout(Readout):
+    """MI355X-native drop-in for the reference Gaussian2DReadout (gaussian2d.py:13-278), full gaussian."""
+
+    def __init__(self, args, input_shape: tuple, output_shape: tuple, ds: t.Any, use_bias: bool = True,
+                 init_mu_range: float = 0.3, init_sigma: float = 0.1, gaussian_type: str = "full", name: str = "Gaussian2DReadout"):
+        super().__init__(args, input_shape=input_shape, output_shape=output_shape, ds=ds, name=name)
+        if init_mu_range > 1.0 or init_mu_range <= 0.0 or init_sigma <= 0.0:
+            raise ValueError("either init_mu_range doesn't belong to [0.0, 1.0] or init_sigma_range is non-positive")
+        if gaussian_type != "full":
+            if gaussian_type in ("uncorrelated", "isotropic"):
+                raise NotImplementedError(f"gaussian_type {gaussian_type} has no gfx950 path (reference always constructs 'full').")
+            raise ValueError(f"Unknown Gaussian type {gaussian_type}.")
+        self.init_mu_range = init_mu_range
+        self.init_sigma = init_sigma
+        self.gaussian_type = gaussian_type
+        n = self.num_neurons
+        c = input_shape[0]
+        self.grid_shape = (1, n, 1, 2)
+        self._predicted_grid = not args.disable_grid_predictor
+        if args.disable_grid_predictor:
+            self._mu = nn.Parameter(torch.empty(*self.grid_shape).uniform_(-init_mu_range, init_mu_range))
+        else:
+            dim = args.grid_predictor_dim
+            src = np.asarray(self.neuron_coordinates)[:, :dim].astype(np.float32)
+            self.mu_transform = nn.Sequential(nn.Linear(dim, 30), nn.ELU(), nn.Linear(30, 2), nn.Tanh())  # gaussian2d.py:113-131
+            src = src - src.mean(axis=0, keepdims=True)
+            src = src / np.abs(src).max()
+            self.register_buffer("source_grid", torch.from_numpy(src))
+        self.sigma = nn.Parameter(torch.empty(1, n, 2, 2).uniform_(-init_sigma, init_sigma))  # gaussian2d.py:182
+        # features: neuron-major storage [N][FS], exposed with the reference's (1, C, 1, N) shape
+        self.feat_stride = (c + 31) // 32 * 32
+        st = torch.zeros(n, self.feat_stride)
+        st[:, :c] = 1.0 / c  # gaussian2d.py:183
+        self._feat_storage = st
+        self.features = nn.Parameter(self._feature_view(st))
+        self.use_bias = use_bias
+        self.bias_mode = args.bias_mode
+        stats = ds.dataset.response_stats
+        if use_bias:  # gaussian2d.py:153-169
+            if self.bias_mode == 0:
+                b = torch.zeros(len(stats["mean"]))
+            elif self.bias_mode == 1:
+                b = torch.from_numpy(np.asarray(stats["mean"], dtype=np.float32))
+            elif self.bias_mode == 2:
+                b = torch.from_numpy(np.asarray(stats["mean"] / stats["std"], dtype=np.float32))
+            else:
+                raise NotImplementedError(f"Gaussian2dReadout: bias mode {self.bias_mode} has not been implemented.")
+            self.bias = nn.Parameter(b.to(torch.float32))
+        else:
+            self.bias = None
+
+    def _feature_view(self, storage: torch.Tensor) -> torch.Tensor:
+        c = self.input_shape[0]
+        return storage.view(self.num_neurons, self.feat_stride)[:, :c].t()[None, :, None, :]
+
+    # storage hooks used by flat.FlatArena (model-level per-mouse arena)
+    def feature_storage_numel(self) -> int:
+        return self.num_neurons * self.feat_stride
+
+    def feature_storage(self) -> torch.Tensor:
+        """Neuron-major [N][FS] tensor backing `features` (rebuilt if the parameter was re-pointed or moved)."""
+        f = self.features
+        n, fs, c = self.num_neurons, self.feat_stride, self.input_shape[0]
+        ok = tuple(f.shape) == (1, c, 1, n) and (c == 1 or f.stride(1) == 1) and (n == 1 or f.stride(3) == fs)
+        st = self._feat_storage
+        if (not ok) or st.device != f.device or st.data_ptr() != f.data_ptr():
+            if ok:
+                # parameter still has the neuron-major layout but lives elsewhere (arena / .to()): alias it
+                st = torch.as_strided(f.data, (n, fs), (fs, 1))
+            else:
+                st = torch.zeros(n, fs, device=f.device, dtype=torch.float32)
+                st[:, :c] = f.data.reshape(c, n).t()
+                f.data = self._feature_view(st)
+            self._feat_storage = st
+        return st
+
+    def feature_l1(self, reduction="sum"):
+        l1 = self.features.abs()
+        if reduction == "sum":
+            l1 = l1.sum()
+        elif reduction == "mean":
+            l1 = l1.mean()
+        return l1
+
+    def regularizer(self, reduction="sum"):
+        """gaussian2d.py:99-100"""
+        return self.reg_scale * self.feature_l1(reduction=reduction)
+
+    @property
+    def mu(self):
+        """gaussian2d.py:188-193"""
+        if self._predicted_grid:
+            return self.mu_transform(self.source_grid.squeeze()).view(*self.grid_shape)
+        return self._mu
+
+    def sample_grid(self, batch_size: int, sample: t.Optional[bool] = None, eps: t.Optional[torch.Tensor] = None):
+        """gaussian2d.py:195-235 (full gaussian). `eps` (B,N,2) optionally injects the normal draws."""
+        mu = self.mu
+        if not self._predicted_grid:
+            with torch.no_grad():
+                self._mu.clamp_(min=-1, max=1)
+        sample = self.training if sample is None else sample
+        if eps is not None:
+            norm = eps.reshape(batch_size, self.num_neurons, 1, 2).to(mu.dtype)
+        elif sample:
+            norm = mu.new_empty(batch_size, self.num_neurons, 1, 2).normal_()
+        else:
+            return mu.clamp(min=-1, max=1).expand(batch_size, -1, -1, -1)
+        return torch.clamp(torch.einsum("ancd,bnid->bnic", self.sigma, norm) + mu, min=-1, max=1)
+
+    def forward(self, inputs: torch.Tensor, sample: t.Optional[bool] = None, shifts: t.Optional[torch.Tensor] = None, eps: t.Optional[torch.Tensor] = None):
+        L.require_cuda(inputs, "Gaussian2DReadout.forward")
+        B, c, h, w = inputs.shape
+        n = self.num_neurons
+        grid = self.sample_grid(batch_size=B, sample=sample, eps=eps)
+        if shifts is not None:
+            grid = grid + shifts[:, None, None, :]
+        grid = grid.reshape(B, n, 2).to(torch.float32)
+        tokens = getattr(inputs, "_v1t_tokens", None)
+        if tokens is not None and tokens.shape[0] == B:
+            T, DP = tokens.shape[1], tokens.shape[2]
+            zbuf, geom = tokens, (DP, T * DP, DP, B, c, h, w, n, self.feat_stride)  # skip the CLS row
+        else:
+            zbuf = inputs.permute(0, 2, 3, 1).contiguous().to(torch.float32)  # (B, h, w, C) channel-last
+            geom = (0, h * w * c, c, B, c, h, w, n, self.feat_stride)
+        st = self.feature_storage()
+        feat_st = _FeatStorageFn.apply(self.features, st) if self.features.requires_grad else st
+        return _Gaussian2dFn.apply(zbuf, grid, feat_st, self.bias, geom, self.features)
+
+
+class _FeatStorageFn(torch.autograd.Function):
+    """Identity bridge from the (1,C,1,N) parameter to its neuron-major [N][FS] storage, so that the
+    gradient produced in storage layout lands in the parameter's .grad (a view of the same layout)."""
+
+    @staticmethod
+    def forward(ctx, feat_param, storage):
+        ctx.shape = feat_param.shape
+        return storage.view_as(storage)
+
+    @staticmethod
+    def backward(ctx, g):
+        # g: [N][FS] -> (1, C, 1, N) strided view, no copy
+        c = ctx.shape[1]
+        return g[:, :c].t()[None, :, None, :], None

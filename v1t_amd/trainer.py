@@ -1,0 +1,94 @@
+"""Training step for the native path: equivalent of the reference's train()/train_step()
+(train.py:42-116) — one optimizer step = one mouse-batch per mouse, gradients SUMMED over mice
+(train.py:97-111), Poisson loss scaled by sqrt(ds_size / batch) (losses.py:114-119), L1 regulariser on
+all core parameters once per mouse-batch and on the visited readout's features (train.py:71,
+model.py:141-149), AdamW with wd = 0 (train.py:216-223).
+
+MI355X-first differences (same math):
+  * the HIP backward accumulates directly into flat gradient arenas;
+  * the L1 term is grad-independent, so its gradient n_mice * lambda * sign(p) is folded into the fused
+    L1+AdamW kernel instead of a read-modify-write of every gradient per micro-batch;
+  * no per-step host sync: losses stay on the device (the reference's gather() does .cpu() each step);
+  * multi-GPU: mice are sharded over ranks, the shared core's gradient arena is ONE RCCL all-reduce(SUM).
+"""
+from __future__ import annotations
+
+import typing as t
+
+import torch
+
+from . import lib as L
+from .dist import MouseSharding
+from .losses import elu1_poisson_loss
+from .model import Model
+
+
+class FusedAdamW:
+    """AdamW over flat arenas via v1t_adamw_step (one launch per (arena, range))."""
+
+    def __init__(self, lr: float, betas=(0.9, 0.9999), eps: float = 1e-8, weight_decay: float = 0.0):
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+
+    def step_arena(self, arena, lr: float, ranges: t.Sequence[t.Tuple[int, int, float]], zero_grad: bool = True) -> None:
+        """ranges: (start, n, l1_coeff) in floats; all ranges of one arena share its step counter."""
+        arena.step += 1
+        m, v = arena.moments()
+        lib = L.load()
+        for start, n, l1 in ranges:
+            if n <= 0:
+                continue
+            o = 4 * start
+            L.check(lib.v1t_adamw_step(arena.data.data_ptr() + o, arena.grad.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, n, lr,
+                                       self.betas[0], self.betas[1], self.eps, self.weight_decay, arena.step, l1, int(zero_grad), L.stream()),
+                    "adamw_step")
+
+
+class Trainer:
+    def __init__(self, args, model: Model, ds: t.Dict[str, t.Any], sharding: t.Optional[MouseSharding] = None):
+        self.args, self.model = args, model
+        self.mouse_ids = list(ds.keys())
+        self.ds_sizes = {m: float(len(d.dataset)) for m, d in ds.items()}
+        self.sharding = sharding or MouseSharding(self.mouse_ids, rank=0, world=1)
+        self.lr = args.lr
+        self.core_lr = args.lr if getattr(args, "core_lr", None) is None else args.core_lr
+        self.opt = FusedAdamW(args.lr, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_eps)
+        self.batch_size = args.batch_size
+
+    def train_step(self, batches: t.Dict[str, t.Dict[str, torch.Tensor]]) -> t.Dict[str, torch.Tensor]:
+        """batches: mouse_id -> full batch (image, behavior, pupil_center, response) on the device.
+        Each rank processes its share (whole mice, or a slice of a replicated mouse's batch)."""
+        model = self.model
+        model.train(True)
+        core = model.core
+        core.prepare()
+        losses = []
+        for mouse_id, sl in self.sharding.local_units():
+            b = batches[mouse_id]
+            full = b["image"].shape[0]
+            if sl is not None:
+                b = {k: v[sl] for k, v in b.items()}
+            model.mouse_arena(mouse_id).attach_grads()
+            u, _, _ = model(inputs=b["image"], mouse_id=mouse_id, behaviors=b["behavior"], pupil_centers=b["pupil_center"], activate=False)
+            loss, _ = elu1_poisson_loss(u, b["response"], self.ds_sizes[mouse_id], full)
+            loss.backward()
+            losses.append(loss.detach())
+        self.sharding.reduce_core(core._arena)
+        for mouse_id in self.sharding.shared_mice():
+            self.sharding.reduce_mouse(mouse_id, model.mouse_arena(mouse_id))
+        # optimizer: core (L1 once per mouse-batch of the global step), then the local mice's arenas
+        if not core.frozen:
+            ca = core._arena
+            self.opt.step_arena(ca, self.core_lr, [(0, ca.param_floats, float(core.reg_scale) * len(self.mouse_ids))])
+            core.mark_updated()
+        for mouse_id in self.sharding.local_mice():
+            a = model.mouse_arena(mouse_id)
+            ro = model.readouts[mouse_id]
+            nfeat = ro.feature_storage_numel()
+            self.opt.step_arena(a, self.lr, [(0, nfeat, float(ro.reg_scale)), (nfeat, a.total - nfeat, 0.0)])
+        return {"loss": torch.stack(losses).sum() if losses else torch.zeros((), device=core._arena.data.device)}
+
+    @torch.no_grad()
+    def predict(self, batch: t.Dict[str, torch.Tensor], mouse_id: str) -> torch.Tensor:
+        self.model.train(False)
+        y, _, _ = self.model(inputs=batch["image"], mouse_id=mouse_id, behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
+        return y
