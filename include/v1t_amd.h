@@ -139,6 +139,12 @@ int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const
                            float dropout_p, uint64_t seed, uint32_t stream_id, float* delta_ws,
                            void* dqkv, float* dscale, void* stream);
 
+/* Live kernel timing (bench.py roofline): when enabled, every launch of the selected kernel class is
+ * bracketed by hipEvents on its own stream. class ids: 0 attention fwd, 1 attention bwd dQ,
+ * 2 attention bwd dK/dV, 3 gemm_nt, 4 gemm_tn, 5 readout fwd, 6 readout bwd. */
+int v1t_profile_enable(int kernel_class, int max_launches);   /* kernel_class < 0 disables */
+int v1t_profile_read(int* launches, double* total_ms);        /* synchronises the recorded events */
+
 /* LayerNorm (vit.py:220,145) forward: z bf16 (rows, DP) = LN(x (+ inject[b])) ; backward: see
  * csrc/elementwise.h LnBwdArgs (gout = gin + dLN; optional token-sum, next-branch cast + bias colsum) */
 int v1t_layernorm_forward(const float* x, const float* inject, float* xout, const float* gamma,

@@ -362,6 +362,31 @@ def gen_resize(out: dict, log=print):
     log("  resize: ok")
 
 
+def gen_elu_edge(out: dict, log=print):
+    """ELU1 + Poisson loss at very negative pre-activations (expm1 quantisation; gradient from the input)."""
+    import_reference()
+    from v1t.losses import PoissonLoss
+    from v1t.models.utils import ELU1
+
+    u = torch.tensor([[-30.0, -20.0, -17.0, -15.0, -5.0, -1e-3, 0.0, 1e-3, 3.0, 15.0]], requires_grad=True)
+    y = torch.tensor([[0.0, 0.5, 1.0, 2.0, 0.1, 0.0, 1.0, 3.0, 0.2, 9.0]])
+    crit = PoissonLoss(SimpleNamespace(ds_scale=1), ds={"A": SimpleNamespace(dataset=range(4500))})
+    yh = ELU1()(u)
+    loss = crit(y_true=y, y_pred=yh, mouse_id="A", batch_size=16)
+    loss.backward()
+    uo = u.detach().clone().requires_grad_(True)
+    yo = O.elu1(uo)
+    lo = O.poisson_loss(y, yo, 4500.0, 16)
+    lo.backward()
+    # expm1 implementations differ by one fp32 ulp of 1.0 near u = -17 (vectorised vs scalar): absolute floor 1.2e-7
+    check("elu_edge.yhat", yh, yo, 1e-6, 1.2e-7)
+    check("elu_edge.loss", loss, lo, 1e-5, 0)
+    check("elu_edge.grad", u.grad, uo.grad, 1e-6, 1e-12)
+    out["elu_edge/u"], out["elu_edge/y_true"] = u.detach().numpy(), y.numpy()
+    out["elu_edge/yhat"], out["elu_edge/loss"], out["elu_edge/du"] = yh.detach().numpy(), np.float64(loss.item()), u.grad.numpy()
+    log("  elu edge: ok")
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
@@ -397,6 +422,7 @@ def main():
     print("G6 optimizer step")
     gen_step(d)
     gen_resize(d)
+    gen_elu_edge(d)
     save("g3_g5_g6.npz", d)
 
 

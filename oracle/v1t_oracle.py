@@ -357,9 +357,25 @@ def gaussian2d_readout(
     return out
 
 
+class _Elu(torch.autograd.Function):
+    """nn.ELU (alpha = 1) exactly as ATen evaluates it: forward expm1(u) for u <= 0 (so elu(u) + 1 is
+    quantised to multiples of 2^-24 near 0), backward exp(u) computed from the INPUT
+    (elu_backward with is_result = False), which stays non-zero where expm1(u) + 1 has rounded to 0."""
+
+    @staticmethod
+    def forward(ctx, u):
+        ctx.save_for_backward(u)
+        return torch.where(u > 0, u, torch.expm1(u))
+
+    @staticmethod
+    def backward(ctx, g):
+        (u,) = ctx.saved_tensors
+        return g * torch.where(u > 0, torch.ones_like(u), torch.exp(u))
+
+
 def elu1(u: Tensor) -> Tensor:
-    """ELU1 models/utils.py:109-118: elu(u) + 1 (expm1 form, as torch's ELU computes it)."""
-    return torch.where(u > 0, u, torch.expm1(u)) + 1.0
+    """ELU1 models/utils.py:109-118: nn.ELU()(u) + 1."""
+    return _Elu.apply(u) + 1.0
 
 
 EPS32 = float(torch.finfo(torch.float32).eps)

@@ -1,0 +1,55 @@
+"""Shared test helpers (test infrastructure; may import the oracle)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+MAX_SAMPLE = 4096
+
+
+def sample(x: torch.Tensor) -> np.ndarray:
+    """Same deterministic strided sample as oracle/gen_golden.py."""
+    f = x.detach().reshape(-1)
+    stride = max(1, -(-f.numel() // MAX_SAMPLE))
+    return f[::stride][:MAX_SAMPLE].to(torch.float32).cpu().numpy().copy()
+
+
+def _np(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().to(torch.float64).cpu().numpy()
+    return np.asarray(x, dtype=np.float64)
+
+
+def assert_close(name, got, ref, rtol, atol):
+    got = _np(got)
+    ref = _np(ref)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = np.abs(got - ref)
+    bound = atol + rtol * np.abs(ref)
+    worst = float((err / bound).max()) if err.size else 0.0
+    assert np.isfinite(got).all() and worst <= 1.0, f"{name}: max err {err.max():.3e}, {worst:.2f}x the bound (rtol {rtol}, atol {atol})"
+
+
+def rel_to_max(got, ref) -> float:
+    got = _np(got)
+    ref = _np(ref)
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def build_native_model(cfg, sd, device, dropout=None):
+    """v1t_amd.Model configured like the oracle Config `cfg`, weights loaded from state-dict `sd`."""
+    import v1t_amd
+    from v1t_amd.synthetic import default_args, make_ds
+
+    args = default_args(
+        input_shape=cfg.input_shape, resize_image=0, num_blocks=cfg.num_blocks, emb_dim=cfg.emb_dim, mlp_dim=cfg.mlp_dim,
+        num_heads=cfg.num_heads, behavior_mode=cfg.behavior_mode, use_lsa=cfg.use_lsa, disable_bias=cfg.disable_bias,
+        patch_mode=cfg.patch_mode, patch_stride=cfg.patch_stride, shift_mode=cfg.shift_mode,
+        disable_grid_predictor=cfg.disable_grid_predictor, grid_predictor_dim=cfg.grid_predictor_dim,
+        p_dropout=cfg.p_dropout, t_dropout=cfg.t_dropout,
+    )
+    args.output_shapes = {m: (cfg.num_neurons[m],) for m in cfg.mouse_ids}
+    model = v1t_amd.Model(args, make_ds(cfg.num_neurons))
+    r = model.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and set(r.missing_keys) <= {"image_cropper.grid", "elu1.one"}, r
+    return model.to(device), args

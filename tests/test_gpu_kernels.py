@@ -1,0 +1,204 @@
+"""GPU: each HIP kernel family through the C-ABI against a plain fp32 torch reference of the same op
+(the reference gets the SAME bf16-rounded inputs, so the tolerance covers accumulation order and the
+bf16 rounding of internal operands / outputs only)."""
+import math
+
+import pytest
+import torch
+
+from tests.helpers import rel_to_max
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from v1t_amd import lib as L
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return L.load(), L, torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 160, 160), (1000, 1920, 160), (257, 512, 160), (700, 160, 640), (129, 64, 256), (64, 768, 64), (1, 32, 32)])
+def test_gemm_nt(ctx, M, N, K):
+    lib, L, dev = ctx
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    B = torch.randn(N, K, generator=g).to(dev).bfloat16()
+    ref = A.float() @ B.float().t()
+    C = torch.empty(M, N, device=dev)
+    L.check(lib.v1t_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, M, N, K, C.data_ptr(), N, 1, L.stream()))
+    assert rel_to_max(C.cpu(), ref.cpu()) < 2e-6  # fp32 accumulate of exact bf16 products
+    Cb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    L.check(lib.v1t_gemm_nt(A.data_ptr(), K, B.data_ptr(), K, M, N, K, Cb.data_ptr(), N, 0, L.stream()))
+    assert rel_to_max(Cb.float().cpu(), ref.cpu()) < 4e-3  # one bf16 rounding of the output
+
+
+@pytest.mark.parametrize("M,NY,NX,mc", [(1000, 160, 512, 256), (3000, 1920, 160, 1024), (500, 512, 160, 128), (777, 64, 256, 128), (100, 160, 640, 128), (31, 32, 32, 32)])
+def test_gemm_tn(ctx, M, NY, NX, mc):
+    lib, L, dev = ctx
+    g = torch.Generator().manual_seed(M + NY)
+    Y = torch.randn(M, NY, generator=g).to(dev).bfloat16()
+    X = torch.randn(M, NX, generator=g).to(dev).bfloat16()
+    ref = Y.float().t() @ X.float()
+    dW = torch.zeros(NY, NX, device=dev)
+    L.check(lib.v1t_gemm_tn(Y.data_ptr(), NY, X.data_ptr(), NX, M, NY, NX, dW.data_ptr(), NX, mc, L.stream()))
+    assert rel_to_max(dW.cpu(), ref.cpu()) < 5e-6  # fp32 atomics: order-dependent last bits only
+    L.check(lib.v1t_gemm_tn(Y.data_ptr(), NY, X.data_ptr(), NX, M, NY, NX, dW.data_ptr(), NX, mc, L.stream()))
+    assert rel_to_max(dW.cpu(), 2 * ref.cpu()) < 5e-6  # accumulates (+=)
+
+
+def _attn_ref(qkv, B, H, T, DP, scale, mask=None, p=0.0, diag=False):
+    q, k, v = qkv.float().view(B, T, 3, H, DP).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * scale.view(1, -1, 1, 1)
+    if diag:
+        s = s.masked_fill(torch.eye(T, dtype=torch.bool, device=s.device), -torch.finfo(torch.float32).max)
+    a = torch.softmax(s, -1)
+    if mask is not None:
+        a = a * mask.view(B, H, T, T).float() / (1 - p)
+    return (a @ v).permute(0, 2, 1, 3).reshape(B * T, H * DP)
+
+
+@pytest.mark.parametrize("B,H,T,DP,p,lsa", [(2, 4, 1654, 160, 0.0, False), (2, 4, 1654, 64, 0.0, False), (1, 2, 100, 160, 0.0, False), (1, 1, 1, 32, 0.0, False),
+                                              (2, 3, 333, 64, 0.25, False), (1, 4, 1654, 160, 0.2544, False), (2, 2, 257, 96, 0.1, True), (1, 2, 130, 128, 0.0, True)])
+def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
+    lib, L, dev = ctx
+    g = torch.Generator().manual_seed(B * 1000 + T + DP)
+    qkv = (torch.randn(B * T, 3 * H * DP, generator=g) * 0.7).to(dev).bfloat16().requires_grad_(True)
+    scale = (torch.full((H,), DP ** -0.5) * (1 + 0.2 * torch.randn(H, generator=g))).to(dev) if lsa else torch.tensor([DP ** -0.5], device=dev)
+    scale_r = scale.clone().requires_grad_(True)
+    o = torch.empty(B * T, H * DP, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, T, device=dev)
+    seed, sid = 4242, 9
+    L.check(lib.v1t_attention_forward(qkv.data_ptr(), B, H, T, DP, scale.data_ptr(), int(lsa), int(lsa), p, seed, sid, o.data_ptr(), lse.data_ptr(), L.stream()))
+    mask = None
+    if p > 0:
+        mask = torch.empty(B * H * T, T, device=dev, dtype=torch.uint8)
+        L.check(lib.v1t_dropout_mask(seed, sid, p, B * H * T, T, mask.data_ptr(), L.stream()))
+        if mask.numel() > 10000:
+            assert abs(float(mask.float().mean()) - (1 - p)) < 5e-3  # keep rate of the counter-based mask
+    ref = _attn_ref(qkv, B, H, T, DP, scale_r if lsa else scale_r.expand(H), mask, p, diag=lsa)
+    assert rel_to_max(o.float().cpu(), ref.detach().cpu()) < 1e-2  # bf16 P and bf16 output
+    dO = (torch.randn(B * T, H * DP, generator=g) * 0.5).to(dev).bfloat16()
+    gq, gs = torch.autograd.grad(ref, (qkv, scale_r), dO.float())
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, T, device=dev)
+    dscale = torch.zeros(H if lsa else 1, device=dev)
+    L.check(lib.v1t_attention_backward(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), int(lsa), int(lsa), p, seed,
+                                       sid, delta.data_ptr(), dqkv.data_ptr(), dscale.data_ptr(), L.stream()))
+    gq, d = gq.view(B * T, 3, H * DP), dqkv.float().view(B * T, 3, H * DP)
+    for i, nm in enumerate("qkv"):
+        if float(gq[:, i].abs().max()) > 0:
+            assert rel_to_max(d[:, i].cpu(), gq[:, i].cpu()) < 2e-2, nm  # bf16 P / dS / outputs
+    if T > 1:
+        assert rel_to_max(dscale.cpu(), gs.cpu()) < 2e-2
+
+
+@pytest.mark.parametrize("B,C,H,W,N", [(3, 155, 29, 57, 1000), (2, 64, 29, 57, 257), (1, 40, 15, 29, 3)])
+def test_readout(ctx, B, C, H, W, N):
+    from oracle import v1t_oracle as O
+
+    lib, L, dev = ctx
+    g = torch.Generator().manual_seed(N)
+    z = torch.randn(B, C, H, W, generator=g).to(dev)
+    grid = (torch.rand(B, N, 2, generator=g) * 2.4 - 1.2).to(dev)  # includes points outside [-1, 1] (zero padding)
+    grid[0, 0] = torch.tensor([-1.0, -1.0])
+    grid[0, min(1, N - 1)] = torch.tensor([1.0, 1.0])
+    FS = (C + 31) // 32 * 32
+    feat = torch.zeros(N, FS, device=dev)
+    feat[:, :C] = torch.randn(N, C, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    zr, gr, fr = z.clone().requires_grad_(True), grid.clone().requires_grad_(True), feat[:, :C].clone().requires_grad_(True)
+    ref = (O.bilinear_sample(zr, gr) * fr.t()[None]).sum(1) + bias
+    zl = z.permute(0, 2, 3, 1).contiguous()
+    out = torch.empty(B, N, device=dev)
+    L.check(lib.v1t_gaussian2d_forward(zl.data_ptr(), H * W * C, C, B, C, H, W, N, grid.data_ptr(), feat.data_ptr(), FS, bias.data_ptr(), out.data_ptr(), L.stream()))
+    assert rel_to_max(out.cpu(), ref.detach().cpu()) < 2e-6
+    go = torch.randn(B, N, generator=g).to(dev)
+    gz, gg, gf = torch.autograd.grad(ref, (zr, gr, fr), go)
+    dz, dgrid, dfeat, dbias = torch.zeros_like(zl), torch.empty_like(grid), torch.zeros_like(feat), torch.zeros_like(bias)
+    L.check(lib.v1t_gaussian2d_backward(zl.data_ptr(), H * W * C, C, B, C, H, W, N, grid.data_ptr(), feat.data_ptr(), FS, go.data_ptr(), dz.data_ptr(), H * W * C, C,
+                                        dgrid.data_ptr(), dfeat.data_ptr(), dbias.data_ptr(), L.stream()))
+    assert rel_to_max(dz.permute(0, 3, 1, 2).cpu(), gz.cpu()) < 5e-6
+    assert rel_to_max(dgrid.cpu(), gg.cpu()) < 5e-6
+    assert rel_to_max(dfeat[:, :C].cpu(), gf.cpu()) < 5e-6
+    assert rel_to_max(dbias.cpu(), go.sum(0).cpu()) < 5e-6
+
+
+@pytest.mark.parametrize("B,T,D,DP", [(2, 1654, 64, 64), (2, 1654, 155, 160), (3, 100, 40, 64)])
+def test_layernorm(ctx, B, T, D, DP):
+    from oracle import v1t_oracle as O
+
+    lib, L, dev = ctx
+    g = torch.Generator().manual_seed(D)
+    x = torch.zeros(B, T, DP)
+    x[:, :, :D] = torch.randn(B, T, D, generator=g)
+    inj = torch.zeros(B, DP)
+    inj[:, :D] = torch.randn(B, D, generator=g)
+    gd, bd = (1 + 0.1 * torch.randn(D, generator=g)).to(dev), (0.1 * torch.randn(D, generator=g)).to(dev)
+    xd, injd = x.to(dev), inj.to(dev)
+    xout, z = torch.empty_like(xd), torch.empty(B, T, DP, device=dev, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(B * T, device=dev), torch.empty(B * T, device=dev)
+    L.check(lib.v1t_layernorm_forward(xd.data_ptr(), injd.data_ptr(), xout.data_ptr(), gd.data_ptr(), bd.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, T, D, DP, 1e-5, L.stream()))
+    xr = (xd[:, :, :D] + injd[:, None, :D]).requires_grad_(True)
+    gam = gd.clone().requires_grad_(True)
+    ref = O.layer_norm(xr, gam, bd)
+    assert rel_to_max(z[:, :, :D].float().cpu(), ref.detach().cpu()) < 4e-3  # bf16 output
+    assert float(z[:, :, D:].float().abs().max()) == 0.0 if DP > D else True
+    dz, gin = torch.zeros(B, T, DP), torch.zeros(B, T, DP)
+    dz[:, :, :D], gin[:, :, :D] = torch.randn(B, T, D, generator=g), torch.randn(B, T, D, generator=g)
+    dzd, gind = dz.to(dev), gin.to(dev)
+    gout = torch.empty_like(gind)
+    dgamma, dbeta, dinj, dbn = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(B, DP, device=dev), torch.zeros(D, device=dev)
+    dyn = torch.empty(B, T, DP, device=dev, dtype=torch.bfloat16)
+    L.check(lib.v1t_layernorm_backward(dzd.data_ptr(), xout.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(), gind.data_ptr(), gout.data_ptr(), dgamma.data_ptr(),
+                                       dbeta.data_ptr(), dinj.data_ptr(), dyn.data_ptr(), dbn.data_ptr(), B, T, D, DP, L.stream()))
+    gx, gg = torch.autograd.grad(ref, (xr, gam), dzd[:, :, :D])
+    full = gx + gind[:, :, :D]
+    assert rel_to_max(gout[:, :, :D].cpu(), full.cpu()) < 2e-6
+    assert rel_to_max(dgamma.cpu(), gg.cpu()) < 5e-6
+    assert rel_to_max(dbeta.cpu(), dzd[:, :, :D].sum((0, 1)).cpu()) < 5e-6
+    assert rel_to_max(dinj[:, :D].cpu(), full.sum(1).cpu()) < 5e-6
+    assert rel_to_max(dyn[:, :, :D].float().cpu(), full.cpu()) < 4e-3
+
+
+def test_adamw_l1_and_loss(ctx):
+    from oracle import v1t_oracle as O
+
+    lib, L, dev = ctx
+    g = torch.Generator().manual_seed(3)
+    n = 100003
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    p, grad, m, v = p0.to(dev), gr.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    params, st = {"p": p0.clone()}, {}
+    for step in (1, 2, 3):
+        L.check(lib.v1t_adamw_step(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1.647e-3, 0.9, 0.9999, 1e-8, 0.0, step, 0.5, 0, L.stream()))
+        O.adamw_step(params, {"p": gr + 0.5 * torch.sign(params["p"])}, st, step=step, lr=1.647e-3)
+    assert rel_to_max(p.cpu(), params["p"]) < 1e-6
+    out = torch.zeros((), device=dev)
+    L.check(lib.v1t_l1_sum(p.data_ptr(), n, 0.25, out.data_ptr(), L.stream()))
+    assert abs(float(out) - 0.25 * float(p.abs().sum())) / float(out) < 1e-5
+    # ELU1 + Poisson
+    u = (torch.randn(16, 1000, generator=g) * 3).to(dev)
+    u[0, :4] = torch.tensor([-20.0, -17.0, 0.0, 15.0], device=dev)
+    y = torch.empty(16, 1000).exponential_(1.0, generator=g).to(dev)
+    ur = u.clone().requires_grad_(True)
+    yh_ref = O.elu1(ur)
+    loss_ref = O.poisson_loss(y, yh_ref, 4500.0, 16)
+    (gu,) = torch.autograd.grad(loss_ref, ur)
+    yh, du, loss = torch.empty_like(u), torch.empty_like(u), torch.zeros((), device=dev)
+    L.check(lib.v1t_elu1_poisson(u.data_ptr(), y.data_ptr(), u.numel(), math.sqrt(4500.0 / 16), 1.0, yh.data_ptr(), du.data_ptr(), loss.data_ptr(), L.stream()))
+    assert torch.allclose(yh, yh_ref.detach(), rtol=1e-6, atol=1.2e-7)  # incl. the expm1 quantisation near 0
+    assert abs(float(loss) - float(loss_ref)) / abs(float(loss_ref)) < 1e-5
+    assert rel_to_max(du.cpu(), gu.cpu()) < 1e-5
+
+
+def test_elu1_poisson_edge_vs_reference_golden(ctx, golden):
+    lib, L, dev = ctx
+    u = torch.from_numpy(golden["elu_edge/u"]).to(dev)
+    y = torch.from_numpy(golden["elu_edge/y_true"]).to(dev)
+    yh, du, loss = torch.empty_like(u), torch.empty_like(u), torch.zeros((), device=dev)
+    L.check(lib.v1t_elu1_poisson(u.data_ptr(), y.data_ptr(), u.numel(), math.sqrt(4500.0 / 16), 1.0, yh.data_ptr(), du.data_ptr(), loss.data_ptr(), L.stream()))
+    assert torch.allclose(yh.cpu(), torch.from_numpy(golden["elu_edge/yhat"]), rtol=1e-6, atol=1.2e-7)
+    assert abs(float(loss) - float(golden["elu_edge/loss"])) <= 1e-5 * abs(float(golden["elu_edge/loss"]))
+    assert rel_to_max(du.cpu(), golden["elu_edge/du"]) < 1e-5

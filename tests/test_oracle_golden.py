@@ -1,0 +1,129 @@
+"""CPU: the oracle (oracle/v1t_oracle.py) against the golden vectors generated from the real reference
+(oracle/gen_golden.py, run in the build container). This is what pins the oracle on the GPU box where
+/root/reference does not exist."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import v1t_oracle as O
+from oracle import weights as W
+from tests.helpers import assert_close, sample
+
+RTOL, ATOL = 2e-4, 2e-5  # fp32 re-association between torch's fused kernels and the elementary restatement
+
+
+def _grads(cfg, sd, batch, mouse, eps=None):
+    sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    loss, reg, y = O.total_loss(cfg, sdd, batch, mouse, 4500.0, eps=eps)
+    (loss + reg).backward()
+    return loss.detach(), reg.detach(), y.detach(), sdd
+
+
+@pytest.mark.parametrize("name,cfg_fn,train", [("g1", W.config_c1, False), ("g4", W.config_c1, True), ("g2b", W.config_c4, False)])
+def test_forward_backward_vs_golden(golden, name, cfg_fn, train):
+    cfg = cfg_fn()
+    if train:
+        cfg.p_dropout = cfg.t_dropout = 0.0
+    sd = W.make_state_dict(cfg, 1234)
+    batch = W.make_batch(cfg, "A", 2, 1234)
+    eps = torch.from_numpy(golden[f"{name}/eps"]) if train else None
+    loss, reg, y, sdd = _grads(cfg, sd, batch, "A", eps)
+    assert_close(f"{name}.y", y.numpy(), golden[f"{name}/y"], RTOL, ATOL)
+    assert_close(f"{name}.loss", loss.item(), golden[f"{name}/loss"], RTOL, ATOL)
+    assert_close(f"{name}.reg", reg.item(), golden[f"{name}/reg"], RTOL, ATOL)
+    n = 0
+    for k in golden:
+        if k.startswith(f"{name}/grad/"):
+            key = k[len(name) + 6 :]
+            g = sdd[key].grad
+            g = torch.zeros_like(sdd[key]) if g is None else g
+            ref = golden[k]
+            assert_close(f"{name}.grad.{key}", sample(g), ref, 1e-3, 1e-3 * float(np.abs(ref).max()) + 1e-7)
+            n += 1
+    assert n >= 20
+
+
+def test_taps_vs_golden(golden):
+    cfg = W.config_c1()
+    sd = W.make_state_dict(cfg, 1234)
+    batch = W.make_batch(cfg, "A", 2, 1234)
+    taps = {}
+    with torch.no_grad():
+        O.model_forward(cfg, sd, batch["image"], "A", batch["behavior"], batch["pupil_center"], taps=taps)
+    for k in ("patch_embed", "mha0", "mlp0", "core"):
+        assert_close(k, sample(taps[k]), golden[f"g1/tap/{k}"], RTOL, ATOL)
+
+
+def test_variants_vs_golden(golden):
+    base = dict(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 200, "B": 123})
+    variants = {
+        "beh0": dict(behavior_mode=0), "beh2": dict(behavior_mode=2), "beh4": dict(behavior_mode=4), "franke": dict(input_shape=(2, 36, 64)),
+        "nogridpred": dict(disable_grid_predictor=True), "grid3": dict(grid_predictor_dim=3), "lsa": dict(use_lsa=True),
+        "nobias": dict(disable_bias=True), "patch1": dict(patch_mode=1), "patch2": dict(patch_mode=2), "patch3": dict(patch_mode=3),
+        "stride2": dict(patch_stride=2), "noshift": dict(shift_mode=0), "heads3_d40": dict(num_heads=3, emb_dim=40, mlp_dim=72),
+    }
+    for vn, kw in variants.items():
+        cfg = O.Config(**{**base, **kw})
+        sd = W.make_state_dict(cfg, 77)
+        for mouse in ("A", "B"):
+            b = W.make_batch(cfg, mouse, 2, 77)
+            with torch.no_grad():
+                y = O.model_forward(cfg, sd, b["image"], mouse, b["behavior"], b["pupil_center"])
+            assert_close(f"variant.{vn}.{mouse}", y.numpy(), golden[f"variant/{vn}/{mouse}/y"], RTOL, ATOL)
+
+
+def test_rollout_vs_golden(golden):
+    cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 64})
+    sd = W.make_state_dict(cfg, 99)
+    b = W.make_batch(cfg, "A", 2, 99)
+    rec = []
+    with torch.no_grad():
+        O.vit_tokens(cfg, sd, b["image"], "A", b["behavior"], b["pupil_center"], record=rec)
+    attn = torch.stack(rec, dim=1)
+    assert_close("attn", sample(attn), golden["rollout/attn_sample"], 2e-4, 1e-7)
+    for i in range(2):
+        assert_close("row", O.attention_rollout_row(attn[i]).numpy(), golden["rollout/row"][i], 1e-4, 1e-9)
+        # min-max normalisation amplifies fp32 re-association: absolute tolerance on [0,1]
+        assert_close("heat", O.attention_rollout(attn[i], (36, 64)).numpy(), golden["rollout/heatmap"][i], 1e-3, 2e-4)
+
+
+def test_optimizer_step_vs_golden(golden):
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 200, "B": 123}, p_dropout=0.0, t_dropout=0.0)
+    sd = W.make_state_dict(cfg, 55)
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    for m in cfg.mouse_ids:
+        b = W.make_batch(cfg, m, 4, 55)
+        l, r, _ = O.total_loss(cfg, osd, b, m, 4500.0, eps=torch.from_numpy(golden[f"step/eps/{m}"]))
+        (l + r).backward()
+    keys = O.core_param_keys(sd)
+    for m in cfg.mouse_ids:
+        keys += O.readout_param_keys(sd, m) + O.shifter_param_keys(sd, m)
+    params = {k: osd[k].detach() for k in keys}
+    O.adamw_step(params, {k: osd[k].grad for k in keys}, {}, step=1, lr=1.647e-3)
+    for k in keys:
+        assert_close(f"step.{k}", sample(params[k]), golden[f"step/param/{k}"], 1e-4, 1e-6)
+
+
+def test_resize_vs_golden(golden):
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 1, 144, 256)).astype(np.float32))
+    assert_close("resize", sample(O.resize_bilinear(x, (36, 64))), golden["resize/out_sample"], 1e-5, 1e-6)
+
+
+def test_edge_cases():
+    """grid points exactly on / beyond +-1 (zero padding after the shift), B = 1."""
+    z = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
+    grid = torch.tensor([[[-1.0, -1.0], [1.0, 1.0], [1.5, 0.0], [0.0, -1.2], [1.0 + 1e-7, 1.0]]]).expand(2, -1, -1)
+    ref = torch.nn.functional.grid_sample(z, grid[:, :, None, :], align_corners=True)[..., 0]
+    assert_close("edges", O.bilinear_sample(z, grid).numpy(), ref.numpy(), 1e-6, 1e-6)
+    assert O.find_shape(1653) == (29, 57) and O.find_shape(436 - 1) == (15, 29)
+
+
+def test_elu1_poisson_edge_vs_golden(golden):
+    u = torch.from_numpy(golden["elu_edge/u"]).requires_grad_(True)
+    y = torch.from_numpy(golden["elu_edge/y_true"])
+    yh = O.elu1(u)
+    loss = O.poisson_loss(y, yh, 4500.0, 16)
+    loss.backward()
+    assert_close("yhat", yh.detach().numpy(), golden["elu_edge/yhat"], 1e-6, 1.2e-7)
+    assert_close("loss", loss.item(), golden["elu_edge/loss"], 1e-5, 0)
+    assert_close("du", u.grad.numpy(), golden["elu_edge/du"], 1e-6, 1e-12)

@@ -37,6 +37,7 @@ struct BlockOff {
     std::vector<BmlpOff> bmlp;
     // shadow (bytes)
     long long s_qkv, s_qkv_t, s_proj, s_proj_t, s_fc1, s_fc1_t, s_fc2, s_fc2_t, s_projb, s_fc1b, s_fc2b;
+    long long s_qkv_lo, s_proj_lo, s_fc1_lo, s_fc2_lo;  // low planes of the forward weights (split-bf16)
 };
 
 inline long long align_up(long long x, long long a) { return (x + a - 1) / a * a; }
@@ -79,6 +80,7 @@ struct WsLayout {
     long long x0, beta, hid;
     // per block
     long long blk_stride, xa, xm, xo, z1, qkv, o, lse2, mean1, rstd1, z2, mean2, rstd2, hpre, hact;
+    long long z1_lo, o_lo, z2_lo, hact_lo;  // low planes (forward-only consumers)
     long long total;
 };
 
@@ -109,10 +111,15 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
     w.rstd2 = take(R * 4) - b0;
     w.hpre = take(R * h->MP * 2) - b0;
     w.hact = take(R * h->MP * 2) - b0;
+    w.z1_lo = take(R * h->DP * 2) - b0;
+    w.o_lo = take(R * h->HDP * 2) - b0;
+    w.z2_lo = take(R * h->DP * 2) - b0;
+    w.hact_lo = take(R * h->MP * 2) - b0;
     w.blk_stride = cur - b0;
     w.total = b0 + (save ? (long long)h->NB : 1LL) * w.blk_stride;
     w.xa += b0; w.xm += b0; w.xo += b0; w.z1 += b0; w.qkv += b0; w.o += b0; w.lse2 += b0;
     w.mean1 += b0; w.rstd1 += b0; w.z2 += b0; w.mean2 += b0; w.rstd2 += b0; w.hpre += b0; w.hact += b0;
+    w.z1_lo += b0; w.o_lo += b0; w.z2_lo += b0; w.hact_lo += b0;
     return w;
 }
 
@@ -175,7 +182,50 @@ int find_shape(int n, int* h, int* w) {
 
 }  // namespace
 
+// ---- per-launch event timing of one kernel class
+namespace {
+struct Prof {
+    int cls = -1;
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+    int used = 0;
+} g_prof;
+}  // namespace
+void prof_begin(int cls, hipStream_t s) {
+    if (cls != g_prof.cls || g_prof.used + 2 > (int)g_prof.ev.size()) return;
+    (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+}
+void prof_end(int cls, hipStream_t s) {
+    if (cls != g_prof.cls || g_prof.used + 2 > (int)g_prof.ev.size()) return;
+    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
+    g_prof.used += 2;
+}
+
 extern "C" {
+
+int v1t_profile_enable(int kernel_class, int max_launches) {
+    for (auto e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.used = 0;
+    g_prof.cls = kernel_class;
+    if (kernel_class < 0) return V1T_OK;
+    g_prof.ev.resize(2 * (size_t)std::max(max_launches, 0));
+    for (auto& e : g_prof.ev)
+        if (hipEventCreate(&e) != hipSuccess) return V1T_ERR_LAUNCH;
+    return V1T_OK;
+}
+int v1t_profile_read(int* launches, double* total_ms) {
+    double tot = 0.0;
+    for (int i = 0; i + 1 < g_prof.used; i += 2) {
+        if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) return V1T_ERR_LAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess) return V1T_ERR_LAUNCH;
+        tot += ms;
+    }
+    if (launches) *launches = g_prof.used / 2;
+    if (total_ms) *total_ms = tot;
+    g_prof.used = 0;
+    return V1T_OK;
+}
 
 int v1t_abi_version(void) { return 1; }
 
@@ -269,7 +319,7 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     auto desc = [&](long long src, int src_ld, long long dst, int drows, int dcols, int rp, int rv, int cp, int cv, int tr, int f32) {
         PackDesc d;
         d.src_off = src; d.dst_off = dst; d.src_ld = src_ld; d.drows = drows; d.dcols = dcols;
-        d.rseg_pad = rp; d.rseg_valid = rv; d.cseg_pad = cp; d.cseg_valid = cv; d.transpose = tr; d.out_f32 = f32;
+        d.rseg_pad = rp; d.rseg_valid = rv; d.cseg_pad = cp; d.cseg_valid = cv; d.transpose = tr; d.out_f32 = f32 & 1; d.lo_plane = (f32 >> 1) & 1;
         h->pack.push_back(d);
     };
     for (int k = 0; k < h->NB; ++k) {
@@ -283,6 +333,10 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
         b.s_fc1_t = stake((long long)MP * DP * 2); desc(b.fc1, D, b.s_fc1_t, DP, MP, MP, M, DP, D, 1, 0);
         b.s_fc2 = stake((long long)DP * MP * 2);   desc(b.fc2, M, b.s_fc2, DP, MP, DP, D, MP, M, 0, 0);
         b.s_fc2_t = stake((long long)DP * MP * 2); desc(b.fc2, M, b.s_fc2_t, MP, DP, DP, D, MP, M, 1, 0);
+        b.s_qkv_lo = stake(3LL * HDP * DP * 2);       desc(b.qkv, D, b.s_qkv_lo, 3 * HDP, DP, DP, D, DP, D, 0, 2);
+        b.s_proj_lo = stake((long long)DP * HDP * 2); desc(b.proj, h->HD, b.s_proj_lo, DP, HDP, DP, D, DP, D, 0, 2);
+        b.s_fc1_lo = stake((long long)MP * DP * 2);   desc(b.fc1, D, b.s_fc1_lo, MP, DP, MP, M, DP, D, 0, 2);
+        b.s_fc2_lo = stake((long long)DP * MP * 2);   desc(b.fc2, M, b.s_fc2_lo, DP, MP, DP, D, MP, M, 0, 2);
         b.s_projb = b.s_fc1b = b.s_fc2b = -1;
         if (bias) {
             b.s_projb = stake(DP * 4); desc(b.projb, D, b.s_projb, 1, DP, 1, 1, DP, D, 0, 1);
@@ -410,41 +464,45 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
 
         LnFwdArgs l1{};
         l1.x = xcur; l1.inject = h->inject ? (float*)(ws + w.beta) + (size_t)k * B * DP : nullptr; l1.xout = xa;
-        l1.gamma = arena + b.ln1w; l1.beta = arena + b.ln1b; l1.z = z1;
+        l1.gamma = arena + b.ln1w; l1.beta = arena + b.ln1b; l1.z = z1; l1.z_lo = (bf16_t*)(wb + w.z1_lo);
         l1.mean = (float*)(wb + w.mean1); l1.rstd = (float*)(wb + w.rstd1);
         l1.rows = R; l1.T = h->T; l1.D = D; l1.DP = DP; l1.eps = h->c.ln_eps;
         CHECK(launch_ln_fwd(l1, s));
 
         GemmNTArgs g{};
         g.A = z1; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_qkv); g.ldb = DP; g.M = R; g.N = 3 * HDP; g.K = DP; g.C = qkv; g.ldc = 3 * HDP;
+        g.A_lo = (const bf16_t*)(wb + w.z1_lo); g.B_lo = (const bf16_t*)(sh + b.s_qkv_lo);
         CHECK(launch_gemm_nt(g, EPI_BF16, s));
 
         AttnArgs at{};
-        at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = o; at.ldo = HDP; at.lse2 = (float*)(wb + w.lse2);
+        at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = o; at.ldo = HDP; at.o_lo = (bf16_t*)(wb + w.o_lo); at.lse2 = (float*)(wb + w.lse2);
         at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
         at.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 0);
         CHECK(launch_attn_fwd(at, DP, s));
 
         g = GemmNTArgs{};
         g.A = o; g.lda = HDP; g.B = (const bf16_t*)(sh + b.s_proj); g.ldb = HDP; g.M = R; g.N = DP; g.K = HDP; g.C = xm; g.ldc = DP;
+        g.A_lo = (const bf16_t*)(wb + w.o_lo); g.B_lo = (const bf16_t*)(sh + b.s_proj_lo);
         g.bias = b.s_projb >= 0 ? (const float*)(sh + b.s_projb) : nullptr; g.res = xa; g.ldres = DP;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 1);
         CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));
 
         LnFwdArgs l2{};
-        l2.x = xm; l2.inject = nullptr; l2.xout = nullptr; l2.gamma = arena + b.ln2w; l2.beta = arena + b.ln2b; l2.z = z2;
+        l2.x = xm; l2.inject = nullptr; l2.xout = nullptr; l2.gamma = arena + b.ln2w; l2.beta = arena + b.ln2b; l2.z = z2; l2.z_lo = (bf16_t*)(wb + w.z2_lo);
         l2.mean = (float*)(wb + w.mean2); l2.rstd = (float*)(wb + w.rstd2);
         l2.rows = R; l2.T = h->T; l2.D = D; l2.DP = DP; l2.eps = h->c.ln_eps;
         CHECK(launch_ln_fwd(l2, s));
 
         g = GemmNTArgs{};
         g.A = z2; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_fc1); g.ldb = DP; g.M = R; g.N = MP; g.K = DP; g.C = hpre; g.ldc = MP;
+        g.A_lo = (const bf16_t*)(wb + w.z2_lo); g.B_lo = (const bf16_t*)(sh + b.s_fc1_lo); g.C2_lo = (bf16_t*)(wb + w.hact_lo);
         g.C2 = hact; g.ldc2 = MP; g.bias = b.s_fc1b >= 0 ? (const float*)(sh + b.s_fc1b) : nullptr;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
         CHECK(launch_gemm_nt(g, EPI_BIAS_GELU, s));
 
         g = GemmNTArgs{};
         g.A = hact; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc2); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = xo; g.ldc = DP;
+        g.A_lo = (const bf16_t*)(wb + w.hact_lo); g.B_lo = (const bf16_t*)(sh + b.s_fc2_lo);
         g.bias = b.s_fc2b >= 0 ? (const float*)(sh + b.s_fc2b) : nullptr; g.res = xm; g.ldres = DP;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 3);
         CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));

@@ -9,6 +9,7 @@
 struct AttnArgs {
     const bf16_t* qkv; int ldqkv;  // [rows][3*H*DP]: q | k | v, each H heads of DP (zero padded) columns
     bf16_t* o; int ldo;            // [rows][H*DP]
+    bf16_t* o_lo;                  // forward only: low plane of o (o - float(bf16(o))) or nullptr
     float* lse2;                   // [B][H][T]  log2-domain: max + log2(sum)
     int B, H, T;
     const float* scale;            // device: 1 value, or H values when scale_per_head

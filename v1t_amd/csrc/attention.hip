@@ -156,10 +156,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int d = 0; d < G::DB; ++d)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                bf16x4 w;
+                bf16x4 w, wl;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(o[d][4 * rq + j] * inv);
+                for (int j = 0; j < 4; ++j) {
+                    const float v = o[d][4 * rq + j] * inv;
+                    w[j] = (bf16_t)v;
+                    wl[j] = (bf16_t)(v - (float)w[j]);
+                }
                 *(bf16x4*)(orow + 32 * d + 8 * rq + 4 * h2) = w;
+                if (a.o_lo) *(bf16x4*)(a.o_lo + (orow - a.o) + 32 * d + 8 * rq + 4 * h2) = wl;
             }
     }
 }
@@ -423,14 +428,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
 template <int DP>
 int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.T + 127) / 128, a.H, a.B);
+    prof_begin(PROF_ATTN_FWD, s);
     hipLaunchKernelGGL((attn_fwd_kernel<DP>), grid, dim3(256), 0, s, a);
+    prof_end(PROF_ATTN_FWD, s);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 template <int DP>
 int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.T + 127) / 128, a.H, a.B);
+    prof_begin(PROF_ATTN_DQ, s);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DP>), grid, dim3(256), 0, s, a);
+    prof_end(PROF_ATTN_DQ, s);
+    prof_begin(PROF_ATTN_DKV, s);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP>), grid, dim3(256), 0, s, a);
+    prof_end(PROF_ATTN_DKV, s);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 template <int DP>

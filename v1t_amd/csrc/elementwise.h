@@ -15,6 +15,7 @@ struct PackDesc {
     int rseg_pad, rseg_valid, cseg_pad, cseg_valid;  // maps in SOURCE orientation (rows, cols of the natural matrix)
     int transpose;      // dst[r][c] = src[c][r]
     int out_f32;
+    int lo_plane;       // bf16 only: write the residual bf16(v - float(bf16(v))) (low plane of the split-bf16 operand)
 };
 int launch_pack(const float* params, void* shadow, const PackDesc* d_desc, int ndesc, hipStream_t s);
 
@@ -40,6 +41,7 @@ struct LnFwdArgs {
     float* xout;         // [rows][DP] (may alias x when inject == nullptr -> not written)
     const float* gamma; const float* beta;  // [D] natural
     bf16_t* z;           // [rows][DP]
+    bf16_t* z_lo;        // [rows][DP] low plane (z - float(bf16(z))) or nullptr
     float* mean; float* rstd;  // [rows]
     int rows, T, D, DP;
     float eps;

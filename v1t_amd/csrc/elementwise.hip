@@ -16,6 +16,7 @@ __global__ void pack_kernel(const float* __restrict__ params, char* shadow, cons
         if (rr < d.rseg_valid && cr < d.cseg_valid)
             v = params[d.src_off + (long long)(rs * d.rseg_valid + rr) * d.src_ld + cs * d.cseg_valid + cr];
         if (d.out_f32) ((float*)(shadow + d.dst_off))[i] = v;
+        else if (d.lo_plane) ((bf16_t*)(shadow + d.dst_off))[i] = (bf16_t)(v - (float)(bf16_t)v);
         else ((bf16_t*)(shadow + d.dst_off))[i] = (bf16_t)v;
     }
 }
@@ -183,7 +184,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
         const int c = lane + 64 * i;
         if (c < a.DP) {
             const float z = (c < a.D) ? (v[i] - mean) * rstd * a.gamma[c] + a.beta[c] : 0.f;
-            a.z[(size_t)row * a.DP + c] = (bf16_t)z;
+            const bf16_t zh = (bf16_t)z;
+            a.z[(size_t)row * a.DP + c] = zh;
+            if (a.z_lo) a.z_lo[(size_t)row * a.DP + c] = (bf16_t)(z - (float)zh);
         }
     }
     if (lane == 0) {

@@ -17,6 +17,12 @@ enum GemmEpi {
 struct GemmNTArgs {
     const bf16_t* A; int lda;
     const bf16_t* B; int ldb;
+    // split-bf16 ("bf16x3") mode when A_lo != nullptr: A = A + A_lo, B = B + B_lo (each a bf16 plane of the
+    // same layout), acc += A.B + A_lo.B + A.B_lo  -> ~2^-17 relative operand precision at 3 MFMAs per step.
+    // Used by the four forward linear layers, whose bf16 operand rounding otherwise dominates the error
+    // of the predicted responses (DESIGN.md "Numerics").
+    const bf16_t* A_lo; const bf16_t* B_lo;
+    bf16_t* C2_lo;                // EPI_BIAS_GELU: low plane of the activation output
     int M, N, K;  // M = valid rows (guarded); N % (32*NBLK) == 0; K % 32 == 0
     void* C; int ldc;
     const float* bias;            // [N] fp32 (padded with zeros) or nullptr

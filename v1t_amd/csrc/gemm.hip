@@ -14,6 +14,60 @@ constexpr int BK = 32;
 constexpr int LS = BK + 8;  // LDS row stride in elements (80 B)
 
 template <int NBLK, int EPI>
+DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], int m0, int n0, int wave, int lane) {
+    // ---- epilogue: col = n0 + 32nb + (lane&31); row = m0 + 32wave + acc_row(r, lane)
+    const int rbase = m0 + 32 * wave;
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+        const int col = n0 + 32 * nb + (lane & 31);
+        float bias = 0.f;
+        if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU) bias = g.bias ? g.bias[col] : 0.f;
+        float csum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + acc_row(r, lane);
+            const bool ok = row < g.M;
+            float v = acc[nb][r];
+            if constexpr (EPI == EPI_BF16) {
+                if (ok) ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = (bf16_t)v;
+            } else if constexpr (EPI == EPI_F32) {
+                if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = v;
+            } else if constexpr (EPI == EPI_BIAS_RES) {
+                v += bias;
+                if (g.drop.thresh) v = drop_keep(g.drop.key, row, col, g.drop.thresh) ? v * g.drop.inv_keep : 0.f;
+                if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = g.res[(size_t)row * g.ldres + col] + v;
+            } else if constexpr (EPI == EPI_BIAS_GELU) {
+                v += bias;
+                float a = gelu_erf(v);
+                if (g.drop.thresh) a = drop_keep(g.drop.key, row, col, g.drop.thresh) ? a * g.drop.inv_keep : 0.f;
+                if (ok) {
+                    ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = (bf16_t)v;
+                    const bf16_t ah = (bf16_t)a;
+                    g.C2[(size_t)row * g.ldc2 + col] = ah;
+                    if (g.C2_lo) g.C2_lo[(size_t)row * g.ldc2 + col] = (bf16_t)(a - (float)ah);
+                }
+            } else if constexpr (EPI == EPI_DGELU) {
+                float d = 0.f;
+                if (ok) {
+                    const float hp = (float)g.aux[(size_t)row * g.ldaux + col];
+                    d = v * gelu_erf_grad(hp);
+                    if (g.drop.thresh) d = drop_keep(g.drop.key, row, col, g.drop.thresh) ? d * g.drop.inv_keep : 0.f;
+                    const bf16_t db = (bf16_t)d;
+                    ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = db;
+                    d = (float)db;
+                }
+                csum += d;
+            }
+        }
+        if constexpr (EPI == EPI_DGELU) {
+            csum += __shfl_xor(csum, 32);
+            if (g.colsum && lane < 32 && col < g.n_valid) atomicAdd(&g.colsum[col], csum);
+        }
+    }
+}
+
+
+template <int NBLK, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs g) {
     constexpr int BN = 32 * NBLK;
     constexpr int B_CHUNKS = BN * 4;                  // 16-B chunks in a B tile
@@ -83,53 +137,89 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: col = n0 + 32nb + (lane&31); row = m0 + 32wave + acc_row(r, lane)
-    const int rbase = m0 + 32 * wave;
+    gemm_epilogue<NBLK, EPI>(g, acc, m0, n0, wave, lane);
+}
+
+
+// Split-bf16 variant (see GemmNTArgs): single LDS buffer (hi + lo planes of A and B), next tile's global
+// loads in flight during the MFMAs, two barriers per K-tile.
+template <int NBLK, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_split_kernel(GemmNTArgs g) {
+    constexpr int BN = 32 * NBLK;
+    constexpr int B_CHUNKS = BN * 4;
+    constexpr int B_ITERS = (B_CHUNKS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16_t sA[2][BM * LS];   // [plane]
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntn = g.N / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = lid / ntn, tile_n = lid % ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = g.K / BK;
+
+    u32x4 ra[2][2], rb[2][B_ITERS];
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
 #pragma unroll
-    for (int nb = 0; nb < NBLK; ++nb) {
-        const int col = n0 + 32 * nb + (lane & 31);
-        float bias = 0.f;
-        if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU) bias = g.bias ? g.bias[col] : 0.f;
-        float csum = 0.f;
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            const int gr = m0 + row;
+            const size_t off = (size_t)gr * g.lda + k0 + 8 * kc;
+            ra[0][i] = (gr < g.M) ? *(const u32x4*)(g.A + off) : u32x4{0, 0, 0, 0};
+            ra[1][i] = (gr < g.M) ? *(const u32x4*)(g.A_lo + off) : u32x4{0, 0, 0, 0};
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rbase + acc_row(r, lane);
-            const bool ok = row < g.M;
-            float v = acc[nb][r];
-            if constexpr (EPI == EPI_BF16) {
-                if (ok) ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = (bf16_t)v;
-            } else if constexpr (EPI == EPI_F32) {
-                if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = v;
-            } else if constexpr (EPI == EPI_BIAS_RES) {
-                v += bias;
-                if (g.drop.thresh) v = drop_keep(g.drop.key, row, col, g.drop.thresh) ? v * g.drop.inv_keep : 0.f;
-                if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = g.res[(size_t)row * g.ldres + col] + v;
-            } else if constexpr (EPI == EPI_BIAS_GELU) {
-                v += bias;
-                float a = gelu_erf(v);
-                if (g.drop.thresh) a = drop_keep(g.drop.key, row, col, g.drop.thresh) ? a * g.drop.inv_keep : 0.f;
-                if (ok) {
-                    ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = (bf16_t)v;
-                    g.C2[(size_t)row * g.ldc2 + col] = (bf16_t)a;
-                }
-            } else if constexpr (EPI == EPI_DGELU) {
-                float d = 0.f;
-                if (ok) {
-                    const float hp = (float)g.aux[(size_t)row * g.ldaux + col];
-                    d = v * gelu_erf_grad(hp);
-                    if (g.drop.thresh) d = drop_keep(g.drop.key, row, col, g.drop.thresh) ? d * g.drop.inv_keep : 0.f;
-                    const bf16_t db = (bf16_t)d;
-                    ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = db;
-                    d = (float)db;
-                }
-                csum += d;
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            if (c < B_CHUNKS) {
+                const size_t off = (size_t)(n0 + row) * g.ldb + k0 + 8 * kc;
+                rb[0][i] = *(const u32x4*)(g.B + off);
+                rb[1][i] = *(const u32x4*)(g.B_lo + off);
             }
         }
-        if constexpr (EPI == EPI_DGELU) {
-            csum += __shfl_xor(csum, 32);
-            if (g.colsum && lane < 32 && col < g.n_valid) atomicAdd(&g.colsum[col], csum);
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+                *(u32x4*)(&sA[pl][row * LS + 8 * kc]) = ra[pl][i];
+            }
+#pragma unroll
+            for (int i = 0; i < B_ITERS; ++i) {
+                const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+                if (c < B_CHUNKS) *(u32x4*)(&sB[pl][row * LS + 8 * kc]) = rb[pl][i];
+            }
+        }
+    };
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    gload(0);
+    const int frag_off = (lane & 31) * LS + 8 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        swrite();
+        __syncthreads();
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 ah = *(const bf16x8*)(&sA[0][32 * wave * LS + frag_off + 16 * ks]);
+            const bf16x8 al = *(const bf16x8*)(&sA[1][32 * wave * LS + frag_off + 16 * ks]);
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) {
+                const bf16x8 bh = *(const bf16x8*)(&sB[0][32 * nb * LS + frag_off + 16 * ks]);
+                const bf16x8 bl = *(const bf16x8*)(&sB[1][32 * nb * LS + frag_off + 16 * ks]);
+                acc[nb] = mfma32(al, bh, acc[nb]);
+                acc[nb] = mfma32(ah, bl, acc[nb]);
+                acc[nb] = mfma32(ah, bh, acc[nb]);
+            }
         }
     }
+    gemm_epilogue<NBLK, EPI>(g, acc, m0, n0, wave, lane);
 }
 
 template <int NBLK>
@@ -137,6 +227,17 @@ int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
     const int BN = 32 * NBLK;
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
     if (grid <= 0) return V1T_OK;
+    if (a.A_lo) {
+        if (!a.B_lo) return V1T_ERR_ARG;
+        switch (epi) {
+            case EPI_BF16: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BF16>), dim3(grid), dim3(256), 0, s, a); break;
+            case EPI_F32: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_F32>), dim3(grid), dim3(256), 0, s, a); break;
+            case EPI_BIAS_RES: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BIAS_RES>), dim3(grid), dim3(256), 0, s, a); break;
+            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, a); break;
+            default: return V1T_ERR_ARG;
+        }
+        return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    }
     switch (epi) {
         case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BF16>), dim3(grid), dim3(256), 0, s, a); break;
         case EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_F32>), dim3(grid), dim3(256), 0, s, a); break;
