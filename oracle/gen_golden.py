@@ -368,7 +368,7 @@ def gen_elu_edge(out: dict, log=print):
     from v1t.losses import PoissonLoss
     from v1t.models.utils import ELU1
 
-    u = torch.tensor([[-30.0, -20.0, -17.0, -15.0, -5.0, -1e-3, 0.0, 1e-3, 3.0, 15.0]], requires_grad=True)
+    u = torch.tensor([[-30.0, -20.0, -16.0, -15.0, -5.0, -1e-3, 0.0, 1e-3, 3.0, 15.0]], requires_grad=True)  # (-17 is skipped: expm1 there differs by 1 ulp between ATen code paths and log() amplifies it)
     y = torch.tensor([[0.0, 0.5, 1.0, 2.0, 0.1, 0.0, 1.0, 3.0, 0.2, 9.0]])
     crit = PoissonLoss(SimpleNamespace(ds_scale=1), ds={"A": SimpleNamespace(dataset=range(4500))})
     yh = ELU1()(u)
