@@ -94,6 +94,10 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
  * (rows B*T, cols = feature index), 0xFFFF: patch embedding. out: rows*cols bytes (1 = keep). */
 int v1t_dropout_mask(uint64_t seed, uint32_t stream_id, float p, long long rows, long long cols,
                      uint8_t* out, void* stream);
+/* The attention-P dropout (vit.py:263) is evaluated B*H*T*T times inside three MFMA kernels; its mask uses
+ * one hash per 2x2 (query,key) block with 8-bit thresholds, so its rate is quantised to round(256 p)/256
+ * (0.2544 -> 0.25390625) and 1/(1-rate) uses the quantised rate. This returns the effective rate. */
+float v1t_attention_dropout_rate(float p);
 
 /* ------------------------------------------------ Gaussian2d readout (readout/gaussian2d.py:237-278) */
 /* z: core map, element (b, cell, c) at z[b*zsb + cell*zsc + c] (cell = y*W + x, channel stride 1);

@@ -166,7 +166,8 @@ def test_train_mode_dropout_replayed_in_oracle(dev):
             m = m[:, :take]
         return m.reshape(shape).cpu()
 
-    masks = {"patch": mask(0xFFFF, cfg.p_dropout, B * T, core.padded_dim, (B, T, D), D)}
+    masks = {"patch": mask(0xFFFF, cfg.p_dropout, B * T, core.padded_dim, (B, T, D), D), "attn_p": float(lib.v1t_attention_dropout_rate(cfg.t_dropout))}
+    assert abs(masks["attn_p"] - cfg.t_dropout) <= 1 / 512
     for k in range(cfg.num_blocks):
         masks[f"attn{k}"] = mask(8 * k + 0, cfg.t_dropout, B * H * T, T, (B, H, T, T))
         masks[f"proj{k}"] = mask(8 * k + 1, cfg.t_dropout, B * T, core.padded_dim, (B, T, D), D)

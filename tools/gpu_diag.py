@@ -90,14 +90,14 @@ def attention():
         scale = torch.tensor([DP ** -0.5], device=dev)
         o = torch.empty(B * T, H * DP, device=dev, dtype=torch.bfloat16)
         lse = torch.empty(B, H, T, device=dev)
-        seed, sid = 777, 5
+        seed, sid = 777, 8
         L.check(lib.v1t_attention_forward(qkv.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid, o.data_ptr(), lse.data_ptr(), L.stream()))
         mask = None
         if p > 0:
             mask = torch.empty(B * H * T, T, device=dev, dtype=torch.uint8)
             L.check(lib.v1t_dropout_mask(seed, sid, p, B * H * T, T, mask.data_ptr(), L.stream()))
             print(f"     keep fraction {float(mask.float().mean()):.4f} (expect {1 - p:.4f})")
-        ref = attn_ref(qkv, B, H, T, DP, float(scale), mask, p)
+        ref = attn_ref(qkv, B, H, T, DP, float(scale), mask, float(lib.v1t_attention_dropout_rate(p)))
         tag = f"B{B} H{H} T{T} DP{DP} p{p}"
         report(f"attn fwd {tag}", o.float(), ref)
         dO = (torch.randn(B * T, H * DP, generator=g) * 0.5).to(dev).bfloat16()

@@ -164,6 +164,22 @@ DropCfg make_drop(bool training, float p, uint64_t seed, uint32_t stream) {
 
 // V1T_DEBUG_SYNC=1: print the launch about to be made and synchronise after it (fault localisation).
 static const bool g_debug_sync = std::getenv("V1T_DEBUG_SYNC") != nullptr;
+ AttnDrop make_adrop(bool training, float p, uint64_t seed, uint32_t stream) {
+    AttnDrop d;
+    d.key = drop_key(seed, stream);
+    d.thresh8 = 0;
+    d.inv_keep = 1.f;
+    d.keep_prob = 1.f;
+    if (training && p > 0.f) {
+        int t = (int)std::floor((double)p * 256.0 + 0.5);
+        t = std::min(std::max(t, 1), 255);
+        d.thresh8 = (uint32_t)t;
+        d.inv_keep = 256.0f / (float)(256 - t);
+        d.keep_prob = (float)(256 - t) / 256.0f;
+    }
+    return d;
+}
+
 #define CHECK(x)                                                                      \
     do {                                                                              \
         if (g_debug_sync) { std::fprintf(stderr, "[v1t] %s:%d %s\n", __func__, __LINE__, #x); std::fflush(stderr); } \
@@ -477,7 +493,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         AttnArgs at{};
         at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = o; at.ldo = HDP; at.o_lo = (bf16_t*)(wb + w.o_lo); at.lse2 = (float*)(wb + w.lse2);
         at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
-        at.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 0);
+        at.adrop = make_adrop(train, h->c.t_dropout, seed, 8 * k + 0);
         CHECK(launch_attn_fwd(at, DP, s));
 
         g = GemmNTArgs{};
@@ -610,7 +626,7 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         AttnArgs at{};
         at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = (bf16_t*)o; at.ldo = HDP; at.lse2 = (float*)(wb + w.lse2);
         at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
-        at.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 0);
+        at.adrop = make_adrop(train, h->c.t_dropout, seed, 8 * k + 0);
         at.dO = dO; at.lddo = HDP; at.delta = delta; at.dqkv = dqkv; at.lddqkv = 3 * HDP;
         at.dscale = h->c.use_lsa ? grads + b.scale : nullptr;
         CHECK(launch_attn_delta(at, DP, delta, s));
@@ -664,7 +680,14 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
 
 int v1t_dropout_mask(uint64_t seed, uint32_t stream_id, float p, long long rows, long long cols, uint8_t* out, void* stream) {
     if (!out || rows <= 0 || cols <= 0) return V1T_ERR_ARG;
+    if (stream_id != 0xFFFFu && stream_id % 8 == 0)  // attention-P stream: rows = B*H*T, cols = T
+        return launch_attn_dropout_mask(out, rows, cols, make_adrop(true, p, seed, stream_id), (hipStream_t)stream);
     return launch_dropout_mask(out, rows, cols, make_drop(true, p, seed, stream_id), (hipStream_t)stream);
+}
+
+float v1t_attention_dropout_rate(float p) {
+    const AttnDrop d = make_adrop(p > 0.f, p, 0, 0);
+    return (float)d.thresh8 / 256.0f;
 }
 
 int v1t_gaussian2d_forward(const float* z, long long zsb, long long zsc, int B, int C, int H, int W, int N, const float* grid,
@@ -722,7 +745,7 @@ int v1t_attention_forward(const void* qkv, int B, int H, int T, int DP, const fl
     AttnArgs a{};
     a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.o = (bf16_t*)o; a.ldo = H * DP; a.lse2 = lse2; a.B = B; a.H = H; a.T = T;
     a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
-    a.drop = make_drop(dropout_p > 0.f, dropout_p, seed, stream_id);
+    a.adrop = make_adrop(dropout_p > 0.f, dropout_p, seed, stream_id);
     return launch_attn_fwd(a, DP, (hipStream_t)stream);
 }
 int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const float* lse2, int B, int H, int T, int DP,
@@ -731,7 +754,7 @@ int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const
     AttnArgs a{};
     a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.o = (bf16_t*)o; a.ldo = H * DP; a.lse2 = (float*)lse2; a.B = B; a.H = H; a.T = T;
     a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
-    a.drop = make_drop(dropout_p > 0.f, dropout_p, seed, stream_id);
+    a.adrop = make_adrop(dropout_p > 0.f, dropout_p, seed, stream_id);
     a.dO = (const bf16_t*)dO; a.lddo = H * DP; a.delta = delta_ws; a.dqkv = (bf16_t*)dqkv; a.lddqkv = 3 * H * DP; a.dscale = dscale;
     CHECK(launch_attn_delta(a, DP, delta_ws, (hipStream_t)stream));
     return launch_attn_bwd(a, DP, (hipStream_t)stream);

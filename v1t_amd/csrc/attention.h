@@ -15,7 +15,7 @@ struct AttnArgs {
     const float* scale;            // device: 1 value, or H values when scale_per_head
     int scale_per_head;
     int mask_diag;                 // LSA: exclude key == query
-    DropCfg drop;
+    AttnDrop adrop;                // P dropout (2x2-block hash, 8-bit rate; common.h)
     // backward only
     const bf16_t* dO; int lddo;    // [rows][H*DP]
     const float* delta;            // [B][H][T] rowsum(dO * O)

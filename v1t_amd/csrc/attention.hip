@@ -13,6 +13,14 @@
 // The backward is split into a dQ kernel and a dK/dV kernel (7 MFMA products instead of 5): a
 // single-kernel backward needs fp32 atomics for dQ, and at T=1654, dh=160 those atomic bytes
 // (B*H*T*160*4 per 128-key block) exceed the chip's ~1.3 TB/s atomic rate by far.
+//
+// The element-wise work between the MFMAs shares the SIMD's issue slots with them, so it is kept
+// branch-free and minimal: dropout / LSA-diagonal / tail masking are template parameters (no runtime
+// flags in the loop), only the last tile carries bounds checks, the softmax scale is folded into the
+// exp2 argument (one fma + one v_exp per element), 1/keep and the score scale are folded into the
+// epilogue, and the dropout mask costs one 32-bit hash per 2x2 (query, key) block (common.h).
+#include <type_traits>
+
 #include "attention.h"
 
 namespace {
@@ -31,45 +39,109 @@ struct Geo {
     static constexpr int ITERS = (CHUNKS + 255) / 256;
 };
 
-// stage a 32-row x DP tile: rows t0.. of image `b`, zero-filled beyond T
-template <int DP>
-DEVFN void tile_gload(u32x4 (&r)[Geo<DP>::ITERS], const bf16_t* base, int ld, int t0, int T, int tid) {
-#pragma unroll
-    for (int i = 0; i < Geo<DP>::ITERS; ++i) {
-        const int c = tid + 256 * i, row = c / (DP / 8), cc = c % (DP / 8);
-        if (c < Geo<DP>::CHUNKS)
-            r[i] = (t0 + row < T) ? *(const u32x4*)(base + (size_t)(t0 + row) * ld + 8 * cc) : u32x4{0, 0, 0, 0};
-    }
-}
+// Global -> LDS tile staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
+// The LDS image of a [32 rows][STR] bf16 tile is a linear array of 16-B chunks (STR/8 per row, the last
+// (STR-DP)/8 of each row are padding); one wave-instruction fills 64 consecutive chunks (1 KiB) with each
+// lane's own global source address, so the row padding costs nothing but a dummy fetch. Instruction n of a
+// tile is issued by wave n % 4. Rows beyond T are clamped to row T-1 (finite data; every consumer masks them).
 template <int DP, int STR>
-DEVFN void tile_swrite(const u32x4 (&r)[Geo<DP>::ITERS], bf16_t* s, int tid) {
+struct TileDma {
+    static constexpr int CPR = STR / 8;                 // chunks per LDS row
+    static constexpr int NCH = 32 * CPR;                // chunks per tile
+    static constexpr int NINST = (NCH + 63) / 64;       // wave-instructions per tile
+    static constexpr int SLOTS = (NINST + 3) / 4;       // per wave
+    int row[SLOTS], c8[SLOTS];
+    bool on[SLOTS];
+    int wave;
+    DEVFN void init(int lane, int wave_uniform) {
+        wave = wave_uniform;
 #pragma unroll
-    for (int i = 0; i < Geo<DP>::ITERS; ++i) {
-        const int c = tid + 256 * i, row = c / (DP / 8), cc = c % (DP / 8);
-        if (c < Geo<DP>::CHUNKS) *(u32x4*)(s + row * STR + 8 * cc) = r[i];
+        for (int s = 0; s < SLOTS; ++s) {
+            const int n = wave + 4 * s, p = 64 * n + lane;
+            on[s] = n < NINST && p < NCH;
+            row[s] = p / CPR;
+            c8[s] = 8 * min(p % CPR, DP / 8 - 1);
+        }
     }
-}
+    // img: element (row 0, col 0) of this (image, head) slice; ld in elements; lds: tile base
+    DEVFN void issue(const bf16_t* img, int ld, int t0, int T, bf16_t* lds) const {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int n = wave + 4 * s;
+            if (n < NINST) {  // wave-uniform
+                const bf16_t* src = img + (size_t)min(t0 + row[s], T - 1) * ld + c8[s];
+                if (on[s])
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(lds + 512 * n), 16, 0, 0);
+            }
+        }
+    }
+};
 
 DEVFN void zero16(f32x16& x) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = 0.f;
 }
 
+// lane part of the transposed-fragment address (see lds_tr_frag in common.h): (4h + q) * stride + 16*(g&1) + 4p
+DEVFN int tr_lane_off(int lane, int stride) {
+    const int g = lane >> 4, i = lane & 15;
+    return (4 * (g >> 1) + (i >> 2)) * stride + 16 * (g & 1) + 4 * (i & 3);
+}
+// A operand, 32 m x 16 k, from an image stored [k][m]; k order matches acc_to_b(). `p` = img + tr_lane_off.
+template <int STR>
+DEVFN bf16x8 tr_frag(const bf16_t* p, int k0, int m0) {
+    const bf16x4 lo = lds_tr_read(p + k0 * STR + m0);
+    const bf16x4 hi = lds_tr_read(p + (k0 + 8) * STR + m0);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// keep-bits of the 4 consecutive elements (r&3 = 0..3) of one accumulator group: the lane's varying
+// coordinate runs over 2 consecutive 2x2 blocks (words w0: elements 0,1; w1: elements 2,3); sh_even /
+// sh_odd select the byte for an even / odd value of the varying coordinate (they encode the parity of
+// the lane's fixed coordinate).
+DEVFN void drop4(uint32_t x0, uint32_t step, uint32_t sh_even, uint32_t sh_odd, uint32_t thr, bool (&keep)[4]) {
+    const uint32_t w0 = mix1(x0), w1 = mix1(x0 + step);
+    keep[0] = __builtin_amdgcn_ubfe(w0, sh_even, 8u) >= thr;
+    keep[1] = __builtin_amdgcn_ubfe(w0, sh_odd, 8u) >= thr;
+    keep[2] = __builtin_amdgcn_ubfe(w1, sh_even, 8u) >= thr;
+    keep[3] = __builtin_amdgcn_ubfe(w1, sh_odd, 8u) >= thr;
+}
+
+// 1-D grid over (row block, head, image), XCD-aware: the row blocks of one (image, head) get consecutive
+// logical ids and each XCD owns a contiguous chunk of ids, so a head's K/V (or Q/dO) stays in ONE L2.
+DEVFN void decode_block(const AttnArgs& a, int& rb, int& h, int& b) {
+    const int nrb = (a.T + 127) / 128;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    rb = lid % nrb;
+    const int bh = lid / nrb;
+    h = bh % a.H;
+    b = bh / a.H;
+}
+
 // ------------------------------------------------------------------------------------------
-template <int DP>
+template <int DP, bool DROP, bool DIAG>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     using G = Geo<DP>;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][32 * G::RSTR];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2][32 * G::TSTR];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q = blockIdx.x * 128 + 32 * wave + (lane & 31);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rb, h, b;
+    decode_block(a, rb, h, b);
+    const int q = rb * 128 + 32 * wave + (lane & 31);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
     const bf16_t* kbase = qkv_b + HD + h * DP;
     const bf16_t* vbase = qkv_b + 2 * HD + h * DP;
     const float c = a.scale[a.scale_per_head ? h : 0] * LOG2E;
+    TileDma<DP, G::RSTR> dmaK;
+    TileDma<DP, G::TSTR> dmaV;
+    dmaK.init(lane, wave);
+    dmaV.init(lane, wave);
 
     bf16x8 qf[G::KS];
 #pragma unroll
@@ -80,77 +152,104 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     f32x16 o[G::DB];
 #pragma unroll
     for (int d = 0; d < G::DB; ++d) zero16(o[d]);
-    float m = NEG_BIG, lsum = 0.f;
-    const uint32_t drow = (uint32_t)((b * a.H + h) * a.T + q) * 0x9E3779B1u + a.drop.key;
+    float m2 = NEG_BIG, lsum = 0.f;  // running max in the scaled log2 domain; per-lane partial sum
 
+    // dropout: lane-fixed coordinate = q (row), varying = key
+    const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
+    const uint32_t dbase = a.adrop.key + ((uint32_t)(b * a.H + h) * T2 + ((uint32_t)q >> 1)) * ADROP_K1 + (uint32_t)(2 * h2) * ADROP_K2;
+    const uint32_t sh_even = 16 * (q & 1), sh_odd = sh_even + 8;
+
+    const int koff = (lane & 31) * G::RSTR + 8 * h2;
+    const int voff = tr_lane_off(lane, G::TSTR);
     const int nt = (a.T + 31) / 32;
-    u32x4 rk[G::ITERS], rv[G::ITERS];
-    tile_gload<DP>(rk, kbase, a.ldqkv, 0, a.T, tid);
-    tile_gload<DP>(rv, vbase, a.ldqkv, 0, a.T, tid);
-    tile_swrite<DP, G::RSTR>(rk, sK[0], tid);
-    tile_swrite<DP, G::TSTR>(rv, sV[0], tid);
-    __syncthreads();
-    for (int kt = 0; kt < nt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nt) {
-            tile_gload<DP>(rk, kbase, a.ldqkv, 32 * (kt + 1), a.T, tid);
-            tile_gload<DP>(rv, vbase, a.ldqkv, 32 * (kt + 1), a.T, tid);
-        }
+
+    auto tile = [&](auto tail_tag, int kt, int buf) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         f32x16 s;
         zero16(s);
+        const bf16_t* kp = &sK[buf][koff];
+        const bf16_t* vp = &sV[buf][voff];
+        // all K fragments in flight, then the S chain; the V fragments (transposed reads) are issued right
+        // behind it so they land while the softmax runs on the VALU
+        bf16x8 kfr[G::KS], vfr[2 * G::DB];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) kfr[ks] = *(const bf16x8*)(kp + 16 * ks);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) s = mfma32(kfr[ks], qf[ks], s);
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) {
+            vfr[2 * d] = tr_frag<G::TSTR>(vp, 0, 32 * d);
+            vfr[2 * d + 1] = tr_frag<G::TSTR>(vp, 16, 32 * d);
+        }
+        // issue order: every K read first (one LDS latency for the whole chain), then one MFMA + the
+        // transposed V reads that fit behind it
+        __builtin_amdgcn_sched_group_barrier(0x100, G::KS, 0);
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            const bf16x8 kf = *(const bf16x8*)(&sK[buf][(lane & 31) * G::RSTR + 16 * ks + 8 * h2]);
-            s = mfma32(kf, qf[ks], s);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * G::DB / G::KS, 0);
         }
-        float pmax = NEG_BIG;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TAIL || DIAG) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = 32 * kt + acc_row(r, lane);
-            float t = s[r] * c;
-            if (key >= a.T || (a.mask_diag && key == q)) t = NEG_BIG;
-            s[r] = t;
-            pmax = fmaxf(pmax, t);
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * kt + acc_row(r, lane);
+                bool dead = false;
+                if constexpr (TAIL) dead = key >= a.T;
+                if constexpr (DIAG) dead = dead || key == q;
+                s[r] = dead ? NEG_BIG : s[r];
+            }
         }
-        pmax = fmaxf(pmax, __shfl_xor(pmax, 32));
-        if (!__all(pmax <= m + RESCALE_THR)) {
-            const float mn = fmaxf(m, pmax);
-            const float alpha = fast_exp2(m - mn);
+        float pmax = fmaxf(s[0], s[1]);
+#pragma unroll
+        for (int r = 2; r < 16; ++r) pmax = fmaxf(pmax, s[r]);
+        pmax = fmaxf(pmax, __shfl_xor(pmax, 32)) * c;
+        if (!__all(pmax <= m2 + RESCALE_THR)) {
+            const float mn = fmaxf(m2, pmax);
+            const float alpha = fast_exp2(m2 - mn);
 #pragma unroll
             for (int d = 0; d < G::DB; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
             lsum *= alpha;
-            m = mn;
+            m2 = mn;
         }
+        const float negm = -m2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float p = fast_exp2(s[r] - m);
-            lsum += p;
-            if (a.drop.thresh) {
-                const uint32_t key = 32 * kt + acc_row(r, lane);
-                p = (mix32(drow + key * 0x85EBCA77u) >= a.drop.thresh) ? p * a.drop.inv_keep : 0.f;
+        for (int g = 0; g < 4; ++g) {
+            bool keep[4] = {true, true, true, true};
+            if constexpr (DROP) drop4(dbase + (uint32_t)(16 * kt + 4 * g) * ADROP_K2, ADROP_K2, sh_even, sh_odd, a.adrop.thresh8, keep);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p = fast_exp2(fmaf(s[4 * g + j], c, negm));
+                lsum += p;
+                s[4 * g + j] = keep[j] ? p : 0.f;
             }
-            s[r] = p;
         }
         const bf16x8 p0 = acc_to_b(s, 0), p1 = acc_to_b(s, 1);
 #pragma unroll
         for (int d = 0; d < G::DB; ++d) {
-            const bf16x8 v0 = lds_tr_frag(sV[buf], G::TSTR, 0, 32 * d, lane);
-            o[d] = mfma32(v0, p0, o[d]);
-            const bf16x8 v1 = lds_tr_frag(sV[buf], G::TSTR, 16, 32 * d, lane);
-            o[d] = mfma32(v1, p1, o[d]);
+            o[d] = mfma32(vfr[2 * d], p0, o[d]);
+            o[d] = mfma32(vfr[2 * d + 1], p1, o[d]);
         }
-        if (kt + 1 < nt) {
-            tile_swrite<DP, G::RSTR>(rk, sK[buf ^ 1], tid);
-            tile_swrite<DP, G::TSTR>(rv, sV[buf ^ 1], tid);
-        }
+    };
+
+    dmaK.issue(kbase, a.ldqkv, 0, a.T, sK[0]);
+    dmaV.issue(vbase, a.ldqkv, 0, a.T, sV[0]);
+    __syncthreads();  // waits vmcnt(0): the DMA has landed
+    for (int kt = 0; kt < nt - 1; ++kt) {
+        const int buf = kt & 1;
+        dmaK.issue(kbase, a.ldqkv, 32 * (kt + 1), a.T, sK[buf ^ 1]);
+        dmaV.issue(vbase, a.ldqkv, 32 * (kt + 1), a.T, sV[buf ^ 1]);
+        tile(std::false_type{}, kt, buf);
         __syncthreads();
     }
+    tile(std::true_type{}, nt - 1, (nt - 1) & 1);
+
     const float ltot = lsum + __shfl_xor(lsum, 32);
-    const float inv = 1.0f / ltot;
+    const float inv = (DROP ? a.adrop.inv_keep : 1.0f) / ltot;
     if (q < a.T) {
-        if (h2 == 0) a.lse2[((size_t)b * a.H + h) * a.T + q] = m + log2f(ltot);
+        if (h2 == 0) a.lse2[((size_t)b * a.H + h) * a.T + q] = m2 + log2f(ltot);
         bf16_t* orow = a.o + ((size_t)b * a.T + q) * a.ldo + h * DP;
 #pragma unroll
         for (int d = 0; d < G::DB; ++d)
@@ -193,19 +292,22 @@ __global__ void attn_delta_kernel(AttnArgs a, float* delta) {
 // ------------------------------------------------------------------------------------------
 // DP >= 128: Q + dO fragments (2*DP/4 VGPRs) + the dQ accumulator (DP/2) + S/dP/staging exceed 256
 // registers, so that shape runs one wave per SIMD with the 512-register budget (no spills).
-template <int DP>
+template <int DP, bool DROP, bool DIAG>
 __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(AttnArgs a) {
     using G = Geo<DP>;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][32 * G::RSTR];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2][32 * G::RSTR];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q = blockIdx.x * 128 + 32 * wave + (lane & 31);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rb, h, b;
+    decode_block(a, rb, h, b);
+    const int q = rb * 128 + 32 * wave + (lane & 31);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
     const bf16_t* kbase = qkv_b + HD + h * DP;
     const bf16_t* vbase = qkv_b + 2 * HD + h * DP;
+    TileDma<DP, G::RSTR> dma;
+    dma.init(lane, wave);
     const float sc = a.scale[a.scale_per_head ? h : 0];
     const float c = sc * LOG2E;
     const bool qok = q < a.T;
@@ -219,67 +321,100 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
         dof[ks] = *(bf16x8*)&u;
     }
     const size_t sidx = ((size_t)b * a.H + h) * a.T + (qok ? q : 0);
-    const float lse = a.lse2[sidx], dl = a.delta[sidx];
+    const float neglse = -a.lse2[sidx];
+    // 1/keep is folded into the epilogue: dS' = P * (keep ? dP : 0  -  delta * keep_prob)
+    const float dl = a.delta[sidx] * (DROP ? a.adrop.keep_prob : 1.0f);
     f32x16 dq[G::DB];
 #pragma unroll
     for (int d = 0; d < G::DB; ++d) zero16(dq[d]);
     float dsc = 0.f;
-    const uint32_t drow = (uint32_t)((b * a.H + h) * a.T + q) * 0x9E3779B1u + a.drop.key;
+    const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
+    const uint32_t dbase = a.adrop.key + ((uint32_t)(b * a.H + h) * T2 + ((uint32_t)q >> 1)) * ADROP_K1 + (uint32_t)(2 * h2) * ADROP_K2;
+    const uint32_t sh_even = 16 * (q & 1), sh_odd = sh_even + 8;
 
+    const int koff = (lane & 31) * G::RSTR + 8 * h2;
+    const int toff = tr_lane_off(lane, G::RSTR);
     const int nt = (a.T + 31) / 32;
-    u32x4 rk[G::ITERS], rv[G::ITERS];
-    tile_gload<DP>(rk, kbase, a.ldqkv, 0, a.T, tid);
-    tile_gload<DP>(rv, vbase, a.ldqkv, 0, a.T, tid);
-    tile_swrite<DP, G::RSTR>(rk, sK[0], tid);
-    tile_swrite<DP, G::RSTR>(rv, sV[0], tid);
-    __syncthreads();
-    for (int kt = 0; kt < nt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nt) {
-            tile_gload<DP>(rk, kbase, a.ldqkv, 32 * (kt + 1), a.T, tid);
-            tile_gload<DP>(rv, vbase, a.ldqkv, 32 * (kt + 1), a.T, tid);
-        }
+
+    auto tile = [&](auto tail_tag, int kt, int buf) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         f32x16 s, dp;
         zero16(s);
         zero16(dp);
+        const bf16_t* kp = &sK[buf][koff];
+        const bf16_t* vp = &sV[buf][koff];
+        const bf16_t* tp = &sK[buf][toff];
+        bf16x8 kfr[G::KS], vfr[G::KS], tfr[2 * G::DB];
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            const int off = (lane & 31) * G::RSTR + 16 * ks + 8 * h2;
-            const bf16x8 kf = *(const bf16x8*)(&sK[buf][off]);
-            s = mfma32(kf, qf[ks], s);
-            const bf16x8 vf = *(const bf16x8*)(&sV[buf][off]);
-            dp = mfma32(vf, dof[ks], dp);
+        for (int ks = 0; ks < G::KS; ++ks) kfr[ks] = *(const bf16x8*)(kp + 16 * ks);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) vfr[ks] = *(const bf16x8*)(vp + 16 * ks);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) s = mfma32(kfr[ks], qf[ks], s);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) dp = mfma32(vfr[ks], dof[ks], dp);
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) {
+            tfr[2 * d] = tr_frag<G::RSTR>(tp, 0, 32 * d);
+            tfr[2 * d + 1] = tr_frag<G::RSTR>(tp, 16, 32 * d);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = 32 * kt + acc_row(r, lane);
-            const bool ok = qok && key < a.T && !(a.mask_diag && key == q);
-            const float p = ok ? fast_exp2(s[r] * c - lse) : 0.f;
-            float g = dp[r];
-            if (a.drop.thresh) g = (mix32(drow + (uint32_t)key * 0x85EBCA77u) >= a.drop.thresh) ? g * a.drop.inv_keep : 0.f;
-            const float ds = p * (g - dl);
-            dsc += ds * s[r];
-            s[r] = ds;
+        for (int ks = 0; ks < 2 * G::KS; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * G::DB / (2 * G::KS), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bool keep[4] = {true, true, true, true};
+            if constexpr (DROP) drop4(dbase + (uint32_t)(16 * kt + 4 * g) * ADROP_K2, ADROP_K2, sh_even, sh_odd, a.adrop.thresh8, keep);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                float p = fast_exp2(fmaf(s[r], c, neglse));
+                if constexpr (TAIL || DIAG) {
+                    const int key = 32 * kt + acc_row(r, lane);
+                    bool dead = false;
+                    if constexpr (TAIL) dead = key >= a.T;
+                    if constexpr (DIAG) dead = dead || key == q;
+                    p = dead ? 0.f : p;
+                }
+                const float gg = keep[j] ? dp[r] : 0.f;
+                const float ds = p * (gg - dl);
+                if constexpr (DIAG) dsc = fmaf(ds, s[r], dsc);
+                s[r] = ds;
+            }
         }
         const bf16x8 b0 = acc_to_b(s, 0), b1 = acc_to_b(s, 1);
 #pragma unroll
         for (int d = 0; d < G::DB; ++d) {
-            const bf16x8 k0 = lds_tr_frag(sK[buf], G::RSTR, 0, 32 * d, lane);
-            dq[d] = mfma32(k0, b0, dq[d]);
-            const bf16x8 k1 = lds_tr_frag(sK[buf], G::RSTR, 16, 32 * d, lane);
-            dq[d] = mfma32(k1, b1, dq[d]);
+            dq[d] = mfma32(tfr[2 * d], b0, dq[d]);
+            dq[d] = mfma32(tfr[2 * d + 1], b1, dq[d]);
         }
-        if (kt + 1 < nt) {
-            tile_swrite<DP, G::RSTR>(rk, sK[buf ^ 1], tid);
-            tile_swrite<DP, G::RSTR>(rv, sV[buf ^ 1], tid);
-        }
+    };
+
+    dma.issue(kbase, a.ldqkv, 0, a.T, sK[0]);
+    dma.issue(vbase, a.ldqkv, 0, a.T, sV[0]);
+    __syncthreads();
+    for (int kt = 0; kt < nt - 1; ++kt) {
+        const int buf = kt & 1;
+        dma.issue(kbase, a.ldqkv, 32 * (kt + 1), a.T, sK[buf ^ 1]);
+        dma.issue(vbase, a.ldqkv, 32 * (kt + 1), a.T, sV[buf ^ 1]);
+        tile(std::false_type{}, kt, buf);
         __syncthreads();
     }
-    if (a.dscale) {
-        const float tot = wave_sum(dsc);
-        if (lane == 0) atomicAdd(&a.dscale[a.scale_per_head ? h : 0], tot);
+    tile(std::true_type{}, nt - 1, (nt - 1) & 1);
+
+    const float kfac = DROP ? a.adrop.inv_keep : 1.0f;
+    if constexpr (DIAG) {
+        if (a.dscale) {
+            const float tot = wave_sum(qok ? dsc : 0.f) * kfac;
+            if (lane == 0) atomicAdd(&a.dscale[a.scale_per_head ? h : 0], tot);
+        }
     }
     if (qok) {
+        const float f = sc * kfac;
         bf16_t* orow = a.dqkv + ((size_t)b * a.T + q) * a.lddqkv + h * DP;
 #pragma unroll
         for (int d = 0; d < G::DB; ++d)
@@ -287,33 +422,37 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
             for (int rq = 0; rq < 4; ++rq) {
                 bf16x4 w;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(dq[d][4 * rq + j] * sc);
+                for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(dq[d][4 * rq + j] * f);
                 *(bf16x4*)(orow + 32 * d + 8 * rq + 4 * h2) = w;
             }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-template <int DP>
+template <int DP, bool DROP, bool DIAG>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     using G = Geo<DP>;
     __shared__ __attribute__((aligned(16))) bf16_t sQ[2][32 * G::RSTR];
     __shared__ __attribute__((aligned(16))) bf16_t sD[2][32 * G::RSTR];
-    __shared__ __attribute__((aligned(16))) float sL[2][32];
-    __shared__ __attribute__((aligned(16))) float sDl[2][32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int key = blockIdx.x * 128 + 32 * wave + (lane & 31);
+    __shared__ __attribute__((aligned(16))) float sL[2][32];   // -lse2 of the tile's queries
+    __shared__ __attribute__((aligned(16))) float sDl[2][32];  // delta * keep_prob
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rb, h, b;
+    decode_block(a, rb, h, b);
+    const int key = rb * 128 + 32 * wave + (lane & 31);
+    TileDma<DP, G::RSTR> dma;
+    dma.init(lane, wave);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
     const bf16_t* qbase = qkv_b + h * DP;
     const bf16_t* dobase = a.dO + (size_t)b * a.T * a.lddo + h * DP;
     const float* lbase = a.lse2 + ((size_t)b * a.H + h) * a.T;
-    const float* dbase = a.delta + ((size_t)b * a.H + h) * a.T;
+    const float* dbase_ = a.delta + ((size_t)b * a.H + h) * a.T;
     const float sc = a.scale[a.scale_per_head ? h : 0];
     const float c = sc * LOG2E;
     const bool kok = key < a.T;
+    const float kprob = DROP ? a.adrop.keep_prob : 1.0f;
 
     bf16x8 kf[G::KS], vf[G::KS];
 #pragma unroll
@@ -330,84 +469,114 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
         zero16(dk[d]);
         zero16(dv[d]);
     }
-    const uint32_t dcol = (uint32_t)key * 0x85EBCA77u + a.drop.key;
-    const uint32_t drow0 = (uint32_t)((b * a.H + h) * a.T);
+    // dropout: lane-fixed coordinate = key (column), varying = query row
+    const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
+    const uint32_t dbase = a.adrop.key + ((uint32_t)(b * a.H + h) * T2 + (uint32_t)(2 * h2)) * ADROP_K1 + ((uint32_t)key >> 1) * ADROP_K2;
+    const uint32_t sh_even = 8 * (key & 1), sh_odd = sh_even + 16;
 
+    const int roff = (lane & 31) * G::RSTR + 8 * h2;
+    const int toff = tr_lane_off(lane, G::RSTR);
     const int nt = (a.T + 31) / 32;
-    u32x4 rq[G::ITERS], rd[G::ITERS];
+    // -lse2 and delta*keep_prob of the tile's 32 queries: two values per lane of wave 0 -> LDS
+    // (register loads are consumed only at the END of the tile, next to the barrier's vmcnt(0): an earlier
+    // use would make the compiler drain the DMA queue in the middle of the tile)
     float rl = 0.f, rdl = 0.f;
-    auto gload = [&](int t) {
-        tile_gload<DP>(rq, qbase, a.ldqkv, 32 * t, a.T, tid);
-        tile_gload<DP>(rd, dobase, a.lddo, 32 * t, a.T, tid);
+    auto stage = [&](int t, int buf) {
+        dma.issue(qbase, a.ldqkv, 32 * t, a.T, sQ[buf]);
+        dma.issue(dobase, a.lddo, 32 * t, a.T, sD[buf]);
         if (tid < 32) {
-            const int qq = 32 * t + tid;
-            rl = (qq < a.T) ? lbase[qq] : 0.f;
-            rdl = (qq < a.T) ? dbase[qq] : 0.f;
+            const int qq = min(32 * t + tid, a.T - 1);
+            rl = lbase[qq];
+            rdl = dbase_[qq];
         }
     };
-    auto swrite = [&](int buf) {
-        tile_swrite<DP, G::RSTR>(rq, sQ[buf], tid);
-        tile_swrite<DP, G::RSTR>(rd, sD[buf], tid);
+    auto stage_finish = [&](int buf) {
         if (tid < 32) {
-            sL[buf][tid] = rl;
-            sDl[buf][tid] = rdl;
+            sL[buf][tid] = -rl;
+            sDl[buf][tid] = rdl * kprob;
         }
     };
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    for (int qt = 0; qt < nt; ++qt) {
-        const int buf = qt & 1;
-        if (qt + 1 < nt) gload(qt + 1);
+    auto tile = [&](auto tail_tag, int qt, int buf) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         f32x16 s, dp;
         zero16(s);
         zero16(dp);
+        const bf16_t* qp = &sQ[buf][roff];
+        const bf16_t* dop = &sD[buf][roff];
+        const bf16_t* tq = &sQ[buf][toff];
+        const bf16_t* td = &sD[buf][toff];
+        bf16x8 qfr[G::KS], dfr[G::KS], tdf[2 * G::DB], tqf[2 * G::DB];
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            const int off = (lane & 31) * G::RSTR + 16 * ks + 8 * h2;
-            const bf16x8 qa = *(const bf16x8*)(&sQ[buf][off]);
-            s = mfma32(qa, kf[ks], s);
-            const bf16x8 da = *(const bf16x8*)(&sD[buf][off]);
-            dp = mfma32(da, vf[ks], dp);
+        for (int ks = 0; ks < G::KS; ++ks) qfr[ks] = *(const bf16x8*)(qp + 16 * ks);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) dfr[ks] = *(const bf16x8*)(dop + 16 * ks);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) s = mfma32(qfr[ks], kf[ks], s);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) dp = mfma32(dfr[ks], vf[ks], dp);
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) {
+            tdf[2 * d] = tr_frag<G::RSTR>(td, 0, 32 * d);
+            tdf[2 * d + 1] = tr_frag<G::RSTR>(td, 16, 32 * d);
+            tqf[2 * d] = tr_frag<G::RSTR>(tq, 0, 32 * d);
+            tqf[2 * d + 1] = tr_frag<G::RSTR>(tq, 16, 32 * d);
         }
-        // rows of s / dp = queries 32qt + acc_row(r, lane); column = this lane's key
-        f32x4 lse4[4], dl4[4];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2 * G::KS; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 * G::DB / (2 * G::KS), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // rows of s / dp = queries 32qt + 8g + 4h2 + j; column = this lane's key
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            lse4[g] = *(const f32x4*)(&sL[buf][8 * g + 4 * h2]);
-            dl4[g] = *(const f32x4*)(&sDl[buf][8 * g + 4 * h2]);
-        }
+            const f32x4 nl = *(const f32x4*)(&sL[buf][8 * g + 4 * h2]);
+            const f32x4 dl = *(const f32x4*)(&sDl[buf][8 * g + 4 * h2]);
+            bool keep[4] = {true, true, true, true};
+            if constexpr (DROP) drop4(dbase + (uint32_t)(16 * qt + 4 * g) * ADROP_K1, ADROP_K1, sh_even, sh_odd, a.adrop.thresh8, keep);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qq = 32 * qt + acc_row(r, lane);
-            const bool ok = kok && qq < a.T && !(a.mask_diag && key == qq);
-            const float p = ok ? fast_exp2(s[r] * c - lse4[r >> 2][r & 3]) : 0.f;
-            float pd = p, g = dp[r];
-            if (a.drop.thresh) {
-                const bool keep = mix32(dcol + (drow0 + (uint32_t)qq) * 0x9E3779B1u) >= a.drop.thresh;
-                pd = keep ? p * a.drop.inv_keep : 0.f;
-                g = keep ? g * a.drop.inv_keep : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                float p = fast_exp2(fmaf(s[r], c, nl[j]));
+                if constexpr (TAIL || DIAG) {
+                    const int qq = 32 * qt + acc_row(r, lane);
+                    bool dead = false;
+                    if constexpr (TAIL) dead = qq >= a.T;
+                    if constexpr (DIAG) dead = dead || qq == key;
+                    p = dead ? 0.f : p;
+                }
+                const float gg = keep[j] ? dp[r] : 0.f;
+                dp[r] = keep[j] ? p : 0.f;       // dropped P (x 1/keep in the epilogue) -> dV
+                s[r] = p * (gg - dl[j]);          // dS' (x scale/keep in the epilogue)   -> dK
             }
-            dp[r] = pd;                             // dropped P   -> dV
-            s[r] = p * (g - dl4[r >> 2][r & 3]);    // dS (unscaled) -> dK
         }
         const bf16x8 p0 = acc_to_b(dp, 0), p1 = acc_to_b(dp, 1);
         const bf16x8 s0 = acc_to_b(s, 0), s1 = acc_to_b(s, 1);
 #pragma unroll
         for (int d = 0; d < G::DB; ++d) {
-            const bf16x8 do0 = lds_tr_frag(sD[buf], G::RSTR, 0, 32 * d, lane);
-            dv[d] = mfma32(do0, p0, dv[d]);
-            const bf16x8 do1 = lds_tr_frag(sD[buf], G::RSTR, 16, 32 * d, lane);
-            dv[d] = mfma32(do1, p1, dv[d]);
-            const bf16x8 q0 = lds_tr_frag(sQ[buf], G::RSTR, 0, 32 * d, lane);
-            dk[d] = mfma32(q0, s0, dk[d]);
-            const bf16x8 q1 = lds_tr_frag(sQ[buf], G::RSTR, 16, 32 * d, lane);
-            dk[d] = mfma32(q1, s1, dk[d]);
+            dv[d] = mfma32(tdf[2 * d], p0, dv[d]);
+            dv[d] = mfma32(tdf[2 * d + 1], p1, dv[d]);
+            dk[d] = mfma32(tqf[2 * d], s0, dk[d]);
+            dk[d] = mfma32(tqf[2 * d + 1], s1, dk[d]);
         }
-        if (qt + 1 < nt) swrite(buf ^ 1);
+    };
+
+    stage(0, 0);
+    stage_finish(0);
+    __syncthreads();
+    for (int qt = 0; qt < nt - 1; ++qt) {
+        const int buf = qt & 1;
+        stage(qt + 1, buf ^ 1);
+        tile(std::false_type{}, qt, buf);
+        stage_finish(buf ^ 1);
         __syncthreads();
     }
+    tile(std::true_type{}, nt - 1, (nt - 1) & 1);
+
     if (kok) {
+        const float kfac = DROP ? a.adrop.inv_keep : 1.0f;
+        const float fk = sc * kfac;
         bf16_t* orow = a.dqkv + ((size_t)b * a.T + key) * a.lddqkv + h * DP;
 #pragma unroll
         for (int d = 0; d < G::DB; ++d)
@@ -416,8 +585,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
                 bf16x4 wk, wv;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    wk[j] = (bf16_t)(dk[d][4 * rq4 + j] * sc);
-                    wv[j] = (bf16_t)(dv[d][4 * rq4 + j]);
+                    wk[j] = (bf16_t)(dk[d][4 * rq4 + j] * fk);
+                    wv[j] = (bf16_t)(dv[d][4 * rq4 + j] * kfac);
                 }
                 *(bf16x4*)(orow + HD + 32 * d + 8 * rq4 + 4 * h2) = wk;
                 *(bf16x4*)(orow + 2 * HD + 32 * d + 8 * rq4 + 4 * h2) = wv;
@@ -425,22 +594,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
 }
 
-template <int DP>
+template <int DP, bool DROP, bool DIAG>
 int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
-    dim3 grid((a.T + 127) / 128, a.H, a.B);
+    dim3 grid(((a.T + 127) / 128) * a.H * a.B);
     prof_begin(PROF_ATTN_FWD, s);
-    hipLaunchKernelGGL((attn_fwd_kernel<DP>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG>), grid, dim3(256), 0, s, a);
     prof_end(PROF_ATTN_FWD, s);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
-template <int DP>
+template <int DP, bool DROP, bool DIAG>
 int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
-    dim3 grid((a.T + 127) / 128, a.H, a.B);
+    dim3 grid(((a.T + 127) / 128) * a.H * a.B);
     prof_begin(PROF_ATTN_DQ, s);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DROP, DIAG>), grid, dim3(256), 0, s, a);
     prof_end(PROF_ATTN_DQ, s);
     prof_begin(PROF_ATTN_DKV, s);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DROP, DIAG>), grid, dim3(256), 0, s, a);
     prof_end(PROF_ATTN_DKV, s);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
@@ -449,6 +618,19 @@ int launch_delta_t(const AttnArgs& a, float* delta, hipStream_t s) {
     const int total = a.B * a.T * a.H;
     hipLaunchKernelGGL((attn_delta_kernel<DP>), dim3((total + 255) / 256), dim3(256), 0, s, a, delta);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+
+template <int DP>
+int fwd_flags(const AttnArgs& a, hipStream_t s) {
+    const bool drop = a.adrop.thresh8 != 0, diag = a.mask_diag != 0;
+    if (drop) return diag ? launch_fwd_t<DP, true, true>(a, s) : launch_fwd_t<DP, true, false>(a, s);
+    return diag ? launch_fwd_t<DP, false, true>(a, s) : launch_fwd_t<DP, false, false>(a, s);
+}
+template <int DP>
+int bwd_flags(const AttnArgs& a, hipStream_t s) {
+    const bool drop = a.adrop.thresh8 != 0, diag = a.mask_diag != 0;
+    if (drop) return diag ? launch_bwd_t<DP, true, true>(a, s) : launch_bwd_t<DP, true, false>(a, s);
+    return diag ? launch_bwd_t<DP, false, true>(a, s) : launch_bwd_t<DP, false, false>(a, s);
 }
 
 }  // namespace
@@ -463,6 +645,6 @@ int launch_delta_t(const AttnArgs& a, float* delta, hipStream_t s) {
         default: return V1T_ERR_UNSUPPORTED;           \
     }
 
-int launch_attn_fwd(const AttnArgs& a, int DP, hipStream_t s) { DP_DISPATCH(launch_fwd_t, a, s) }
+int launch_attn_fwd(const AttnArgs& a, int DP, hipStream_t s) { DP_DISPATCH(fwd_flags, a, s) }
 int launch_attn_delta(const AttnArgs& a, int DP, float* delta, hipStream_t s) { DP_DISPATCH(launch_delta_t, a, delta, s) }
-int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s) { DP_DISPATCH(launch_bwd_t, a, s) }
+int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s) { DP_DISPATCH(bwd_flags, a, s) }

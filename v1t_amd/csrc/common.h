@@ -103,6 +103,29 @@ struct DropCfg {
     float inv_keep;   // 1 / (1 - p)
 };
 
+// Attention-P dropout: B*H*T*T decisions per block and pass, evaluated inside three MFMA kernels, so the
+// mask must be cheap. One 32-bit word serves a 2x2 block of (query, key): word(bh, q>>1, k>>1) =
+// mix1(key + (bh*T2 + (q>>1))*K1 + (k>>1)*K2), T2 = (T+1)/2; element (q,k) keeps iff
+// byte[2*(q&1) + (k&1)] >= thresh8. The rate is therefore quantised to thresh8/256 (0.2544 -> 65/256 =
+// 0.2539) and 1/keep uses the quantised rate, so the estimator stays unbiased. mix1 is one
+// xorshift-multiply-xorshift round (byte uniformity / neighbour correlation checked).
+DEVFN uint32_t mix1(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
+    return x;
+}
+#define ADROP_K1 0x9E3779B1u
+#define ADROP_K2 0x85EBCA77u
+struct AttnDrop {
+    uint32_t key;      // drop_key(seed, stream)
+    uint32_t thresh8;  // 0 => disabled; keep iff byte >= thresh8
+    float inv_keep;    // 256 / (256 - thresh8)
+    float keep_prob;   // (256 - thresh8) / 256
+};
+DEVFN bool attn_drop_keep(uint32_t key, uint32_t bh, uint32_t T2, uint32_t q, uint32_t k, uint32_t thresh8) {
+    const uint32_t w = mix1(key + (bh * T2 + (q >> 1)) * ADROP_K1 + (k >> 1) * ADROP_K2);
+    return ((w >> (8 * (2 * (q & 1) + (k & 1)))) & 0xFFu) >= thresh8;
+}
+
 DEVFN float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
 // ---- small math --------------------------------------------------------------------------
 DEVFN float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

@@ -111,3 +111,4 @@ struct LossArgs {
 int launch_elu1_poisson(const LossArgs& a, hipStream_t s);
 
 int launch_dropout_mask(uint8_t* out, long long rows, long long cols, DropCfg d, hipStream_t s);
+int launch_attn_dropout_mask(uint8_t* out, long long rows, long long T, AttnDrop d, hipStream_t s);

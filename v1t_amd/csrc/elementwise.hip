@@ -452,6 +452,16 @@ __global__ void dropout_mask_kernel(uint8_t* out, long long rows, long long cols
     }
 }
 
+__global__ void attn_dropout_mask_kernel(uint8_t* out, long long rows, long long T, AttnDrop d) {
+    const long long total = rows * T;
+    const uint32_t T2 = (uint32_t)(T + 1) >> 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(i / T), k = (uint32_t)(i % T);
+        const uint32_t bh = row / (uint32_t)T, q = row % (uint32_t)T;
+        out[i] = (d.thresh8 == 0 || attn_drop_keep(d.key, bh, T2, q, k, d.thresh8)) ? 1 : 0;
+    }
+}
+
 inline int ok() { return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH; }
 inline int nblocks(long long n, int cap = 2048) { return (int)std::min<long long>((n + 255) / 256, cap); }
 
@@ -558,6 +568,10 @@ int launch_l1_grad(const float* p, float* g, long long n, float scale, hipStream
 int launch_elu1_poisson(const LossArgs& a, hipStream_t s) {
     if (a.n <= 0) return V1T_OK;
     hipLaunchKernelGGL(elu1_poisson_kernel, dim3(nblocks(a.n, 1024)), dim3(256), 0, s, a);
+    return ok();
+}
+int launch_attn_dropout_mask(uint8_t* out, long long rows, long long T, AttnDrop d, hipStream_t s) {
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(nblocks(rows * T, 4096)), dim3(256), 0, s, out, rows, T, d);
     return ok();
 }
 int launch_dropout_mask(uint8_t* out, long long rows, long long cols, DropCfg d, hipStream_t s) {
