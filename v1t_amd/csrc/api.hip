@@ -662,19 +662,25 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
     pa.dW = grads + h->o_pw; pa.dbias = grads + h->o_pb; pa.dcls = grads + h->o_cls; pa.dpos = grads + h->o_pos;
     CHECK(launch_patch_embed_bwd(pa, s));
     // ---- BehaviorMLP backward
-    if (h->inject)
-        for (int k = 0; k < h->NB; ++k) {
-            const BmlpOff& bo = h->blk[k].bmlp[bm];
-            BmlpArgs ba{};
-            ba.v = behaviors; ba.B = B; ba.IN = h->IN; ba.J = h->J; ba.D = D; ba.DP = DP;
-            ba.W1 = arena + bo.w1; ba.W3 = arena + bo.w3;
-            ba.hid = (float*)(ws + w.hid) + (size_t)k * B * h->J;
-            ba.out = (float*)(ws + w.beta) + (size_t)k * B * DP;
-            ba.dout = dbeta + (size_t)k * B * DP;
-            ba.dW1 = grads + bo.w1; ba.db1 = bo.b1 >= 0 ? grads + bo.b1 : nullptr;
-            ba.dW3 = grads + bo.w3; ba.db3 = bo.b3 >= 0 ? grads + bo.b3 : nullptr;
-            CHECK(launch_bmlp_bwd(ba, s));
+    if (h->inject) {
+        for (int k0 = 0; k0 < h->NB; k0 += BMLP_MAX_BLOCKS) {
+            BmlpBatch bb{};
+            bb.n = std::min(BMLP_MAX_BLOCKS, h->NB - k0);
+            for (int i = 0; i < bb.n; ++i) {
+                const int k = k0 + i;
+                const BmlpOff& bo = h->blk[k].bmlp[bm];
+                BmlpArgs& ba = bb.blk[i];
+                ba.v = behaviors; ba.B = B; ba.IN = h->IN; ba.J = h->J; ba.D = D; ba.DP = DP;
+                ba.W1 = arena + bo.w1; ba.W3 = arena + bo.w3;
+                ba.hid = (float*)(ws + w.hid) + (size_t)k * B * h->J;
+                ba.out = (float*)(ws + w.beta) + (size_t)k * B * DP;
+                ba.dout = dbeta + (size_t)k * B * DP;
+                ba.dW1 = grads + bo.w1; ba.db1 = bo.b1 >= 0 ? grads + bo.b1 : nullptr;
+                ba.dW3 = grads + bo.w3; ba.db3 = bo.b3 >= 0 ? grads + bo.b3 : nullptr;
+            }
+            CHECK(launch_bmlp_bwd(bb, s));
         }
+    }
     return V1T_OK;
 }
 

@@ -18,7 +18,7 @@ struct AttnArgs {
     AttnDrop adrop;                // P dropout (2x2-block hash, 8-bit rate; common.h)
     // backward only
     const bf16_t* dO; int lddo;    // [rows][H*DP]
-    const float* delta;            // [B][H][T] rowsum(dO * O)
+    const float* delta;            // [B][H][T] keep_prob * rowsum(dO * O)
     bf16_t* dqkv; int lddqkv;      // [rows][3*H*DP]
     float* dscale;                 // [H] fp32 atomics or nullptr (LSA scale gradient)
 };

@@ -39,15 +39,46 @@ struct Geo {
     static constexpr int ITERS = (CHUNKS + 255) / 256;
 };
 
+// One LDS-DMA wave-instruction: 16 B per lane from each lane's own global address to lds_base + 16*lane.
+// Issued through inline asm ON PURPOSE: for the builtin, hipcc cannot tell which LDS buffer a pending DMA
+// writes and drains vmcnt(0) in front of the next ds_read of ANY buffer, which serialises the prefetch of
+// tile t+1 with the compute of tile t. The asm form is invisible to its wait-count bookkeeping; dma_wait()
+// (vmcnt(0)) in front of the tile-end barrier orders it. M0 is saved/restored inside the same statement.
+DEVFN void lds_dma16(const void* gsrc, const void* lds_dst_wave_uniform) {
+    unsigned keep;
+    const unsigned dst = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_dst_wave_uniform;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
+}
+DEVFN void lds_dma4(const void* gsrc, const void* lds_dst_wave_uniform) {
+    unsigned keep;
+    const unsigned dst = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_dst_wave_uniform;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
+}
+// Pin the wait for prologue loads in front of the main loop: otherwise hipcc places its vmcnt(0) at their
+// first use INSIDE the loop, where it would also drain the (invisible to it) DMA queue on every iteration.
+template <int N>
+DEVFN void touch(const bf16x8 (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" ::"v"(x[i]));
+}
+DEVFN void touch(float x) { asm volatile("" ::"v"(x)); }
+
+DEVFN void dma_wait_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // Global -> LDS tile staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
-// The LDS image of a [32 rows][STR] bf16 tile is a linear array of 16-B chunks (STR/8 per row, the last
+// The LDS image of a [ROWS][STR] bf16 tile is a linear array of 16-B chunks (STR/8 per row, the last
 // (STR-DP)/8 of each row are padding); one wave-instruction fills 64 consecutive chunks (1 KiB) with each
 // lane's own global source address, so the row padding costs nothing but a dummy fetch. Instruction n of a
 // tile is issued by wave n % 4. Rows beyond T are clamped to row T-1 (finite data; every consumer masks them).
-template <int DP, int STR>
+template <int DP, int STR, int ROWS = 32>
 struct TileDma {
     static constexpr int CPR = STR / 8;                 // chunks per LDS row
-    static constexpr int NCH = 32 * CPR;                // chunks per tile
+    static constexpr int NCH = ROWS * CPR;              // chunks per tile
     static constexpr int NINST = (NCH + 63) / 64;       // wave-instructions per tile
     static constexpr int SLOTS = (NINST + 3) / 4;       // per wave
     int row[SLOTS], c8[SLOTS];
@@ -70,9 +101,7 @@ struct TileDma {
             const int n = wave + 4 * s;
             if (n < NINST) {  // wave-uniform
                 const bf16_t* src = img + (size_t)min(t0 + row[s], T - 1) * ld + c8[s];
-                if (on[s])
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(lds + 512 * n), 16, 0, 0);
+                if (on[s]) lds_dma16(src, lds + 512 * n);
             }
         }
     }
@@ -236,13 +265,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     dmaK.issue(kbase, a.ldqkv, 0, a.T, sK[0]);
     dmaV.issue(vbase, a.ldqkv, 0, a.T, sV[0]);
-    __syncthreads();  // waits vmcnt(0): the DMA has landed
+    touch(qf);
+    touch(c);
+    dma_wait_and_barrier();
     for (int kt = 0; kt < nt - 1; ++kt) {
         const int buf = kt & 1;
         dmaK.issue(kbase, a.ldqkv, 32 * (kt + 1), a.T, sK[buf ^ 1]);
         dmaV.issue(vbase, a.ldqkv, 32 * (kt + 1), a.T, sV[buf ^ 1]);
         tile(std::false_type{}, kt, buf);
-        __syncthreads();
+        dma_wait_and_barrier();
     }
     tile(std::true_type{}, nt - 1, (nt - 1) & 1);
 
@@ -268,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
-// delta[b][h][t] = sum_d dO * O
+// delta[b][h][t] = keep_prob * sum_d dO * O
 template <int DP>
 __global__ void attn_delta_kernel(AttnArgs a, float* delta) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -286,7 +317,7 @@ __global__ void attn_delta_kernel(AttnArgs a, float* delta) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
     }
-    delta[((size_t)b * a.H + h) * a.T + t] = acc;
+    delta[((size_t)b * a.H + h) * a.T + t] = acc * a.adrop.keep_prob;  // 1/keep is folded into the backward epilogues
 }
 
 // ------------------------------------------------------------------------------------------
@@ -295,8 +326,11 @@ __global__ void attn_delta_kernel(AttnArgs a, float* delta) {
 template <int DP, bool DROP, bool DIAG>
 __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(AttnArgs a) {
     using G = Geo<DP>;
-    __shared__ __attribute__((aligned(16))) bf16_t sK[2][32 * G::RSTR];
-    __shared__ __attribute__((aligned(16))) bf16_t sV[2][32 * G::RSTR];
+    // 64-key tiles processed as two independent 32-key halves: with one wave per SIMD the element-wise
+    // work of one half is issued while the MFMAs of the other half execute (the matrix pipe is asynchronous)
+    constexpr int TR = 64;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][TR * G::RSTR];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[2][TR * G::RSTR];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, h, b;
     decode_block(a, rb, h, b);
@@ -306,7 +340,7 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
     const bf16_t* kbase = qkv_b + HD + h * DP;
     const bf16_t* vbase = qkv_b + 2 * HD + h * DP;
-    TileDma<DP, G::RSTR> dma;
+    TileDma<DP, G::RSTR, TR> dma;
     dma.init(lane, wave);
     const float sc = a.scale[a.scale_per_head ? h : 0];
     const float c = sc * LOG2E;
@@ -323,7 +357,7 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
     const size_t sidx = ((size_t)b * a.H + h) * a.T + (qok ? q : 0);
     const float neglse = -a.lse2[sidx];
     // 1/keep is folded into the epilogue: dS' = P * (keep ? dP : 0  -  delta * keep_prob)
-    const float dl = a.delta[sidx] * (DROP ? a.adrop.keep_prob : 1.0f);
+    const float dl = a.delta[sidx];  // already x keep_prob (delta kernel)
     f32x16 dq[G::DB];
 #pragma unroll
     for (int d = 0; d < G::DB; ++d) zero16(dq[d]);
@@ -334,75 +368,88 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
 
     const int koff = (lane & 31) * G::RSTR + 8 * h2;
     const int toff = tr_lane_off(lane, G::RSTR);
-    const int nt = (a.T + 31) / 32;
+    const int nt = (a.T + TR - 1) / TR;
 
     auto tile = [&](auto tail_tag, int kt, int buf) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        f32x16 s, dp;
-        zero16(s);
-        zero16(dp);
-        const bf16_t* kp = &sK[buf][koff];
-        const bf16_t* vp = &sV[buf][koff];
-        const bf16_t* tp = &sK[buf][toff];
-        bf16x8 kfr[G::KS], vfr[G::KS], tfr[2 * G::DB];
+        f32x16 s[2], dp[2];
+        // phase 1 of both halves: S^T = K.Q^T and dP^T = V.dO^T
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) kfr[ks] = *(const bf16x8*)(kp + 16 * ks);
+        for (int hf = 0; hf < 2; ++hf) {
+            zero16(s[hf]);
+            zero16(dp[hf]);
+            const bf16_t* kp = &sK[buf][32 * hf * G::RSTR + koff];
+            const bf16_t* vp = &sV[buf][32 * hf * G::RSTR + koff];
+            bf16x8 kfr[G::KS], vfr[G::KS];
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) vfr[ks] = *(const bf16x8*)(vp + 16 * ks);
+            for (int ks = 0; ks < G::KS; ++ks) kfr[ks] = *(const bf16x8*)(kp + 16 * ks);
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) s = mfma32(kfr[ks], qf[ks], s);
+            for (int ks = 0; ks < G::KS; ++ks) vfr[ks] = *(const bf16x8*)(vp + 16 * ks);
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) dp = mfma32(vfr[ks], dof[ks], dp);
+            for (int ks = 0; ks < G::KS; ++ks) s[hf] = mfma32(kfr[ks], qf[ks], s[hf]);
 #pragma unroll
-        for (int d = 0; d < G::DB; ++d) {
-            tfr[2 * d] = tr_frag<G::RSTR>(tp, 0, 32 * d);
-            tfr[2 * d + 1] = tr_frag<G::RSTR>(tp, 16, 32 * d);
+            for (int ks = 0; ks < G::KS; ++ks) dp[hf] = mfma32(vfr[ks], dof[ks], dp[hf]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * G::KS, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 0);
 #pragma unroll
-        for (int ks = 0; ks < 2 * G::KS; ++ks) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 * G::DB / (2 * G::KS), 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int hf = 0; hf < 2; ++hf) {
+            const bf16_t* tp = &sK[buf][32 * hf * G::RSTR + toff];
+            bf16x8 tfr[2 * G::DB];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bool keep[4] = {true, true, true, true};
-            if constexpr (DROP) drop4(dbase + (uint32_t)(16 * kt + 4 * g) * ADROP_K2, ADROP_K2, sh_even, sh_odd, a.adrop.thresh8, keep);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * g + j;
-                float p = fast_exp2(fmaf(s[r], c, neglse));
-                if constexpr (TAIL || DIAG) {
-                    const int key = 32 * kt + acc_row(r, lane);
-                    bool dead = false;
-                    if constexpr (TAIL) dead = key >= a.T;
-                    if constexpr (DIAG) dead = dead || key == q;
-                    p = dead ? 0.f : p;
-                }
-                const float gg = keep[j] ? dp[r] : 0.f;
-                const float ds = p * (gg - dl);
-                if constexpr (DIAG) dsc = fmaf(ds, s[r], dsc);
-                s[r] = ds;
+            for (int d = 0; d < G::DB; ++d) {
+                tfr[2 * d] = tr_frag<G::RSTR>(tp, 0, 32 * d);
+                tfr[2 * d + 1] = tr_frag<G::RSTR>(tp, 16, 32 * d);
             }
-        }
-        const bf16x8 b0 = acc_to_b(s, 0), b1 = acc_to_b(s, 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int d = 0; d < G::DB; ++d) {
-            dq[d] = mfma32(tfr[2 * d], b0, dq[d]);
-            dq[d] = mfma32(tfr[2 * d + 1], b1, dq[d]);
+            for (int g = 0; g < 4; ++g) {
+                bool keep[4] = {true, true, true, true};
+                if constexpr (DROP)
+                    drop4(dbase + (uint32_t)(32 * kt + 16 * hf + 4 * g) * ADROP_K2, ADROP_K2, sh_even, sh_odd, a.adrop.thresh8, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    float p = fast_exp2(fmaf(s[hf][r], c, neglse));
+                    if constexpr (TAIL || DIAG) {
+                        const int key = TR * kt + 32 * hf + acc_row(r, lane);
+                        bool dead = false;
+                        if constexpr (TAIL) dead = key >= a.T;
+                        if constexpr (DIAG) dead = dead || key == q;
+                        p = dead ? 0.f : p;
+                    }
+                    const float gg = keep[j] ? dp[hf][r] : 0.f;
+                    const float ds = p * (gg - dl);
+                    if constexpr (DIAG) dsc = fmaf(ds, s[hf][r], dsc);
+                    s[hf][r] = ds;
+                }
+            }
+            const bf16x8 b0 = acc_to_b(s[hf], 0), b1 = acc_to_b(s[hf], 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < G::DB; ++d) {
+                dq[d] = mfma32(tfr[2 * d], b0, dq[d]);
+                dq[d] = mfma32(tfr[2 * d + 1], b1, dq[d]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     dma.issue(kbase, a.ldqkv, 0, a.T, sK[0]);
     dma.issue(vbase, a.ldqkv, 0, a.T, sV[0]);
-    __syncthreads();
+    touch(qf);
+    touch(dof);
+    touch(neglse);
+    touch(dl);
+    touch(c);
+    dma_wait_and_barrier();
     for (int kt = 0; kt < nt - 1; ++kt) {
         const int buf = kt & 1;
-        dma.issue(kbase, a.ldqkv, 32 * (kt + 1), a.T, sK[buf ^ 1]);
-        dma.issue(vbase, a.ldqkv, 32 * (kt + 1), a.T, sV[buf ^ 1]);
+        dma.issue(kbase, a.ldqkv, TR * (kt + 1), a.T, sK[buf ^ 1]);
+        dma.issue(vbase, a.ldqkv, TR * (kt + 1), a.T, sV[buf ^ 1]);
         tile(std::false_type{}, kt, buf);
-        __syncthreads();
+        dma_wait_and_barrier();
     }
     tile(std::true_type{}, nt - 1, (nt - 1) & 1);
 
@@ -432,15 +479,16 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
 template <int DP, bool DROP, bool DIAG>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     using G = Geo<DP>;
-    __shared__ __attribute__((aligned(16))) bf16_t sQ[2][32 * G::RSTR];
-    __shared__ __attribute__((aligned(16))) bf16_t sD[2][32 * G::RSTR];
-    __shared__ __attribute__((aligned(16))) float sL[2][32];   // -lse2 of the tile's queries
-    __shared__ __attribute__((aligned(16))) float sDl[2][32];  // delta * keep_prob
+    constexpr int TR = 64;  // 64-query tiles = two independent 32-query halves (see the dQ kernel)
+    __shared__ __attribute__((aligned(16))) bf16_t sQ[2][TR * G::RSTR];
+    __shared__ __attribute__((aligned(16))) bf16_t sD[2][TR * G::RSTR];
+    __shared__ __attribute__((aligned(16))) float sL[2][TR];   // lse2 of the tile's queries
+    __shared__ __attribute__((aligned(16))) float sDl[2][TR];  // delta * keep_prob
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, h, b;
     decode_block(a, rb, h, b);
     const int key = rb * 128 + 32 * wave + (lane & 31);
-    TileDma<DP, G::RSTR> dma;
+    TileDma<DP, G::RSTR, TR> dma;
     dma.init(lane, wave);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
@@ -452,7 +500,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     const float sc = a.scale[a.scale_per_head ? h : 0];
     const float c = sc * LOG2E;
     const bool kok = key < a.T;
-    const float kprob = DROP ? a.adrop.keep_prob : 1.0f;
 
     bf16x8 kf[G::KS], vf[G::KS];
 #pragma unroll
@@ -476,101 +523,99 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
 
     const int roff = (lane & 31) * G::RSTR + 8 * h2;
     const int toff = tr_lane_off(lane, G::RSTR);
-    const int nt = (a.T + 31) / 32;
-    // -lse2 and delta*keep_prob of the tile's 32 queries: two values per lane of wave 0 -> LDS
-    // (register loads are consumed only at the END of the tile, next to the barrier's vmcnt(0): an earlier
-    // use would make the compiler drain the DMA queue in the middle of the tile)
-    float rl = 0.f, rdl = 0.f;
+    const int nt = (a.T + TR - 1) / TR;
+    // lse2 and delta (pre-scaled by keep_prob in the delta kernel) of the tile's 64 queries go to LDS by DMA too
+    // (an ordinary load inside the loop would make hipcc drain the whole vmcnt queue at its first use)
     auto stage = [&](int t, int buf) {
-        dma.issue(qbase, a.ldqkv, 32 * t, a.T, sQ[buf]);
-        dma.issue(dobase, a.lddo, 32 * t, a.T, sD[buf]);
-        if (tid < 32) {
-            const int qq = min(32 * t + tid, a.T - 1);
-            rl = lbase[qq];
-            rdl = dbase_[qq];
-        }
-    };
-    auto stage_finish = [&](int buf) {
-        if (tid < 32) {
-            sL[buf][tid] = -rl;
-            sDl[buf][tid] = rdl * kprob;
-        }
+        dma.issue(qbase, a.ldqkv, TR * t, a.T, sQ[buf]);
+        dma.issue(dobase, a.lddo, TR * t, a.T, sD[buf]);
+        const int qq = min(TR * t + lane, a.T - 1);
+        if (wave == 0) lds_dma4(lbase + qq, sL[buf]);
+        if (wave == 1) lds_dma4(dbase_ + qq, sDl[buf]);
     };
     auto tile = [&](auto tail_tag, int qt, int buf) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        f32x16 s, dp;
-        zero16(s);
-        zero16(dp);
-        const bf16_t* qp = &sQ[buf][roff];
-        const bf16_t* dop = &sD[buf][roff];
-        const bf16_t* tq = &sQ[buf][toff];
-        const bf16_t* td = &sD[buf][toff];
-        bf16x8 qfr[G::KS], dfr[G::KS], tdf[2 * G::DB], tqf[2 * G::DB];
+        f32x16 s[2], dp[2];
+        // phase 1 of both halves: S = Q.K^T and dP = dO.V^T (rows = queries, column = this lane's key)
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) qfr[ks] = *(const bf16x8*)(qp + 16 * ks);
+        for (int hf = 0; hf < 2; ++hf) {
+            zero16(s[hf]);
+            zero16(dp[hf]);
+            const bf16_t* qp = &sQ[buf][32 * hf * G::RSTR + roff];
+            const bf16_t* dop = &sD[buf][32 * hf * G::RSTR + roff];
+            bf16x8 qfr[G::KS], dfr[G::KS];
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) dfr[ks] = *(const bf16x8*)(dop + 16 * ks);
+            for (int ks = 0; ks < G::KS; ++ks) qfr[ks] = *(const bf16x8*)(qp + 16 * ks);
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) s = mfma32(qfr[ks], kf[ks], s);
+            for (int ks = 0; ks < G::KS; ++ks) dfr[ks] = *(const bf16x8*)(dop + 16 * ks);
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) dp = mfma32(dfr[ks], vf[ks], dp);
+            for (int ks = 0; ks < G::KS; ++ks) s[hf] = mfma32(qfr[ks], kf[ks], s[hf]);
 #pragma unroll
-        for (int d = 0; d < G::DB; ++d) {
-            tdf[2 * d] = tr_frag<G::RSTR>(td, 0, 32 * d);
-            tdf[2 * d + 1] = tr_frag<G::RSTR>(td, 16, 32 * d);
-            tqf[2 * d] = tr_frag<G::RSTR>(tq, 0, 32 * d);
-            tqf[2 * d + 1] = tr_frag<G::RSTR>(tq, 16, 32 * d);
+            for (int ks = 0; ks < G::KS; ++ks) dp[hf] = mfma32(dfr[ks], vf[ks], dp[hf]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * G::KS, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 0);
 #pragma unroll
-        for (int ks = 0; ks < 2 * G::KS; ++ks) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8 * G::DB / (2 * G::KS), 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // rows of s / dp = queries 32qt + 8g + 4h2 + j; column = this lane's key
+        for (int hf = 0; hf < 2; ++hf) {
+            const bf16_t* tq = &sQ[buf][32 * hf * G::RSTR + toff];
+            const bf16_t* td = &sD[buf][32 * hf * G::RSTR + toff];
+            bf16x8 tdf[2 * G::DB], tqf[2 * G::DB];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 nl = *(const f32x4*)(&sL[buf][8 * g + 4 * h2]);
-            const f32x4 dl = *(const f32x4*)(&sDl[buf][8 * g + 4 * h2]);
-            bool keep[4] = {true, true, true, true};
-            if constexpr (DROP) drop4(dbase + (uint32_t)(16 * qt + 4 * g) * ADROP_K1, ADROP_K1, sh_even, sh_odd, a.adrop.thresh8, keep);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * g + j;
-                float p = fast_exp2(fmaf(s[r], c, nl[j]));
-                if constexpr (TAIL || DIAG) {
-                    const int qq = 32 * qt + acc_row(r, lane);
-                    bool dead = false;
-                    if constexpr (TAIL) dead = qq >= a.T;
-                    if constexpr (DIAG) dead = dead || qq == key;
-                    p = dead ? 0.f : p;
-                }
-                const float gg = keep[j] ? dp[r] : 0.f;
-                dp[r] = keep[j] ? p : 0.f;       // dropped P (x 1/keep in the epilogue) -> dV
-                s[r] = p * (gg - dl[j]);          // dS' (x scale/keep in the epilogue)   -> dK
+            for (int d = 0; d < G::DB; ++d) {
+                tdf[2 * d] = tr_frag<G::RSTR>(td, 0, 32 * d);
+                tdf[2 * d + 1] = tr_frag<G::RSTR>(td, 16, 32 * d);
+                tqf[2 * d] = tr_frag<G::RSTR>(tq, 0, 32 * d);
+                tqf[2 * d + 1] = tr_frag<G::RSTR>(tq, 16, 32 * d);
             }
-        }
-        const bf16x8 p0 = acc_to_b(dp, 0), p1 = acc_to_b(dp, 1);
-        const bf16x8 s0 = acc_to_b(s, 0), s1 = acc_to_b(s, 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int d = 0; d < G::DB; ++d) {
-            dv[d] = mfma32(tdf[2 * d], p0, dv[d]);
-            dv[d] = mfma32(tdf[2 * d + 1], p1, dv[d]);
-            dk[d] = mfma32(tqf[2 * d], s0, dk[d]);
-            dk[d] = mfma32(tqf[2 * d + 1], s1, dk[d]);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 nl = *(const f32x4*)(&sL[buf][32 * hf + 8 * g + 4 * h2]);
+                const f32x4 dl = *(const f32x4*)(&sDl[buf][32 * hf + 8 * g + 4 * h2]);
+                bool keep[4] = {true, true, true, true};
+                if constexpr (DROP)
+                    drop4(dbase + (uint32_t)(32 * qt + 16 * hf + 4 * g) * ADROP_K1, ADROP_K1, sh_even, sh_odd, a.adrop.thresh8, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    float p = fast_exp2(fmaf(s[hf][r], c, -nl[j]));
+                    if constexpr (TAIL || DIAG) {
+                        const int qq = TR * qt + 32 * hf + acc_row(r, lane);
+                        bool dead = false;
+                        if constexpr (TAIL) dead = qq >= a.T;
+                        if constexpr (DIAG) dead = dead || qq == key;
+                        p = dead ? 0.f : p;
+                    }
+                    const float gg = keep[j] ? dp[hf][r] : 0.f;
+                    dp[hf][r] = keep[j] ? p : 0.f;     // dropped P (x 1/keep in the epilogue) -> dV
+                    s[hf][r] = p * (gg - dl[j]);        // dS' (x scale/keep in the epilogue)   -> dK
+                }
+            }
+            const bf16x8 p0 = acc_to_b(dp[hf], 0), p1 = acc_to_b(dp[hf], 1);
+            const bf16x8 s0 = acc_to_b(s[hf], 0), s1 = acc_to_b(s[hf], 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < G::DB; ++d) {
+                dv[d] = mfma32(tdf[2 * d], p0, dv[d]);
+                dv[d] = mfma32(tdf[2 * d + 1], p1, dv[d]);
+                dk[d] = mfma32(tqf[2 * d], s0, dk[d]);
+                dk[d] = mfma32(tqf[2 * d + 1], s1, dk[d]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     stage(0, 0);
-    stage_finish(0);
-    __syncthreads();
+    touch(kf);
+    touch(vf);
+    touch(c);
+    dma_wait_and_barrier();
     for (int qt = 0; qt < nt - 1; ++qt) {
         const int buf = qt & 1;
         stage(qt + 1, buf ^ 1);
         tile(std::false_type{}, qt, buf);
-        stage_finish(buf ^ 1);
-        __syncthreads();
+        dma_wait_and_barrier();
     }
     tile(std::true_type{}, nt - 1, (nt - 1) & 1);
 

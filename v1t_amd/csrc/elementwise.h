@@ -83,8 +83,13 @@ struct BmlpArgs {
     const float* dout;   // [B][DP]
     float* dW1; float* db1; float* dW3; float* db3;
 };
+constexpr int BMLP_MAX_BLOCKS = 16;
+struct BmlpBatch {
+    BmlpArgs blk[BMLP_MAX_BLOCKS];
+    int n;
+};
 int launch_bmlp_fwd(const BmlpArgs& a, hipStream_t s);
-int launch_bmlp_bwd(const BmlpArgs& a, hipStream_t s);
+int launch_bmlp_bwd(const BmlpBatch& bb, hipStream_t s);  // all blocks' B-MLPs in one launch
 
 struct AdamArgs {
     float* p; float* g; float* m; float* v;

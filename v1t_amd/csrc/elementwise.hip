@@ -197,8 +197,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
 
 // LayerNorm backward + residual add + (optional) token-sum for the injection gradient +
 // (optional) dropout-backward/cast of the result for the next branch and its bias gradient.
-// Workgroup = 64 rows of one image (16 per wave); column partials stay in registers across rows.
+// Workgroup = 64 rows of one image (16 per wave, 4 at a time); column partials stay in registers across rows.
 constexpr int LNB_ROWS = 64;
+constexpr int LNB_RPI = 4;  // rows per wave iteration: their loads are issued together (latency hiding by ILP)
 template <int NE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     __shared__ float sred[4][4][256];
@@ -211,46 +212,64 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         gam[i] = (c < a.D) ? a.gamma[c] : 0.f;
         adg[i] = adb[i] = ainj[i] = abn[i] = 0.f;
     }
-    for (int rr = wave; rr < LNB_ROWS; rr += 4) {
-        const int t = t0 + rr;
-        if (t >= a.T) break;
-        const int row = b * a.T + t;
-        const float mean = a.mean[row], rstd = a.rstd[row];
-        float dz[NE], xh[NE], dy[NE];
-        float s1 = 0.f, s2 = 0.f;
+    for (int r0 = wave * (LNB_ROWS / 4); r0 < (wave + 1) * (LNB_ROWS / 4); r0 += LNB_RPI) {
+        if (t0 + r0 >= a.T) break;
+        float dz[LNB_RPI][NE], xv[LNB_RPI][NE], gi[LNB_RPI][NE], mean[LNB_RPI], rstd[LNB_RPI];
+        // issue the loads of LNB_RPI rows together
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int c = lane + 64 * i;
-            dz[i] = xh[i] = dy[i] = 0.f;
-            if (c < a.D) {
-                dz[i] = a.dz[(size_t)row * a.DP + c];
-                xh[i] = (a.x[(size_t)row * a.DP + c] - mean) * rstd;
-                dy[i] = dz[i] * gam[i];
-            }
-            s1 += dy[i];
-            s2 += dy[i] * xh[i];
-        }
-        s1 = wave_sum(s1) / a.D;
-        s2 = wave_sum(s2) / a.D;
+        for (int u = 0; u < LNB_RPI; ++u) {
+            const int t = min(t0 + r0 + u, a.T - 1);
+            const int row = b * a.T + t;
+            mean[u] = a.mean[row];
+            rstd[u] = a.rstd[row];
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int c = lane + 64 * i;
-            if (c < a.DP) {
-                float go = 0.f;
+            for (int i = 0; i < NE; ++i) {
+                const int c = lane + 64 * i;
+                dz[u][i] = xv[u][i] = gi[u][i] = 0.f;
                 if (c < a.D) {
-                    go = a.gin[(size_t)row * a.DP + c] + rstd * (dy[i] - s1 - xh[i] * s2);
-                    adg[i] += dz[i] * xh[i];
-                    adb[i] += dz[i];
-                    ainj[i] += go;
+                    dz[u][i] = a.dz[(size_t)row * a.DP + c];
+                    xv[u][i] = a.x[(size_t)row * a.DP + c];
+                    gi[u][i] = a.gin[(size_t)row * a.DP + c];
                 }
-                a.gout[(size_t)row * a.DP + c] = go;
-                if (a.dy_next) {
-                    float v = go;
-                    if (a.drop_next.thresh && c < a.D)
-                        v = drop_keep(a.drop_next.key, row, c, a.drop_next.thresh) ? v * a.drop_next.inv_keep : 0.f;
-                    const bf16_t vb = (bf16_t)v;
-                    a.dy_next[(size_t)row * a.DP + c] = vb;
-                    abn[i] += (float)vb;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LNB_RPI; ++u) {
+            const int t = t0 + r0 + u;
+            if (t >= a.T) break;
+            const int row = b * a.T + t;
+            float xh[NE], dy[NE];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int c = lane + 64 * i;
+                xh[i] = (c < a.D) ? (xv[u][i] - mean[u]) * rstd[u] : 0.f;
+                dy[i] = dz[u][i] * gam[i];
+                s1 += dy[i];
+                s2 += dy[i] * xh[i];
+            }
+            s1 = wave_sum(s1) / a.D;
+            s2 = wave_sum(s2) / a.D;
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int c = lane + 64 * i;
+                if (c < a.DP) {
+                    float go = 0.f;
+                    if (c < a.D) {
+                        go = gi[u][i] + rstd[u] * (dy[i] - s1 - xh[i] * s2);
+                        adg[i] += dz[u][i] * xh[i];
+                        adb[i] += dz[u][i];
+                        ainj[i] += go;
+                    }
+                    a.gout[(size_t)row * a.DP + c] = go;
+                    if (a.dy_next) {
+                        float v = go;
+                        if (a.drop_next.thresh && c < a.D)
+                            v = drop_keep(a.drop_next.key, row, c, a.drop_next.thresh) ? v * a.drop_next.inv_keep : 0.f;
+                        const bf16_t vb = (bf16_t)v;
+                        a.dy_next[(size_t)row * a.DP + c] = vb;
+                        abn[i] += (float)vb;
+                    }
                 }
             }
         }
@@ -286,18 +305,31 @@ __global__ __launch_bounds__(256) void drop_cast_kernel(CastArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * LNB_ROWS;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int rr = wave; rr < LNB_ROWS; rr += 4) {
-        const int row = r0 + rr;
-        if (row >= a.rows) break;
+    for (int rr = wave * (LNB_ROWS / 4); rr < (wave + 1) * (LNB_ROWS / 4); rr += LNB_RPI) {
+        float g[LNB_RPI][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = lane + 64 * i;
-            if (c < a.DP) {
-                float v = (c < a.D) ? a.g[(size_t)row * a.DP + c] : 0.f;
-                if (a.drop.thresh && c < a.D) v = drop_keep(a.drop.key, row, c, a.drop.thresh) ? v * a.drop.inv_keep : 0.f;
-                const bf16_t vb = (bf16_t)v;
-                a.dy[(size_t)row * a.DP + c] = vb;
-                acc[i] += (float)vb;
+        for (int u = 0; u < LNB_RPI; ++u) {
+            const int row = min(r0 + rr + u, a.rows - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                g[u][i] = (c < a.D) ? a.g[(size_t)row * a.DP + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LNB_RPI; ++u) {
+            const int row = r0 + rr + u;
+            if (row >= a.rows) break;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                if (c < a.DP) {
+                    float v = g[u][i];
+                    if (a.drop.thresh && c < a.D) v = drop_keep(a.drop.key, row, c, a.drop.thresh) ? v * a.drop.inv_keep : 0.f;
+                    const bf16_t vb = (bf16_t)v;
+                    a.dy[(size_t)row * a.DP + c] = vb;
+                    acc[i] += (float)vb;
+                }
             }
         }
     }
@@ -335,27 +367,30 @@ __global__ __launch_bounds__(256) void bmlp_fwd_kernel(BmlpArgs a) {
     }
 }
 
-// Single workgroup; all sums over the (small) batch are owned by one thread -> plain += into the
-// gradient arena (launches on one stream are ordered).
-__global__ __launch_bounds__(256) void bmlp_bwd_kernel(BmlpArgs a) {
+// BehaviorMLP backward for all blocks in one launch: grid (BMLP_SPLIT, NB). Every workgroup recomputes the
+// tiny intermediates (dpre2 (B,D), dpre1 (B,J)) in LDS and owns a 1/BMLP_SPLIT slice of each gradient, so
+// every output element has exactly one writer -> plain += into the gradient arena.
+constexpr int BMLP_SPLIT = 16;
+__global__ __launch_bounds__(256) void bmlp_bwd_kernel(BmlpBatch bb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const BmlpArgs& a = bb.blk[blockIdx.y];
     float* s2 = smem;               // [B][D]
     float* s1 = smem + a.B * a.D;   // [B][J]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, part = blockIdx.x, nparts = gridDim.x;
     for (int e = tid; e < a.B * a.D; e += 256) {
         const int b = e / a.D, d = e % a.D;
         const float o = a.out[(size_t)b * a.DP + d];
         s2[e] = a.dout[(size_t)b * a.DP + d] * (1.f - o * o);
     }
     __syncthreads();
-    for (int e = tid; e < a.D * a.J; e += 256) {
+    for (int e = part * 256 + tid; e < a.D * a.J; e += 256 * nparts) {
         const int d = e / a.J, j = e % a.J;
         float s = 0.f;
         for (int b = 0; b < a.B; ++b) s += s2[b * a.D + d] * a.hid[(size_t)b * a.J + j];
         a.dW3[e] += s;
     }
     if (a.db3)
-        for (int d = tid; d < a.D; d += 256) {
+        for (int d = part * 256 + tid; d < a.D; d += 256 * nparts) {
             float s = 0.f;
             for (int b = 0; b < a.B; ++b) s += s2[b * a.D + d];
             a.db3[d] += s;
@@ -368,14 +403,14 @@ __global__ __launch_bounds__(256) void bmlp_bwd_kernel(BmlpArgs a) {
         s1[e] = s * (1.f - h * h);
     }
     __syncthreads();
-    for (int e = tid; e < a.J * a.IN; e += 256) {
+    for (int e = part * 256 + tid; e < a.J * a.IN; e += 256 * nparts) {
         const int j = e / a.IN, i = e % a.IN;
         float s = 0.f;
         for (int b = 0; b < a.B; ++b) s += s1[b * a.J + j] * a.v[b * a.IN + i];
         a.dW1[e] += s;
     }
     if (a.db1)
-        for (int j = tid; j < a.J; j += 256) {
+        for (int j = part * 256 + tid; j < a.J; j += 256 * nparts) {
             float s = 0.f;
             for (int b = 0; b < a.B; ++b) s += s1[b * a.J + j];
             a.db1[j] += s;
@@ -543,10 +578,12 @@ int launch_bmlp_fwd(const BmlpArgs& a, hipStream_t s) {
     return ok();
 }
 
-int launch_bmlp_bwd(const BmlpArgs& a, hipStream_t s) {
+int launch_bmlp_bwd(const BmlpBatch& bb, hipStream_t s) {
+    if (bb.n <= 0) return V1T_OK;
+    const BmlpArgs& a = bb.blk[0];
     const size_t smem = sizeof(float) * (size_t)a.B * (a.D + a.J);
-    if (smem > 64 * 1024) return V1T_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bmlp_bwd_kernel, dim3(1), dim3(256), smem, s, a);
+    if (smem > 64 * 1024 || bb.n > BMLP_MAX_BLOCKS) return V1T_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bmlp_bwd_kernel, dim3(BMLP_SPLIT, bb.n), dim3(256), smem, s, bb);
     return ok();
 }
 

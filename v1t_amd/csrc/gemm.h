@@ -10,8 +10,8 @@ enum GemmEpi {
     EPI_BF16 = 0,       // C bf16 = acc
     EPI_F32 = 1,        // C fp32 = acc
     EPI_BIAS_RES = 2,   // C fp32 = res + dropout(acc + bias)                       (proj, FC2)
-    EPI_BIAS_GELU = 3,  // C bf16 = acc + bias (pre-activation); C2 bf16 = dropout(gelu(.)) (FC1)
-    EPI_DGELU = 4,      // C bf16 = acc * mask/keep * gelu'(aux); colsum += column sums  (dX of FC2)
+    EPI_BIAS_GELU = 3,  // v = acc + bias; C bf16 = gelu'(v) (for the backward); C2 bf16 = dropout(gelu(v)) (FC1)
+    EPI_DGELU = 4,      // C bf16 = acc * mask/keep * aux (aux = saved gelu'); colsum += column sums  (dX of FC2)
 };
 
 struct GemmNTArgs {

@@ -38,10 +38,13 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], int m0, int n
                 if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = g.res[(size_t)row * g.ldres + col] + v;
             } else if constexpr (EPI == EPI_BIAS_GELU) {
                 v += bias;
-                float a = gelu_erf(v);
+                // gelu and gelu' share erf / exp: the backward only needs gelu'(v), stored in place of v
+                const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+                const float gp = cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+                float a = v * cdf;
                 if (g.drop.thresh) a = drop_keep(g.drop.key, row, col, g.drop.thresh) ? a * g.drop.inv_keep : 0.f;
                 if (ok) {
-                    ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = (bf16_t)v;
+                    ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = (bf16_t)gp;
                     const bf16_t ah = (bf16_t)a;
                     g.C2[(size_t)row * g.ldc2 + col] = ah;
                     if (g.C2_lo) g.C2_lo[(size_t)row * g.ldc2 + col] = (bf16_t)(a - (float)ah);
@@ -49,8 +52,7 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], int m0, int n
             } else if constexpr (EPI == EPI_DGELU) {
                 float d = 0.f;
                 if (ok) {
-                    const float hp = (float)g.aux[(size_t)row * g.ldaux + col];
-                    d = v * gelu_erf_grad(hp);
+                    d = v * (float)g.aux[(size_t)row * g.ldaux + col];  // aux = gelu'(pre-activation), saved by FC1
                     if (g.drop.thresh) d = drop_keep(g.drop.key, row, col, g.drop.thresh) ? d * g.drop.inv_keep : 0.f;
                     const bf16_t db = (bf16_t)d;
                     ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = db;
