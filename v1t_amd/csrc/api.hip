@@ -109,7 +109,7 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
     w.z2 = take(R * h->DP * 2) - b0;
     w.mean2 = take(R * 4) - b0;
     w.rstd2 = take(R * 4) - b0;
-    w.hpre = take(R * h->MP * 2) - b0;
+    w.hpre = take((R + 127) / 128 * 128 * h->MP * 2) - b0;  // gelu' in accumulator-fragment order (full 128-row tiles)
     w.hact = take(R * h->MP * 2) - b0;
     w.z1_lo = take(R * h->DP * 2) - b0;
     w.o_lo = take(R * h->HDP * 2) - b0;
@@ -482,7 +482,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         l1.x = xcur; l1.inject = h->inject ? (float*)(ws + w.beta) + (size_t)k * B * DP : nullptr; l1.xout = xa;
         l1.gamma = arena + b.ln1w; l1.beta = arena + b.ln1b; l1.z = z1; l1.z_lo = (bf16_t*)(wb + w.z1_lo);
         l1.mean = (float*)(wb + w.mean1); l1.rstd = (float*)(wb + w.rstd1);
-        l1.rows = R; l1.T = h->T; l1.D = D; l1.DP = DP; l1.eps = h->c.ln_eps;
+        l1.rows = R; l1.T = h->T; l1.D = D; l1.DP = DP; l1.eps = h->c.ln_eps; l1.ones_col = -1;
         CHECK(launch_ln_fwd(l1, s));
 
         GemmNTArgs g{};
@@ -507,6 +507,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         l2.x = xm; l2.inject = nullptr; l2.xout = nullptr; l2.gamma = arena + b.ln2w; l2.beta = arena + b.ln2b; l2.z = z2; l2.z_lo = (bf16_t*)(wb + w.z2_lo);
         l2.mean = (float*)(wb + w.mean2); l2.rstd = (float*)(wb + w.rstd2);
         l2.rows = R; l2.T = h->T; l2.D = D; l2.DP = DP; l2.eps = h->c.ln_eps;
+        l2.ones_col = (DP > D && h->blk[k].fc1b >= 0) ? DP - 1 : -1;  // d(fc1 bias) comes out of the dW1 GEMM
         CHECK(launch_ln_fwd(l2, s));
 
         g = GemmNTArgs{};
@@ -590,13 +591,15 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         // d_hpre = (dy . W2) * mask * gelu'(hpre); db1 += colsum
         GemmNTArgs g{};
         g.A = dy; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_fc2_t); g.ldb = DP; g.M = R; g.N = MP; g.K = DP; g.C = dhpre; g.ldc = MP;
-        g.aux = hpre; g.ldaux = MP; g.colsum = b.fc1b >= 0 ? grads + b.fc1b : nullptr; g.n_valid = M;
+        g.aux = hpre; g.ldaux = MP;
+        g.colsum = (b.fc1b >= 0 && DP == D) ? grads + b.fc1b : nullptr; g.n_valid = M;  // else: ones column in dW1
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
         CHECK(launch_gemm_nt(g, EPI_DGELU, s));
         // dW1 += d_hpre^T z2
         t = GemmTNArgs{};
         t.Y = dhpre; t.ldy = MP; t.X = z2; t.ldx = DP; t.M = R; t.NY = MP; t.NX = DP; t.dW = grads + b.fc1; t.ldw = D;
         t.yseg_pad = MP; t.yseg_valid = M; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
+        if (DP > D && b.fc1b >= 0) { t.dbias = grads + b.fc1b; t.ones_col = DP - 1; }  // z2[:, DP-1] == 1 (LN kernel)
         t.m_chunk = mchunk((MP + 127) / 128);
         CHECK(launch_gemm_tn(t, s));
         // dz2 = d_hpre . W1
@@ -770,7 +773,7 @@ int v1t_layernorm_forward(const float* x, const float* inject, float* xout, cons
                           float* mean, float* rstd, int B, int T, int D, int DP, float eps, void* stream) {
     LnFwdArgs a{};
     a.x = x; a.inject = inject; a.xout = xout; a.gamma = gamma; a.beta = beta; a.z = (bf16_t*)z; a.mean = mean; a.rstd = rstd;
-    a.rows = B * T; a.T = T; a.D = D; a.DP = DP; a.eps = eps;
+    a.rows = B * T; a.T = T; a.D = D; a.DP = DP; a.eps = eps; a.ones_col = -1;
     return launch_ln_fwd(a, (hipStream_t)stream);
 }
 int v1t_layernorm_backward(const float* dz, const float* x, const float* mean, const float* rstd, const float* gamma,

@@ -45,6 +45,7 @@ struct LnFwdArgs {
     float* mean; float* rstd;  // [rows]
     int rows, T, D, DP;
     float eps;
+    int ones_col;        // >= D: z[:, ones_col] = 1 (bias-gradient column for the weight-gradient GEMM), < 0: none
 };
 int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s);
 

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
     for (int i = 0; i < NE; ++i) {
         const int c = lane + 64 * i;
         if (c < a.DP) {
-            const float z = (c < a.D) ? (v[i] - mean) * rstd * a.gamma[c] + a.beta[c] : 0.f;
+            const float z = (c < a.D) ? (v[i] - mean) * rstd * a.gamma[c] + a.beta[c] : (c == a.ones_col ? 1.f : 0.f);
             const bf16_t zh = (bf16_t)z;
             a.z[(size_t)row * a.DP + c] = zh;
             if (a.z_lo) a.z_lo[(size_t)row * a.DP + c] = (bf16_t)(z - (float)zh);

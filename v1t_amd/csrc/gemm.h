@@ -10,8 +10,12 @@ enum GemmEpi {
     EPI_BF16 = 0,       // C bf16 = acc
     EPI_F32 = 1,        // C fp32 = acc
     EPI_BIAS_RES = 2,   // C fp32 = res + dropout(acc + bias)                       (proj, FC2)
-    EPI_BIAS_GELU = 3,  // v = acc + bias; C bf16 = gelu'(v) (for the backward); C2 bf16 = dropout(gelu(v)) (FC1)
-    EPI_DGELU = 4,      // C bf16 = acc * mask/keep * aux (aux = saved gelu'); colsum += column sums  (dX of FC2)
+    EPI_BIAS_GELU = 3,  // v = acc + bias; C bf16 = gelu'(v) in ACCUMULATOR-FRAGMENT order (below); C2 bf16 = dropout(gelu(v)) (FC1)
+    EPI_DGELU = 4,      // C bf16 = acc * mask/keep * aux (aux = saved gelu', fragment order)          (dX of FC2)
+    // Fragment order: the 16 accumulator values a lane holds for one 32x32 block are stored contiguously,
+    // index (((tile_m * (N/32) + col_block) * 4 + wave) * 64 + lane) * 16 + reg. Producer (FC1) and consumer
+    // (dX of FC2) share M, N and the 128-row tile, so both sides move 2 x 16 B per lane per block instead of 16
+    // scattered 2-byte accesses (the 2-byte loads alone cost 34 us of that 86 us kernel).
 };
 
 struct GemmNTArgs {
@@ -31,6 +35,7 @@ struct GemmNTArgs {
     const bf16_t* aux; int ldaux;
     float* colsum; int n_valid;   // fp32 atomics, natural column index < n_valid
     DropCfg drop;
+    int dbg;  // ablation switches (env V1T_DBG_GEMM), 0 in production
 };
 
 struct GemmTNArgs {
@@ -42,6 +47,9 @@ struct GemmTNArgs {
     int xseg_pad, xseg_valid;
     int m_chunk;               // contraction rows per workgroup (multiple of 32)
     float alpha;
+    // bias gradient for free: if X carries a column of ones at padded index `ones_col` (the LayerNorm kernel
+    // writes it into a pad column), output column ones_col = column sums of Y -> atomicAdd into dbias
+    float* dbias; int ones_col;
 };
 
 int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s);

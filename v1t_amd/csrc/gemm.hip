@@ -5,6 +5,8 @@
 // by 16 B (80-B stride -> the 16 rows a ds_read_b128 lane group touches land on 16 distinct
 // 16-B slots), double-buffered LDS, next tile's global loads issued before the MFMAs and written
 // to the other buffer after them (one barrier per K-tile).
+#include <cstdlib>
+
 #include "gemm.h"
 
 namespace {
@@ -13,8 +15,12 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LS = BK + 8;  // LDS row stride in elements (80 B)
 
+DEVFN size_t frag_index(const GemmNTArgs& g, int m0, int n0, int nb, int wave, int lane) {
+    return ((((size_t)(m0 / BM) * (g.N / 32) + (n0 / 32 + nb)) * 4 + wave) * 64 + lane) * 16;
+}
+
 template <int NBLK, int EPI>
-DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], int m0, int n0, int wave, int lane) {
+DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 (&resv)[NBLK], int m0, int n0, int wave, int lane) {
     // ---- epilogue: col = n0 + 32nb + (lane&31); row = m0 + 32wave + acc_row(r, lane)
     const int rbase = m0 + 32 * wave;
 #pragma unroll
@@ -22,6 +28,12 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], int m0, int n
         const int col = n0 + 32 * nb + (lane & 31);
         float bias = 0.f;
         if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU) bias = g.bias ? g.bias[col] : 0.f;
+        bf16x8 gp0 = {}, gp1 = {};  // gelu' of this lane's 16 accumulator slots (fragment order)
+        if constexpr (EPI == EPI_DGELU) {
+            const bf16_t* fp = g.aux + frag_index(g, m0, n0, nb, wave, lane);
+            gp0 = *(const bf16x8*)fp;
+            gp1 = *(const bf16x8*)(fp + 8);
+        }
         float csum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -35,7 +47,7 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], int m0, int n
             } else if constexpr (EPI == EPI_BIAS_RES) {
                 v += bias;
                 if (g.drop.thresh) v = drop_keep(g.drop.key, row, col, g.drop.thresh) ? v * g.drop.inv_keep : 0.f;
-                if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = g.res[(size_t)row * g.ldres + col] + v;
+                if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = resv[nb][r] + v;
             } else if constexpr (EPI == EPI_BIAS_GELU) {
                 v += bias;
                 // gelu and gelu' share erf / exp: the backward only needs gelu'(v), stored in place of v
@@ -43,8 +55,8 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], int m0, int n
                 const float gp = cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
                 float a = v * cdf;
                 if (g.drop.thresh) a = drop_keep(g.drop.key, row, col, g.drop.thresh) ? a * g.drop.inv_keep : 0.f;
+                if (r < 8) gp0[r & 7] = (bf16_t)(ok ? gp : 0.f); else gp1[r & 7] = (bf16_t)(ok ? gp : 0.f);
                 if (ok) {
-                    ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = (bf16_t)gp;
                     const bf16_t ah = (bf16_t)a;
                     g.C2[(size_t)row * g.ldc2 + col] = ah;
                     if (g.C2_lo) g.C2_lo[(size_t)row * g.ldc2 + col] = (bf16_t)(a - (float)ah);
@@ -52,7 +64,7 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], int m0, int n
             } else if constexpr (EPI == EPI_DGELU) {
                 float d = 0.f;
                 if (ok) {
-                    d = v * (float)g.aux[(size_t)row * g.ldaux + col];  // aux = gelu'(pre-activation), saved by FC1
+                    d = v * (float)(r < 8 ? gp0[r & 7] : gp1[r & 7]);  // aux = gelu'(pre-activation), saved by FC1
                     if (g.drop.thresh) d = drop_keep(g.drop.key, row, col, g.drop.thresh) ? d * g.drop.inv_keep : 0.f;
                     const bf16_t db = (bf16_t)d;
                     ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = db;
@@ -62,8 +74,15 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], int m0, int n
             }
         }
         if constexpr (EPI == EPI_DGELU) {
-            csum += __shfl_xor(csum, 32);
-            if (g.colsum && lane < 32 && col < g.n_valid) atomicAdd(&g.colsum[col], csum);
+            if (g.colsum) {  // only when the weight-gradient GEMM cannot carry the bias column (no pad column)
+                csum += __shfl_xor(csum, 32);
+                if (lane < 32 && col < g.n_valid) atomicAdd(&g.colsum[col], csum);
+            }
+        }
+        if constexpr (EPI == EPI_BIAS_GELU) {
+            bf16_t* fp = (bf16_t*)g.C + frag_index(g, m0, n0, nb, wave, lane);
+            *(bf16x8*)fp = gp0;
+            *(bf16x8*)(fp + 8) = gp1;
         }
     }
 }
@@ -85,6 +104,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs g) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = g.K / BK;
 
+    // residual operand of the epilogue: its 16*NBLK narrow loads are issued HERE, in the prologue, so their
+    // latency hides under the K loop (issued in the epilogue they cost more than the MFMAs of these skinny GEMMs)
+    f32x16 resv[NBLK];
+    if constexpr (EPI == EPI_BIAS_RES) {
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * wave + acc_row(r, lane);
+                resv[nb][r] = (row < g.M) ? g.res[(size_t)row * g.ldres + n0 + 32 * nb + (lane & 31)] : 0.f;
+            }
+    }
     u32x4 ra[2], rb[B_ITERS];
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
@@ -139,7 +170,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs g) {
         __syncthreads();
     }
 
-    gemm_epilogue<NBLK, EPI>(g, acc, m0, n0, wave, lane);
+    gemm_epilogue<NBLK, EPI>(g, acc, resv, m0, n0, wave, lane);
 }
 
 
@@ -159,6 +190,18 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(GemmNTArgs g) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = g.K / BK;
 
+    // residual operand of the epilogue: its 16*NBLK narrow loads are issued HERE, in the prologue, so their
+    // latency hides under the K loop (issued in the epilogue they cost more than the MFMAs of these skinny GEMMs)
+    f32x16 resv[NBLK];
+    if constexpr (EPI == EPI_BIAS_RES) {
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * wave + acc_row(r, lane);
+                resv[nb][r] = (row < g.M) ? g.res[(size_t)row * g.ldres + n0 + 32 * nb + (lane & 31)] : 0.f;
+            }
+    }
     u32x4 ra[2][2], rb[2][B_ITERS];
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
@@ -221,7 +264,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(GemmNTArgs g) {
             }
         }
     }
-    gemm_epilogue<NBLK, EPI>(g, acc, m0, n0, wave, lane);
+    gemm_epilogue<NBLK, EPI>(g, acc, resv, m0, n0, wave, lane);
 }
 
 template <int NBLK>
@@ -336,20 +379,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs g) {
         const int xc = x0 + 32 * xb + (lane & 31);
         const int xs = xc / g.xseg_pad, xr = xc % g.xseg_pad;
         const bool xok = xr < g.xseg_valid;
+        const bool isb = g.dbias != nullptr && xc == g.ones_col;
         const int ncol = xs * g.xseg_valid + xr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int yr = n0 + 32 * wave + acc_row(r, lane);
             const int ys = yr / g.yseg_pad, yy = yr % g.yseg_pad;
-            if (xok && yr < g.NY && yy < g.yseg_valid)
-                atomicAdd(&g.dW[(size_t)(ys * g.yseg_valid + yy) * g.ldw + ncol], acc[xb][r] * g.alpha);
+            if (yr < g.NY && yy < g.yseg_valid) {
+                if (xok) atomicAdd(&g.dW[(size_t)(ys * g.yseg_valid + yy) * g.ldw + ncol], acc[xb][r] * g.alpha);
+                else if (isb) atomicAdd(&g.dbias[ys * g.yseg_valid + yy], acc[xb][r] * g.alpha);
+            }
         }
     }
 }
 
 }  // namespace
 
-int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s) {
+int launch_gemm_nt(const GemmNTArgs& a_, int epi, hipStream_t s) {
+    GemmNTArgs a = a_;
+    static const int dbg = std::getenv("V1T_DBG_GEMM") ? std::atoi(std::getenv("V1T_DBG_GEMM")) : 0;
+    a.dbg = dbg;
     if (a.K % BK != 0 || a.N % 32 != 0 || (a.lda % 8) || (a.ldb % 8)) return V1T_ERR_ARG;
     if (a.N % 160 == 0) return launch_nt_n<5>(a, epi, s);
     if (a.N % 128 == 0) return launch_nt_n<4>(a, epi, s);
