@@ -143,6 +143,20 @@ int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const
                            float dropout_p, uint64_t seed, uint32_t stream_id, float* delta_ws,
                            void* dqkv, float* dscale, void* stream);
 
+/* ------------------------------------------- attention rollout (utils/attention_rollout.py:92-133) */
+/* Head-max of the softmax probabilities of one block, recomputed from that block's saved qkv
+ * (B*T, 3*H*DP bf16) and log2-sum-exp (B,H,T) instead of the (B,H,T,T) tensors the reference's
+ * forward hooks clone (attention_rollout.py:28-36): A (B, T, TP) fp32 with TP = T rounded up to 4
+ * (= max over heads, attention_rollout.py:105), rowsum (B,T) = sum_j A[i][j] + 1 (the row sums of A + I,
+ * :109-111). */
+int v1t_rollout_headmax(const void* qkv, const float* lse2, int B, int H, int T, int DP,
+                        const float* scale, int scale_per_head, int mask_diag, float* A, int TP,
+                        float* rowsum, void* stream);
+/* One step of the rollout chain restricted to row 0 (only J[-1, 0, 1:] is used, :118):
+ * u = v . ((A + I) / rowsum); v == NULL means v = e_0 (first step = row 0 of the last block). */
+int v1t_rollout_vecmat(const float* A, const float* rowsum, const float* v, float* u, int B, int T,
+                       int TP, void* stream);
+
 /* Live kernel timing (bench.py roofline): when enabled, every launch of the selected kernel class is
  * bracketed by hipEvents on its own stream. class ids: 0 attention fwd, 1 attention bwd dQ,
  * 2 attention bwd dK/dV, 3 gemm_nt, 4 gemm_tn, 5 readout fwd, 6 readout bwd. */

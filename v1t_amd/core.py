@@ -320,8 +320,10 @@ class ViTCore(Core):
         a = self._arena
         return _L1Fn.apply(a, 0, a.param_floats, float(self.reg_scale), self._anchor)
 
-    def forward_tokens(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor) -> torch.Tensor:
-        """Token-major residual stream (B, T, DP) fp32 (CLS at t=0, columns >= emb_dim are zero)."""
+    def forward_tokens(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor,
+                       keep_workspace: bool = False) -> torch.Tensor:
+        """Token-major residual stream (B, T, DP) fp32 (CLS at t=0, columns >= emb_dim are zero).
+        keep_workspace: keep every block's activations (qkv, lse2, ...) even under no_grad (attention rollout)."""
         L.require_cuda(inputs, "ViTCore.forward")
         if inputs.requires_grad:
             raise NotImplementedError("gradient w.r.t. the core input (image shifter, shift_mode 1/3/4) has no gfx950 kernel yet")
@@ -336,7 +338,7 @@ class ViTCore(Core):
             beh = behaviors.to(torch.float32).contiguous()
         midx = self.mouse_ids.index(mouse_id) if self.behavior_mode == 4 else 0
         self._anchor.requires_grad_(any(p.requires_grad for p in (self.patch_embedding.cls_token,)) and not self.frozen)
-        need_bwd = torch.is_grad_enabled() and self._anchor.requires_grad
+        need_bwd = (torch.is_grad_enabled() and self._anchor.requires_grad) or keep_workspace
         return _VitFn.apply(self, inputs, beh, midx, self._anchor, need_bwd)
 
     def forward(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor):

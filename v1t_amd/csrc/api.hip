@@ -769,6 +769,19 @@ int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const
     return launch_attn_bwd(a, DP, (hipStream_t)stream);
 }
 
+int v1t_rollout_headmax(const void* qkv, const float* lse2, int B, int H, int T, int DP, const float* scale, int scale_per_head,
+                        int mask_diag, float* A, int TP, float* rowsum, void* stream) {
+    if (!qkv || !lse2 || !scale || !A || !rowsum || TP < T || TP % 4) return V1T_ERR_ARG;
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.lse2 = (float*)lse2; a.B = B; a.H = H; a.T = T;
+    a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
+    return launch_rollout_headmax(a, DP, A, TP, rowsum, (hipStream_t)stream);
+}
+int v1t_rollout_vecmat(const float* A, const float* rowsum, const float* v, float* u, int B, int T, int TP, void* stream) {
+    if (!A || !rowsum || !u || TP < T || TP % 4) return V1T_ERR_ARG;
+    return launch_rollout_vecmat(A, rowsum, v, u, B, T, TP, (hipStream_t)stream);
+}
+
 int v1t_layernorm_forward(const float* x, const float* inject, float* xout, const float* gamma, const float* beta, void* z,
                           float* mean, float* rstd, int B, int T, int D, int DP, float eps, void* stream) {
     LnFwdArgs a{};

@@ -26,3 +26,7 @@ struct AttnArgs {
 int launch_attn_fwd(const AttnArgs& a, int DP, hipStream_t s);
 int launch_attn_delta(const AttnArgs& a, int DP, float* delta, hipStream_t s);
 int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s);  // dq + dkv kernels
+
+// attention rollout building blocks (reference utils/attention_rollout.py:92-122)
+int launch_rollout_headmax(const AttnArgs& a, int DP, float* A, int TP, float* rowsum, hipStream_t s);
+int launch_rollout_vecmat(const float* A, const float* rowsum, const float* v, float* u, int B, int T, int TP, hipStream_t s);

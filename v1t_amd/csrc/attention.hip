@@ -678,6 +678,129 @@ int bwd_flags(const AttnArgs& a, hipStream_t s) {
     return diag ? launch_bwd_t<DP, false, true>(a, s) : launch_bwd_t<DP, false, false>(a, s);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Attention rollout support (reference utils/attention_rollout.py:92-122): A[b][i][j] = max over heads of
+// the softmax probabilities P_h[i][j] = exp2(S_h * c_h - lse2_h[i]) (recomputed from the saved q, k and
+// log2-sum-exp, never materialising the (B,H,T,T) tensor the reference's forward hooks stack), plus the row
+// sums rs[i] = sum_j A[i][j] + 1 of the identity-augmented matrix. One wave = 32 query rows, all heads' Q
+// fragments in registers (one wave per SIMD), K tiles of all heads staged by LDS-DMA.
+template <int DP, int HH>
+__global__ __launch_bounds__(256, 1) void rollout_headmax_kernel(AttnArgs a, float* A, int TP, float* rowsum) {
+    using G = Geo<DP>;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][HH][32 * G::RSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 128 + 32 * wave + (lane & 31);
+    const int h2 = lane >> 5;
+    const int HD = HH * DP;
+    const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
+    TileDma<DP, G::RSTR> dma;
+    dma.init(lane, wave);
+    const bool qok = q < a.T;
+    bf16x8 qf[HH][G::KS];
+    float cs[HH], nl[HH];
+#pragma unroll
+    for (int h = 0; h < HH; ++h) {
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            u32x4 t = qok ? *(const u32x4*)(qkv_b + (size_t)q * a.ldqkv + h * DP + 16 * ks + 8 * h2) : u32x4{0, 0, 0, 0};
+            qf[h][ks] = *(bf16x8*)&t;
+        }
+        cs[h] = a.scale[a.scale_per_head ? h : 0] * LOG2E;
+        nl[h] = -a.lse2[((size_t)b * HH + h) * a.T + (qok ? q : 0)];
+    }
+    const int koff = (lane & 31) * G::RSTR + 8 * h2;
+    const int nt = (a.T + 31) / 32;
+    float rs = 0.f;
+    auto stage = [&](int t, int buf) {
+#pragma unroll
+        for (int h = 0; h < HH; ++h) dma.issue(qkv_b + HD + h * DP, a.ldqkv, 32 * t, a.T, sK[buf][h]);
+    };
+    stage(0, 0);
+#pragma unroll
+    for (int h = 0; h < HH; ++h) {
+        touch(qf[h]);
+        touch(cs[h]);
+        touch(nl[h]);
+    }
+    dma_wait_and_barrier();
+    for (int kt = 0; kt < nt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nt) stage(kt + 1, buf ^ 1);
+        f32x16 amax;
+#pragma unroll
+        for (int h = 0; h < HH; ++h) {
+            f32x16 s;
+            zero16(s);
+            const bf16_t* kp = &sK[buf][h][koff];
+            bf16x8 kfr[G::KS];
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) kfr[ks] = *(const bf16x8*)(kp + 16 * ks);
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) s = mfma32(kfr[ks], qf[h][ks], s);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = fast_exp2(fmaf(s[r], cs[h], nl[h]));
+                amax[r] = (h == 0) ? p : fmaxf(amax[r], p);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int key0 = 32 * kt + 8 * g + 4 * h2;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = key0 + j;
+                const bool dead = key >= a.T || (a.mask_diag && key == q);
+                o[j] = dead ? 0.f : amax[4 * g + j];
+                rs += o[j];
+            }
+            if (qok && key0 < TP) *(f32x4*)(A + ((size_t)b * a.T + q) * TP + key0) = o;
+        }
+        dma_wait_and_barrier();
+    }
+    rs += __shfl_xor(rs, 32);
+    if (qok && h2 == 0) rowsum[(size_t)b * a.T + q] = rs + 1.0f;
+}
+
+// u[b][j] = sum_i w_i * (A[b][i][j] + delta_ij),  w_i = v[b][i] / rs[b][i]   (v == nullptr: v = e_0)
+__global__ __launch_bounds__(256) void rollout_vecmat_kernel(const float* A, const float* rowsum, const float* v, float* u, int T, int TP) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < T; i += 256) {
+        const float vi = v ? v[(size_t)b * T + i] : (i == 0 ? 1.f : 0.f);
+        sw[i] = vi / rowsum[(size_t)b * T + i];
+    }
+    __syncthreads();
+    const int j0 = 4 * (blockIdx.x * 256 + threadIdx.x);
+    if (j0 >= TP) return;
+    const float* Ab = A + (size_t)b * T * TP + j0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int iend = v ? T : 1;  // e_0 picks row 0 only
+    for (int i = 0; i < iend; ++i) {
+        const f32x4 x = *(const f32x4*)(Ab + (size_t)i * TP);
+        const float w = sw[i];
+        acc[0] += w * x[0]; acc[1] += w * x[1]; acc[2] += w * x[2]; acc[3] += w * x[3];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j0 + j < T) u[(size_t)b * T + j0 + j] = acc[j] + sw[j0 + j];
+}
+
+template <int DP>
+int launch_headmax_t(const AttnArgs& a, float* A, int TP, float* rowsum, hipStream_t s) {
+    dim3 grid((a.T + 127) / 128, a.B);
+    switch (a.H) {
+        case 1: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 1>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;
+        case 2: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 2>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;
+        case 3: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 3>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;
+        case 4: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 4>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;
+        default: return V1T_ERR_UNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+
 }  // namespace
 
 #define DP_DISPATCH(FN, ...)                           \
@@ -693,3 +816,13 @@ int bwd_flags(const AttnArgs& a, hipStream_t s) {
 int launch_attn_fwd(const AttnArgs& a, int DP, hipStream_t s) { DP_DISPATCH(fwd_flags, a, s) }
 int launch_attn_delta(const AttnArgs& a, int DP, float* delta, hipStream_t s) { DP_DISPATCH(launch_delta_t, a, delta, s) }
 int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s) { DP_DISPATCH(bwd_flags, a, s) }
+
+int launch_rollout_headmax(const AttnArgs& a, int DP, float* A, int TP, float* rowsum, hipStream_t s) {
+    if (a.H * (DP > 96 ? 4 : 2) > 16) return V1T_ERR_UNSUPPORTED;  // Q fragments of all heads must fit the register file
+    DP_DISPATCH(launch_headmax_t, a, A, TP, rowsum, s)
+}
+int launch_rollout_vecmat(const float* A, const float* rowsum, const float* v, float* u, int B, int T, int TP, hipStream_t s) {
+    dim3 grid((TP / 4 + 255) / 256, B);
+    hipLaunchKernelGGL(rollout_vecmat_kernel, grid, dim3(256), sizeof(float) * T, s, A, rowsum, v, u, T, TP);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}

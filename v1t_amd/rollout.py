@@ -1,0 +1,98 @@
+"""Attention rollout on the native path (reference src/v1t/utils/attention_rollout.py).
+
+The reference records every block's softmax output with forward hooks — a (B, blocks, heads, T, T) fp32
+tensor, 175 MB per image at the default size (attention_rollout.py:28-36, 76) — then, per sample, takes the
+max over heads, adds the identity, row-normalises, multiplies the L matrices together and keeps row 0 of the
+product without the CLS column (:92-118), min-max normalises it and resizes it to the image (:119-121).
+
+Here the fused attention never materialises P. After one eval forward that keeps each block's q/k and
+log2-sum-exp, the head-max matrix of ONE block at a time is recomputed on the MFMAs
+(`v1t_rollout_headmax`, (B, T, T) fp32), and because only row 0 of the product is used, the chain is run as
+a row-vector chain from the last block down, `v <- v . (A_k + I) / rowsum` (`v1t_rollout_vecmat`): 3*2*T^2
+instead of 3*2*T^3 flops per image, mathematically identical (matrix products are associative; the fp32
+re-association difference is ~1e-9).
+"""
+from __future__ import annotations
+
+import typing as t
+
+import torch
+from torch.nn import functional as F
+
+from . import lib as L
+from .core import ViTCore, find_shape
+
+
+@torch.no_grad()
+def rollout_rows(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, pupil_centers: torch.Tensor, mouse_id: str,
+                 return_headmax: bool = False):
+    """images: CORE input (B, C, H, W) (post image-cropper). Returns the pre-normalisation heat vector
+    J_last[0, 1:] (B, T-1) of attention_rollout.py:118 (and optionally the list of head-max matrices)."""
+    was_training = core.training
+    core.train(False)
+    try:
+        tokens = core.forward_tokens(images, mouse_id, behaviors, pupil_centers, keep_workspace=True)
+    finally:
+        core.train(was_training)
+    lib = L.load()
+    B, T = tokens.shape[0], core.num_tokens
+    TP = (T + 3) // 4 * 4
+    cfg = core._cfg
+    H, DP = cfg.num_heads, core.padded_dim
+    dev = tokens.device
+    A = torch.empty((B, T, TP), dtype=torch.float32, device=dev)
+    rowsum = torch.empty((B, T), dtype=torch.float32, device=dev)
+    v: t.Optional[torch.Tensor] = None
+    maps = []
+    nqkv, nlse = B * T * 3 * H * DP * 2, B * H * T * 4
+    for k in reversed(range(cfg.num_blocks)):
+        qkv = core.workspace_tensor("qkv", k)[:nqkv]
+        lse2 = core.workspace_tensor("lse2", k)[:nlse]
+        scale = core.transformer.blocks[k]["mha"].scale
+        L.check(lib.v1t_rollout_headmax(qkv.data_ptr(), lse2.data_ptr(), B, H, T, DP, scale.data_ptr(), int(cfg.use_lsa), int(cfg.use_lsa),
+                                        A.data_ptr(), TP, rowsum.data_ptr(), L.stream()), "rollout_headmax")
+        u = torch.empty((B, T), dtype=torch.float32, device=dev)
+        L.check(lib.v1t_rollout_vecmat(A.data_ptr(), rowsum.data_ptr(), L.ptr(v), u.data_ptr(), B, T, TP, L.stream()), "rollout_vecmat")
+        v = u
+        if return_headmax:
+            maps.append(A[:, :, :T].clone())
+    rows = v[:, 1:]
+    return (rows, maps[::-1]) if return_headmax else rows
+
+
+@torch.no_grad()
+def attention_rollouts(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, pupil_centers: torch.Tensor, mouse_id: str) -> torch.Tensor:
+    """Heat-maps (B, H, W) like reference `attention_rollouts` (attention_rollout.py:125-133) applied to the
+    recorder output of `core` on `images`."""
+    rows = rollout_rows(core, images, behaviors, pupil_centers, mouse_id)
+    B = rows.shape[0]
+    h, w = find_shape(rows.shape[1])
+    heat = rows.reshape(B, h, w)
+    lo = heat.amin(dim=(1, 2), keepdim=True)
+    hi = heat.amax(dim=(1, 2), keepdim=True)
+    heat = (heat - lo) / (hi - lo)
+    return F.interpolate(heat[:, None], size=tuple(images.shape[2:]), mode="bilinear", align_corners=False, antialias=False)[:, 0]
+
+
+@torch.no_grad()
+def extract_attention_maps(model, batches: t.Iterable[t.Dict[str, torch.Tensor]], mouse_id: str, num_samples: t.Optional[int] = None) -> t.Dict[str, torch.Tensor]:
+    """Counterpart of reference `extract_attention_maps` (attention_rollout.py:136-201) over an iterable of
+    batches (image, behavior, pupil_center) that are already on the model's device; the dataset's inverse
+    transforms of the reference are the caller's business here."""
+    model.train(False)
+    out = {"images": [], "heatmaps": [], "pupil_centers": [], "behaviors": []}
+    count = 0
+    for b in batches:
+        images, _ = model.image_cropper(b["image"], mouse_id=mouse_id, behaviors=b["behavior"], pupil_centers=b["pupil_center"])
+        heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], mouse_id)
+        out["images"].append(images)
+        out["heatmaps"].append(heat)
+        out["behaviors"].append(b["behavior"])
+        out["pupil_centers"].append(b["pupil_center"])
+        count += images.shape[0]
+        if num_samples is not None and count >= num_samples:
+            break
+    res = {k: torch.cat(v) for k, v in out.items()}
+    if num_samples is not None:
+        res = {k: v[:num_samples] for k, v in res.items()}
+    return res
