@@ -113,6 +113,27 @@ int v1t_gaussian2d_backward(const float* z, long long zsb, long long zsc, int B,
                             float* dz, long long dzsb, long long dzsc, float* dgrid, float* dfeat,
                             float* dbias, void* stream);
 
+/* Readout sample positions (gaussian2d.py:188-235, 265-268): mu from the grid predictor
+ * (Linear(gd,30) -> ELU -> Linear(30,2) -> tanh on the normalised cortical coordinates src (N,gd); gd == 0:
+ * free parameter mu_free (N,2)), grid[b][n] = clamp(sigma_n . eps[b][n] + mu_n, -1, 1) + shift[b].
+ * eps NULL = eval (grid = clamp(mu)); shift NULL = no shifter. */
+int v1t_readout_grid_forward(int B, int N, int gd, const float* src, const float* W0, const float* b0,
+                             const float* W2, const float* b2, const float* mu_free, const float* sigma,
+                             const float* eps, const float* shift, float* grid, void* stream);
+/* dgrid (B,N,2) -> dW0 (30,gd), db0 (30), dW2 (2,30), db2 (2) (+= via atomics, zero them first),
+ * dmu_free (N,2) / dsigma (N,2,2) overwritten, dshift (B,2) += (zero it first). NULL outputs are skipped. */
+int v1t_readout_grid_backward(int B, int N, int gd, const float* src, const float* W0, const float* b0,
+                              const float* W2, const float* b2, const float* mu_free, const float* sigma,
+                              const float* eps, const float* dgrid, float* dW0, float* db0, float* dW2,
+                              float* db2, float* dmu_free, float* dsigma, float* dshift, void* stream);
+/* CoreShifter MLP 2->5->5->2, tanh after every layer (core_shifter.py:24-40; model.py:86-92) */
+int v1t_core_shifter_forward(int B, const float* pupil, const float* W0, const float* b0, const float* W2,
+                             const float* b2, const float* W4, const float* b4, float* shift, void* stream);
+int v1t_core_shifter_backward(int B, const float* pupil, const float* W0, const float* b0, const float* W2,
+                              const float* b2, const float* W4, const float* b4, const float* dshift,
+                              float* dW0, float* db0, float* dW2, float* db2, float* dW4, float* db4,
+                              void* stream);
+
 /* ELU1 (models/utils.py:109-118) + PoissonLoss (losses.py:153-166, scale_ds :114-119).
  * yhat/du/loss may be NULL; y may be NULL (inference: only yhat). loss is += (zero it first). */
 int v1t_elu1_poisson(const float* u, const float* y, long long n, float loss_scale, float gscale,

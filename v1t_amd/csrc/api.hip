@@ -12,6 +12,7 @@
 #include "attention.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "gridprep.h"
 #include "readout.h"
 
 namespace {
@@ -715,6 +716,40 @@ int v1t_gaussian2d_backward(const float* z, long long zsb, long long zsc, int B,
     a.z = z; a.zsb = zsb; a.zsc = zsc; a.B = B; a.C = C; a.H = H; a.W = W; a.N = N; a.grid = grid; a.feat = feat; a.FS = FS;
     a.gout = gout; a.dz = dz; a.dzsb = dzsb; a.dzsc = dzsc; a.dgrid = dgrid; a.dfeat = dfeat; a.dbias = dbias;
     return launch_readout_bwd(a, (hipStream_t)stream);
+}
+
+int v1t_readout_grid_forward(int B, int N, int gd, const float* src, const float* W0, const float* b0, const float* W2, const float* b2,
+                             const float* mu_free, const float* sigma, const float* eps, const float* shift, float* grid, void* stream) {
+    if (!sigma || !grid || (gd > 0 && (!src || !W0 || !b0 || !W2 || !b2)) || (gd == 0 && !mu_free)) return V1T_ERR_ARG;
+    GridArgs a{};
+    a.B = B; a.N = N; a.gd = gd; a.src = src; a.W0 = W0; a.b0 = b0; a.W2 = W2; a.b2 = b2; a.mu_free = mu_free; a.sigma = sigma;
+    a.eps = eps; a.shift = shift; a.grid = grid;
+    return launch_grid_fwd(a, (hipStream_t)stream);
+}
+int v1t_readout_grid_backward(int B, int N, int gd, const float* src, const float* W0, const float* b0, const float* W2, const float* b2,
+                              const float* mu_free, const float* sigma, const float* eps, const float* dgrid, float* dW0, float* db0,
+                              float* dW2, float* db2, float* dmu_free, float* dsigma, float* dshift, void* stream) {
+    if (!sigma || !dgrid || (gd > 0 && (!src || !W0 || !b0 || !W2 || !b2 || !dW0 || !db0 || !dW2 || !db2)) || (gd == 0 && !mu_free)) return V1T_ERR_ARG;
+    GridArgs a{};
+    a.B = B; a.N = N; a.gd = gd; a.src = src; a.W0 = W0; a.b0 = b0; a.W2 = W2; a.b2 = b2; a.mu_free = mu_free; a.sigma = sigma;
+    a.eps = eps; a.dgrid = dgrid; a.dW0 = dW0; a.db0 = db0; a.dW2 = dW2; a.db2 = db2; a.dmu_free = dmu_free; a.dsigma = dsigma; a.dshift = dshift;
+    return launch_grid_bwd(a, (hipStream_t)stream);
+}
+int v1t_core_shifter_forward(int B, const float* pupil, const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
+                             const float* b4, float* shift, void* stream) {
+    if (!pupil || !W0 || !b0 || !W2 || !b2 || !W4 || !b4 || !shift) return V1T_ERR_ARG;
+    ShifterArgs a{};
+    a.B = B; a.pupil = pupil; a.W0 = W0; a.b0 = b0; a.W2 = W2; a.b2 = b2; a.W4 = W4; a.b4 = b4; a.shift = shift;
+    return launch_shifter_fwd(a, (hipStream_t)stream);
+}
+int v1t_core_shifter_backward(int B, const float* pupil, const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
+                              const float* b4, const float* dshift, float* dW0, float* db0, float* dW2, float* db2, float* dW4, float* db4,
+                              void* stream) {
+    if (!pupil || !W0 || !b0 || !W2 || !b2 || !W4 || !b4 || !dshift || !dW0 || !db0 || !dW2 || !db2 || !dW4 || !db4) return V1T_ERR_ARG;
+    ShifterArgs a{};
+    a.B = B; a.pupil = pupil; a.W0 = W0; a.b0 = b0; a.W2 = W2; a.b2 = b2; a.W4 = W4; a.b4 = b4; a.dshift = dshift;
+    a.dW0 = dW0; a.db0 = db0; a.dW2 = dW2; a.db2 = db2; a.dW4 = dW4; a.db4 = db4;
+    return launch_shifter_bwd(a, (hipStream_t)stream);
 }
 
 int v1t_elu1_poisson(const float* u, const float* y, long long n, float loss_scale, float gscale, float* yhat, float* du,

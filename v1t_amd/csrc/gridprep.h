@@ -1,0 +1,43 @@
+// v1t_amd — O(N) bookkeeping around the readout sample positions, fused into four small kernels:
+//   readout grid:  mu_n = tanh(W2 . ELU(W0 . src_n + b0) + b2)  (or the free parameter _mu),
+//                  grid[b][n] = clamp(sigma_n . eps[b][n] + mu_n, -1, 1) + shift[b]
+//                  (reference gaussian2d.py:188-235, 265-268, init_grid_predictor :113-131) and its backward;
+//   core shifter:  shift[b] = tanh(W4 . tanh(W2 . tanh(W0 . pupil[b] + b0) + b2) + b4)
+//                  (reference core_shifter.py:24-40 with num_layers = 3, model.py:86-92) and its backward.
+#pragma once
+#include "common.h"
+
+constexpr int GRID_HID = 30;  // hidden width of the grid predictor (gaussian2d.py:105)
+
+struct GridArgs {
+    int B, N, gd;             // gd = grid_predictor_dim (2 or 3); gd == 0: free parameter mu_free
+    const float* src;         // (N, gd) normalised cortical coordinates
+    const float* W0; const float* b0;  // (30, gd), (30)
+    const float* W2; const float* b2;  // (2, 30), (2)
+    const float* mu_free;     // (N, 2) when gd == 0
+    const float* sigma;       // (N, 2, 2)
+    const float* eps;         // (B, N, 2) or nullptr (eval: grid = clamp(mu))
+    const float* shift;       // (B, 2) or nullptr
+    float* grid;              // (B, N, 2) out
+    // backward
+    const float* dgrid;       // (B, N, 2)
+    float* dW0; float* db0; float* dW2; float* db2;  // atomics (zero-initialised by the caller)
+    float* dmu_free;          // (N, 2) overwritten (gd == 0)
+    float* dsigma;            // (N, 2, 2) overwritten, or nullptr
+    float* dshift;            // (B, 2) atomics (zero-initialised), or nullptr
+};
+int launch_grid_fwd(const GridArgs& a, hipStream_t s);
+int launch_grid_bwd(const GridArgs& a, hipStream_t s);
+
+struct ShifterArgs {
+    int B;
+    const float* pupil;       // (B, 2)
+    const float* W0; const float* b0;  // (5, 2), (5)
+    const float* W2; const float* b2;  // (5, 5), (5)
+    const float* W4; const float* b4;  // (2, 5), (2)
+    float* shift;             // (B, 2) out
+    const float* dshift;      // (B, 2)
+    float* dW0; float* db0; float* dW2; float* db2; float* dW4; float* db4;  // overwritten
+};
+int launch_shifter_fwd(const ShifterArgs& a, hipStream_t s);
+int launch_shifter_bwd(const ShifterArgs& a, hipStream_t s);

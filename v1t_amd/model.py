@@ -47,6 +47,29 @@ class _Elu1Fn(torch.autograd.Function):
         return g * torch.where(u > 0, torch.ones_like(u), y)  # d/du (elu(u)+1) = 1 | exp(u) = y (u<=0)
 
 
+class _ShifterFn(torch.autograd.Function):
+    """2 -> 5 -> 5 -> 2 tanh MLP (core_shifter.py:24-40) as one HIP kernel forward / one backward."""
+
+    @staticmethod
+    def forward(ctx, pupil, W0, b0, W2, b2, W4, b4):
+        B = pupil.shape[0]
+        out = torch.empty((B, 2), dtype=torch.float32, device=pupil.device)
+        L.check(L.load().v1t_core_shifter_forward(B, pupil.data_ptr(), W0.data_ptr(), b0.data_ptr(), W2.data_ptr(), b2.data_ptr(), W4.data_ptr(),
+                                                  b4.data_ptr(), out.data_ptr(), L.stream()), "core_shifter_forward")
+        ctx.save_for_backward(pupil, W0, b0, W2, b2, W4, b4)
+        return out
+
+    @staticmethod
+    def backward(ctx, dshift):
+        pupil, W0, b0, W2, b2, W4, b4 = ctx.saved_tensors
+        g = [torch.empty_like(t_) for t_ in (W0, b0, W2, b2, W4, b4)]
+        dshift = dshift.contiguous()
+        L.check(L.load().v1t_core_shifter_backward(pupil.shape[0], pupil.data_ptr(), W0.data_ptr(), b0.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+                                                   W4.data_ptr(), b4.data_ptr(), dshift.data_ptr(), *[x.data_ptr() for x in g], L.stream()),
+                "core_shifter_backward")
+        return (None, *g)
+
+
 class CoreShifter(nn.Module):
     """reference core_shifter.py:7-40"""
 
@@ -66,6 +89,9 @@ class CoreShifter(nn.Module):
         return self.reg_scale * sum(p.abs().sum() for p in self.parameters())
 
     def forward(self, pupil_center: torch.Tensor):
+        if pupil_center.is_cuda and len(self.mlp) == 6:
+            m = self.mlp
+            return _ShifterFn.apply(pupil_center.to(torch.float32).contiguous(), m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
         return self.mlp(pupil_center)
 
 

@@ -123,6 +123,40 @@ class _Gaussian2dFn(torch.autograd.Function):
         return dz, dgrid, dfeat, dbias, None, None
 
 
+class _GridFn(torch.autograd.Function):
+    """grid[b][n] = clamp(sigma_n . eps[b][n] + mu_n, -1, 1) + shift[b] with mu from the grid predictor (or the
+    free parameter) — one HIP kernel forward, one backward (v1t_readout_grid_forward/backward)."""
+
+    @staticmethod
+    def forward(ctx, B, src, W0, b0, W2, b2, mu_free, sigma, eps, shift):
+        N = sigma.shape[1]
+        gd = 0 if src is None else src.shape[1]
+        grid = torch.empty((B, N, 2), dtype=torch.float32, device=sigma.device)
+        eps = None if eps is None else eps.contiguous()
+        shift = None if shift is None else shift.contiguous()
+        L.check(L.load().v1t_readout_grid_forward(B, N, gd, L.ptr(src), L.ptr(W0), L.ptr(b0), L.ptr(W2), L.ptr(b2), L.ptr(mu_free), sigma.data_ptr(),
+                                                  L.ptr(eps), L.ptr(shift), grid.data_ptr(), L.stream()), "readout_grid_forward")
+        ctx.save_for_backward(src, W0, b0, W2, b2, mu_free, sigma, eps, shift)
+        ctx.B = B
+        return grid
+
+    @staticmethod
+    def backward(ctx, dgrid):
+        src, W0, b0, W2, b2, mu_free, sigma, eps, shift = ctx.saved_tensors
+        B, N = ctx.B, sigma.shape[1]
+        gd = 0 if src is None else src.shape[1]
+        dgrid = dgrid.contiguous()
+        z = lambda t: None if t is None else torch.zeros_like(t)
+        dW0, db0, dW2, db2 = z(W0), z(b0), z(W2), z(b2)
+        dmu = None if mu_free is None else torch.empty_like(mu_free)
+        dsigma = torch.empty_like(sigma) if eps is not None else torch.zeros_like(sigma)
+        dshift = z(shift)
+        L.check(L.load().v1t_readout_grid_backward(B, N, gd, L.ptr(src), L.ptr(W0), L.ptr(b0), L.ptr(W2), L.ptr(b2), L.ptr(mu_free), sigma.data_ptr(),
+                                                   L.ptr(eps), dgrid.data_ptr(), L.ptr(dW0), L.ptr(db0), L.ptr(dW2), L.ptr(db2), L.ptr(dmu),
+                                                   dsigma.data_ptr() if eps is not None else None, L.ptr(dshift), L.stream()), "readout_grid_backward")
+        return None, None, dW0, db0, dW2, db2, dmu, dsigma, None, dshift
+
+
 @register("gaussian2d")
 class Gaussian2DReadout(Readout):
     """MI355X-native drop-in for the reference Gaussian2DReadout (gaussian2d.py:13-278), full gaussian."""
@@ -234,14 +268,25 @@ class Gaussian2DReadout(Readout):
             return mu.clamp(min=-1, max=1).expand(batch_size, -1, -1, -1)
         return torch.clamp(torch.einsum("ancd,bnid->bnic", self.sigma, norm) + mu, min=-1, max=1)
 
+    def _grid(self, B: int, sample: t.Optional[bool], eps: t.Optional[torch.Tensor], shifts: t.Optional[torch.Tensor]) -> torch.Tensor:
+        """(B, N, 2) sample positions incl. shifts, through the fused HIP grid kernel."""
+        sample = self.training if sample is None else sample
+        if eps is not None:
+            eps = eps.reshape(B, self.num_neurons, 2).to(torch.float32)
+        elif sample:
+            eps = torch.empty(B, self.num_neurons, 2, dtype=torch.float32, device=self.sigma.device).normal_()
+        if self._predicted_grid:
+            l0, l2 = self.mu_transform[0], self.mu_transform[2]
+            return _GridFn.apply(B, self.source_grid, l0.weight, l0.bias, l2.weight, l2.bias, None, self.sigma, eps, shifts)
+        with torch.no_grad():
+            self._mu.clamp_(min=-1, max=1)  # gaussian2d.py:212-215 (acts on the free parameter only)
+        return _GridFn.apply(B, None, None, None, None, None, self._mu, self.sigma, eps, shifts)
+
     def forward(self, inputs: torch.Tensor, sample: t.Optional[bool] = None, shifts: t.Optional[torch.Tensor] = None, eps: t.Optional[torch.Tensor] = None):
         L.require_cuda(inputs, "Gaussian2DReadout.forward")
         B, c, h, w = inputs.shape
         n = self.num_neurons
-        grid = self.sample_grid(batch_size=B, sample=sample, eps=eps)
-        if shifts is not None:
-            grid = grid + shifts[:, None, None, :]
-        grid = grid.reshape(B, n, 2).to(torch.float32)
+        grid = self._grid(B, sample, eps, shifts)
         tokens = getattr(inputs, "_v1t_tokens", None)
         if tokens is not None and tokens.shape[0] == B:
             T, DP = tokens.shape[1], tokens.shape[2]
