@@ -370,70 +370,93 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
     const int toff = tr_lane_off(lane, G::RSTR);
     const int nt = (a.T + TR - 1) / TR;
 
-    auto tile = [&](auto tail_tag, int kt, int buf) {
+    auto phase1 = [&](f32x16& s, f32x16& dp, int hf, int buf) {
+        zero16(s);
+        zero16(dp);
+        const bf16_t* kp = &sK[buf][32 * hf * G::RSTR + koff];
+        const bf16_t* vp = &sV[buf][32 * hf * G::RSTR + koff];
+        bf16x8 kfr[G::KS], vfr[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) kfr[ks] = *(const bf16x8*)(kp + 16 * ks);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) vfr[ks] = *(const bf16x8*)(vp + 16 * ks);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) s = mfma32(kfr[ks], qf[ks], s);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) dp = mfma32(vfr[ks], dof[ks], dp);
+    };
+    // element-wise stage of one 32-key half: S^T, dP^T -> dS'^T (in s)
+    auto softmax_half = [&](auto tail_tag, f32x16& s, const f32x16& dp, int kt, int hf) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        f32x16 s[2], dp[2];
-        // phase 1 of both halves: S^T = K.Q^T and dP^T = V.dO^T
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            zero16(s[hf]);
-            zero16(dp[hf]);
-            const bf16_t* kp = &sK[buf][32 * hf * G::RSTR + koff];
-            const bf16_t* vp = &sV[buf][32 * hf * G::RSTR + koff];
-            bf16x8 kfr[G::KS], vfr[G::KS];
+        for (int g = 0; g < 4; ++g) {
+            bool keep[4] = {true, true, true, true};
+            if constexpr (DROP)
+                drop4(dbase + (uint32_t)(32 * kt + 16 * hf + 4 * g) * ADROP_K2, ADROP_K2, sh_even, sh_odd, a.adrop.thresh8, keep);
 #pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) kfr[ks] = *(const bf16x8*)(kp + 16 * ks);
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) vfr[ks] = *(const bf16x8*)(vp + 16 * ks);
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) s[hf] = mfma32(kfr[ks], qf[ks], s[hf]);
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) dp[hf] = mfma32(vfr[ks], dof[ks], dp[hf]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * G::KS, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const bf16_t* tp = &sK[buf][32 * hf * G::RSTR + toff];
-            bf16x8 tfr[2 * G::DB];
-#pragma unroll
-            for (int d = 0; d < G::DB; ++d) {
-                tfr[2 * d] = tr_frag<G::RSTR>(tp, 0, 32 * d);
-                tfr[2 * d + 1] = tr_frag<G::RSTR>(tp, 16, 32 * d);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bool keep[4] = {true, true, true, true};
-                if constexpr (DROP)
-                    drop4(dbase + (uint32_t)(32 * kt + 16 * hf + 4 * g) * ADROP_K2, ADROP_K2, sh_even, sh_odd, a.adrop.thresh8, keep);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g + j;
-                    float p = fast_exp2(fmaf(s[hf][r], c, neglse));
-                    if constexpr (TAIL || DIAG) {
-                        const int key = TR * kt + 32 * hf + acc_row(r, lane);
-                        bool dead = false;
-                        if constexpr (TAIL) dead = key >= a.T;
-                        if constexpr (DIAG) dead = dead || key == q;
-                        p = dead ? 0.f : p;
-                    }
-                    const float gg = keep[j] ? dp[hf][r] : 0.f;
-                    const float ds = p * (gg - dl);
-                    if constexpr (DIAG) dsc = fmaf(ds, s[hf][r], dsc);
-                    s[hf][r] = ds;
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                float p = fast_exp2(fmaf(s[r], c, neglse));
+                if constexpr (TAIL || DIAG) {
+                    const int key = TR * kt + 32 * hf + acc_row(r, lane);
+                    bool dead = false;
+                    if constexpr (TAIL) dead = key >= a.T;
+                    if constexpr (DIAG) dead = dead || key == q;
+                    p = dead ? 0.f : p;
                 }
+                const float gg = keep[j] ? dp[r] : 0.f;
+                const float ds = p * (gg - dl);
+                if constexpr (DIAG) dsc = fmaf(ds, s[r], dsc);
+                s[r] = ds;
             }
-            const bf16x8 b0 = acc_to_b(s[hf], 0), b1 = acc_to_b(s[hf], 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int d = 0; d < G::DB; ++d) {
-                dq[d] = mfma32(tfr[2 * d], b0, dq[d]);
-                dq[d] = mfma32(tfr[2 * d + 1], b1, dq[d]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto tr_load = [&](bf16x8 (&tfr)[2 * G::DB], int hf, int buf) {
+        const bf16_t* tp = &sK[buf][32 * hf * G::RSTR + toff];
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) {
+            tfr[2 * d] = tr_frag<G::RSTR>(tp, 0, 32 * d);
+            tfr[2 * d + 1] = tr_frag<G::RSTR>(tp, 16, 32 * d);
+        }
+    };
+    auto phase3 = [&](const bf16x8 (&tfr)[2 * G::DB], const f32x16& s) {
+        const bf16x8 b0 = acc_to_b(s, 0), b1 = acc_to_b(s, 1);
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) {
+            dq[d] = mfma32(tfr[2 * d], b0, dq[d]);
+            dq[d] = mfma32(tfr[2 * d + 1], b1, dq[d]);
+        }
+    };
+    // same MFMA / VALU interleave as the dK/dV kernel (see there)
+    auto tile = [&](auto tail_tag, int kt, int buf) {
+        f32x16 s0, dp0, s1, dp1;
+        bf16x8 tfr[2 * G::DB];
+        phase1(s0, dp0, 0, buf);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * G::KS, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        phase1(s1, dp1, 1, buf);
+        softmax_half(tail_tag, s0, dp0, kt, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 1);
+#pragma unroll
+        for (int i = 0; i < 2 * G::KS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        tr_load(tfr, 0, buf);
+        phase3(tfr, s0);
+        softmax_half(tail_tag, s1, dp1, kt, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * G::DB, 2);
+#pragma unroll
+        for (int i = 0; i < 2 * G::DB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+            __builtin_amdgcn_sched_group_barrier(0x002, 16, 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        tr_load(tfr, 1, buf);
+        phase3(tfr, s1);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     dma.issue(kbase, a.ldqkv, 0, a.T, sK[0]);
@@ -533,77 +556,119 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (wave == 0) lds_dma4(lbase + qq, sL[buf]);
         if (wave == 1) lds_dma4(dbase_ + qq, sDl[buf]);
     };
-    auto tile = [&](auto tail_tag, int qt, int buf) {
+    // element-wise stage of one 32-query half: S, dP accumulators -> dropped P (dp) and dS' (s), in place
+    auto softmax_half = [&](auto tail_tag, f32x16& s, f32x16& dp, int qt, int hf, int buf) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        f32x16 s[2], dp[2];
-        // phase 1 of both halves: S = Q.K^T and dP = dO.V^T (rows = queries, column = this lane's key)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            zero16(s[hf]);
-            zero16(dp[hf]);
-            const bf16_t* qp = &sQ[buf][32 * hf * G::RSTR + roff];
-            const bf16_t* dop = &sD[buf][32 * hf * G::RSTR + roff];
-            bf16x8 qfr[G::KS], dfr[G::KS];
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 nl = *(const f32x4*)(&sL[buf][32 * hf + 8 * g + 4 * h2]);
+            const f32x4 dl = *(const f32x4*)(&sDl[buf][32 * hf + 8 * g + 4 * h2]);
+            bool keep[4] = {true, true, true, true};
+            if constexpr (DROP)
+                drop4(dbase + (uint32_t)(32 * qt + 16 * hf + 4 * g) * ADROP_K1, ADROP_K1, sh_even, sh_odd, a.adrop.thresh8, keep);
 #pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) qfr[ks] = *(const bf16x8*)(qp + 16 * ks);
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) dfr[ks] = *(const bf16x8*)(dop + 16 * ks);
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) s[hf] = mfma32(qfr[ks], kf[ks], s[hf]);
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) dp[hf] = mfma32(dfr[ks], vf[ks], dp[hf]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * G::KS, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const bf16_t* tq = &sQ[buf][32 * hf * G::RSTR + toff];
-            const bf16_t* td = &sD[buf][32 * hf * G::RSTR + toff];
-            bf16x8 tdf[2 * G::DB], tqf[2 * G::DB];
-#pragma unroll
-            for (int d = 0; d < G::DB; ++d) {
-                tdf[2 * d] = tr_frag<G::RSTR>(td, 0, 32 * d);
-                tdf[2 * d + 1] = tr_frag<G::RSTR>(td, 16, 32 * d);
-                tqf[2 * d] = tr_frag<G::RSTR>(tq, 0, 32 * d);
-                tqf[2 * d + 1] = tr_frag<G::RSTR>(tq, 16, 32 * d);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 nl = *(const f32x4*)(&sL[buf][32 * hf + 8 * g + 4 * h2]);
-                const f32x4 dl = *(const f32x4*)(&sDl[buf][32 * hf + 8 * g + 4 * h2]);
-                bool keep[4] = {true, true, true, true};
-                if constexpr (DROP)
-                    drop4(dbase + (uint32_t)(32 * qt + 16 * hf + 4 * g) * ADROP_K1, ADROP_K1, sh_even, sh_odd, a.adrop.thresh8, keep);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g + j;
-                    float p = fast_exp2(fmaf(s[hf][r], c, -nl[j]));
-                    if constexpr (TAIL || DIAG) {
-                        const int qq = TR * qt + 32 * hf + acc_row(r, lane);
-                        bool dead = false;
-                        if constexpr (TAIL) dead = qq >= a.T;
-                        if constexpr (DIAG) dead = dead || qq == key;
-                        p = dead ? 0.f : p;
-                    }
-                    const float gg = keep[j] ? dp[hf][r] : 0.f;
-                    dp[hf][r] = keep[j] ? p : 0.f;     // dropped P (x 1/keep in the epilogue) -> dV
-                    s[hf][r] = p * (gg - dl[j]);        // dS' (x scale/keep in the epilogue)   -> dK
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                float p = fast_exp2(fmaf(s[r], c, -nl[j]));
+                if constexpr (TAIL || DIAG) {
+                    const int qq = TR * qt + 32 * hf + acc_row(r, lane);
+                    bool dead = false;
+                    if constexpr (TAIL) dead = qq >= a.T;
+                    if constexpr (DIAG) dead = dead || qq == key;
+                    p = dead ? 0.f : p;
                 }
+                const float gg = keep[j] ? dp[r] : 0.f;
+                dp[r] = keep[j] ? p : 0.f;     // dropped P (x 1/keep in the epilogue) -> dV
+                s[r] = p * (gg - dl[j]);        // dS' (x scale/keep in the epilogue)   -> dK
             }
-            const bf16x8 p0 = acc_to_b(dp[hf], 0), p1 = acc_to_b(dp[hf], 1);
-            const bf16x8 s0 = acc_to_b(s[hf], 0), s1 = acc_to_b(s[hf], 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int d = 0; d < G::DB; ++d) {
-                dv[d] = mfma32(tdf[2 * d], p0, dv[d]);
-                dv[d] = mfma32(tdf[2 * d + 1], p1, dv[d]);
-                dk[d] = mfma32(tqf[2 * d], s0, dk[d]);
-                dk[d] = mfma32(tqf[2 * d + 1], s1, dk[d]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto phase1 = [&](f32x16& s, f32x16& dp, int hf, int buf) {
+        zero16(s);
+        zero16(dp);
+        const bf16_t* qp = &sQ[buf][32 * hf * G::RSTR + roff];
+        const bf16_t* dop = &sD[buf][32 * hf * G::RSTR + roff];
+        bf16x8 qfr[G::KS], dfr[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) qfr[ks] = *(const bf16x8*)(qp + 16 * ks);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) dfr[ks] = *(const bf16x8*)(dop + 16 * ks);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) s = mfma32(qfr[ks], kf[ks], s);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) dp = mfma32(dfr[ks], vf[ks], dp);
+    };
+    auto tr_load_d = [&](bf16x8 (&tdf)[2 * G::DB], int hf, int buf) {
+        const bf16_t* td = &sD[buf][32 * hf * G::RSTR + toff];
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) {
+            tdf[2 * d] = tr_frag<G::RSTR>(td, 0, 32 * d);
+            tdf[2 * d + 1] = tr_frag<G::RSTR>(td, 16, 32 * d);
+        }
+    };
+    auto tr_load_q = [&](bf16x8 (&tqf)[2 * G::DB], int hf, int buf) {
+        const bf16_t* tq = &sQ[buf][32 * hf * G::RSTR + toff];
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) {
+            tqf[2 * d] = tr_frag<G::RSTR>(tq, 0, 32 * d);
+            tqf[2 * d + 1] = tr_frag<G::RSTR>(tq, 16, 32 * d);
+        }
+    };
+    auto phase3_v = [&](const bf16x8 (&tdf)[2 * G::DB], const f32x16& dp) {
+        const bf16x8 p0 = acc_to_b(dp, 0), p1 = acc_to_b(dp, 1);
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) {
+            dv[d] = mfma32(tdf[2 * d], p0, dv[d]);
+            dv[d] = mfma32(tdf[2 * d + 1], p1, dv[d]);
+        }
+    };
+    auto phase3_k = [&](const bf16x8 (&tqf)[2 * G::DB], const f32x16& s) {
+        const bf16x8 s0 = acc_to_b(s, 0), s1 = acc_to_b(s, 1);
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) {
+            dk[d] = mfma32(tqf[2 * d], s0, dk[d]);
+            dk[d] = mfma32(tqf[2 * d + 1], s1, dk[d]);
+        }
+    };
+    // One wave per SIMD issues in order, and an MFMA keeps the issue port only 8 of its 32 cycles: the
+    // element-wise work of one half is therefore INTERLEAVED, instruction by instruction, with the MFMAs of
+    // the other half (sched_group_barrier: 1 MFMA + a few VALU), instead of alternating MFMA-only and VALU-only
+    // stretches. Fragment loads are batched so that the live set stays inside the 512-register budget.
+    auto tile = [&](auto tail_tag, int qt, int buf) {
+        f32x16 s0, dp0, s1, dp1;
+        bf16x8 tdf[2 * G::DB], tqf[2 * G::DB];
+        phase1(s0, dp0, 0, buf);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * G::KS, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // group A: phase 1 of half 1 (MFMA) interleaved with the element-wise stage of half 0 (VALU)
+        phase1(s1, dp1, 1, buf);
+        softmax_half(tail_tag, s0, dp0, qt, 0, buf);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * G::KS + 8, 1);
+#pragma unroll
+        for (int i = 0; i < 2 * G::KS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x002, 9, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // group B: phase 3 of half 0 (MFMA) interleaved with the element-wise stage of half 1 (VALU)
+        tr_load_d(tdf, 0, buf);
+        tr_load_q(tqf, 0, buf);
+        phase3_v(tdf, dp0);
+        phase3_k(tqf, s0);
+        softmax_half(tail_tag, s1, dp1, qt, 1, buf);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8 * G::DB + 8, 2);
+#pragma unroll
+        for (int i = 0; i < 4 * G::DB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+            __builtin_amdgcn_sched_group_barrier(0x002, 9, 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        tr_load_d(tdf, 1, buf);
+        tr_load_q(tqf, 1, buf);
+        phase3_v(tdf, dp1);
+        phase3_k(tqf, s1);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     stage(0, 0);
