@@ -155,6 +155,12 @@ int v1t_gemm_nt(const void* A, int lda, const void* B, int ldb, int M, int N, in
 /* dW[n][k] (fp32, +=) = sum_m Y[m][n] X[m][k], bf16 inputs */
 int v1t_gemm_tn(const void* Y, int ldy, const void* X, int ldx, int M, int NY, int NX, float* dW,
                 int ldw, int m_chunk, void* stream);
+/* same, with the per-chunk partial tiles staged in `slab` (v1t_gemm_tn_slab_bytes bytes of scratch; 0 bytes =
+ * this shape has no slab path) and summed by a reduce kernel instead of fp32 atomics: the form the ViT
+ * backward uses, deterministic for a given m_chunk */
+long long v1t_gemm_tn_slab_bytes(int M, int NY, int NX, int m_chunk);
+int v1t_gemm_tn_slab(const void* Y, int ldy, const void* X, int ldx, int M, int NY, int NX, float* dW,
+                     int ldw, int m_chunk, float* slab, long long slab_bytes, void* stream);
 /* qkv (B*T, 3*H*DP) bf16 -> o (B*T, H*DP) bf16, lse2 (B,H,T) */
 int v1t_attention_forward(const void* qkv, int B, int H, int T, int DP, const float* scale,
                           int scale_per_head, int mask_diag, float dropout_p, uint64_t seed,

@@ -34,7 +34,8 @@ def test_gemm_nt(ctx, M, N, K):
     assert rel_to_max(Cb.float().cpu(), ref.cpu()) < 4e-3  # one bf16 rounding of the output
 
 
-@pytest.mark.parametrize("M,NY,NX,mc", [(1000, 160, 512, 256), (3000, 1920, 160, 1024), (500, 512, 160, 128), (777, 64, 256, 128), (100, 160, 640, 128), (31, 32, 32, 32)])
+@pytest.mark.parametrize("M,NY,NX,mc", [(1000, 160, 512, 256), (3000, 1920, 160, 1024), (500, 512, 160, 128), (777, 64, 256, 128), (100, 160, 640, 128), (31, 32, 32, 32),
+                                        (640, 320, 128, 64), (130, 96, 160, 64), (200, 160, 640, 96), (26464, 160, 640, 2048)])
 def test_gemm_tn(ctx, M, NY, NX, mc):
     lib, L, dev = ctx
     g = torch.Generator().manual_seed(M + NY)
@@ -46,6 +47,17 @@ def test_gemm_tn(ctx, M, NY, NX, mc):
     assert rel_to_max(dW.cpu(), ref.cpu()) < 5e-6  # fp32 atomics: order-dependent last bits only
     L.check(lib.v1t_gemm_tn(Y.data_ptr(), NY, X.data_ptr(), NX, M, NY, NX, dW.data_ptr(), NX, mc, L.stream()))
     assert rel_to_max(dW.cpu(), 2 * ref.cpu()) < 5e-6  # accumulates (+=)
+    # slab + reduce form (what the ViT backward uses); same result, deterministic
+    nb = lib.v1t_gemm_tn_slab_bytes(M, NY, NX, mc)
+    slab = torch.empty(max(nb, 4) // 4, device=dev)
+    outs = []
+    for _ in range(2):
+        dW2 = torch.zeros(NY, NX, device=dev)
+        L.check(lib.v1t_gemm_tn_slab(Y.data_ptr(), NY, X.data_ptr(), NX, M, NY, NX, dW2.data_ptr(), NX, mc, slab.data_ptr(), nb, L.stream()))
+        outs.append(dW2.cpu())
+    assert rel_to_max(outs[0], ref.cpu()) < 5e-6
+    if nb > 0:
+        assert torch.equal(outs[0], outs[1])
 
 
 def _attn_ref(qkv, B, H, T, DP, scale, mask=None, p=0.0, diag=False):

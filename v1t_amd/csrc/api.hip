@@ -125,8 +125,27 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
 }
 
 struct ScratchLayout {
-    long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, total;
+    long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, slab, total;
 };
+// contraction rows per workgroup of the weight-gradient GEMMs: aim at >= ~512 workgroups
+int tn_mchunk(long long R, int tiles) {
+    const int want = std::max(1, 512 / std::max(tiles, 1));
+    const int mc = (int)round_up((R + want - 1) / want, 64);
+    return std::max(mc, 128);
+}
+struct TnPlan { int mc_fc2, mc_fc1, mc_proj, mc_qkv; size_t slab; };
+TnPlan tn_plan(const v1t_vit* h, long long R) {
+    TnPlan p;
+    const int DP = h->DP, MP = h->MP, HDP = h->HDP;
+    p.mc_fc2 = tn_mchunk(R, ((DP + 127) / 128) * (MP / 128 > 0 ? MP / 128 : 1));
+    p.mc_fc1 = tn_mchunk(R, (MP + 127) / 128);
+    p.mc_proj = tn_mchunk(R, ((DP + 127) / 128) * h->H);
+    p.mc_qkv = tn_mchunk(R, (3 * HDP + 127) / 128);
+    p.slab = std::max(std::max(gemm_tn_slab_bytes((int)R, DP, MP, p.mc_fc2), gemm_tn_slab_bytes((int)R, MP, DP, p.mc_fc1)),
+                      std::max(gemm_tn_slab_bytes((int)R, DP, HDP, p.mc_proj), gemm_tn_slab_bytes((int)R, 3 * HDP, DP, p.mc_qkv)));
+    return p;
+}
+
 ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     ScratchLayout s;
     const long long R = (long long)B * h->T;
@@ -144,6 +163,7 @@ ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     s.delta = take((long long)B * h->H * h->T * 4);
     s.dqkv = take(R * 3 * h->HDP * 2);
     s.dbeta = take((long long)h->NB * B * h->DP * 4);
+    s.slab = take((long long)tn_plan(h, R).slab);
     s.total = cur;
     return s;
 }
@@ -554,12 +574,8 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
     bf16_t* dqkv = (bf16_t*)(sc + sl.dqkv);
     float* dbeta = (float*)(sc + sl.dbeta);
     if (h->inject && hipMemsetAsync(dbeta, 0, (size_t)h->NB * B * DP * 4, s) != hipSuccess) return V1T_ERR_LAUNCH;
-    // contraction rows per workgroup of the weight-gradient GEMMs: aim at >= ~512 workgroups
-    auto mchunk = [&](int tiles) {
-        int want = std::max(1, 512 / std::max(tiles, 1));
-        int mc = round_up((R + want - 1) / want, 32);
-        return std::max(mc, 128);
-    };
+    const TnPlan tp = tn_plan(h, R);
+    float* slab = tp.slab ? (float*)(sc + sl.slab) : nullptr;
 
     const float* gin = gout;
     if (h->NB > 0) {
@@ -587,7 +603,7 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         GemmTNArgs t{};
         t.Y = dy; t.ldy = DP; t.X = hact; t.ldx = MP; t.M = R; t.NY = DP; t.NX = MP; t.dW = grads + b.fc2; t.ldw = M;
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = MP; t.xseg_valid = M; t.alpha = 1.f;
-        t.m_chunk = mchunk(((DP + 127) / 128) * (MP / 128 > 0 ? MP / 128 : 1));
+        t.m_chunk = tp.mc_fc2; t.slab = slab;
         CHECK(launch_gemm_tn(t, s));
         // d_hpre = (dy . W2) * mask * gelu'(hpre); db1 += colsum
         GemmNTArgs g{};
@@ -601,7 +617,7 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         t.Y = dhpre; t.ldy = MP; t.X = z2; t.ldx = DP; t.M = R; t.NY = MP; t.NX = DP; t.dW = grads + b.fc1; t.ldw = D;
         t.yseg_pad = MP; t.yseg_valid = M; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
         if (DP > D && b.fc1b >= 0) { t.dbias = grads + b.fc1b; t.ones_col = DP - 1; }  // z2[:, DP-1] == 1 (LN kernel)
-        t.m_chunk = mchunk((MP + 127) / 128);
+        t.m_chunk = tp.mc_fc1; t.slab = slab;
         CHECK(launch_gemm_tn(t, s));
         // dz2 = d_hpre . W1
         g = GemmNTArgs{};
@@ -621,7 +637,7 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         t = GemmTNArgs{};
         t.Y = dy; t.ldy = DP; t.X = o; t.ldx = HDP; t.M = R; t.NY = DP; t.NX = HDP; t.dW = grads + b.proj; t.ldw = h->HD;
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
-        t.m_chunk = mchunk(((DP + 127) / 128) * h->H);
+        t.m_chunk = tp.mc_proj; t.slab = slab;
         CHECK(launch_gemm_tn(t, s));
         // dO = dy . Wo
         g = GemmNTArgs{};
@@ -639,7 +655,7 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         t = GemmTNArgs{};
         t.Y = dqkv; t.ldy = 3 * HDP; t.X = z1; t.ldx = DP; t.M = R; t.NY = 3 * HDP; t.NX = DP; t.dW = grads + b.qkv; t.ldw = D;
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
-        t.m_chunk = mchunk((3 * HDP + 127) / 128);
+        t.m_chunk = tp.mc_qkv; t.slab = slab;
         CHECK(launch_gemm_tn(t, s));
         // dz1 = dqkv . Wqkv
         g = GemmNTArgs{};
@@ -782,6 +798,17 @@ int v1t_gemm_tn(const void* Y, int ldy, const void* X, int ldx, int M, int NY, i
     GemmTNArgs t{};
     t.Y = (const bf16_t*)Y; t.ldy = ldy; t.X = (const bf16_t*)X; t.ldx = ldx; t.M = M; t.NY = NY; t.NX = NX; t.dW = dW; t.ldw = ldw;
     t.yseg_pad = NY; t.yseg_valid = NY; t.xseg_pad = NX; t.xseg_valid = NX; t.m_chunk = m_chunk; t.alpha = 1.f;
+    return launch_gemm_tn(t, (hipStream_t)stream);
+}
+long long v1t_gemm_tn_slab_bytes(int M, int NY, int NX, int m_chunk) { return (long long)gemm_tn_slab_bytes(M, NY, NX, m_chunk); }
+int v1t_gemm_tn_slab(const void* Y, int ldy, const void* X, int ldx, int M, int NY, int NX, float* dW, int ldw, int m_chunk,
+                     float* slab, long long slab_bytes, void* stream) {
+    GemmTNArgs t{};
+    t.Y = (const bf16_t*)Y; t.ldy = ldy; t.X = (const bf16_t*)X; t.ldx = ldx; t.M = M; t.NY = NY; t.NX = NX; t.dW = dW; t.ldw = ldw;
+    t.yseg_pad = NY; t.yseg_valid = NY; t.xseg_pad = NX; t.xseg_valid = NX; t.m_chunk = m_chunk; t.alpha = 1.f;
+    const long long need = (long long)gemm_tn_slab_bytes(M, NY, NX, m_chunk);
+    if (need > 0 && (!slab || slab_bytes < need)) return V1T_ERR_ARG;
+    t.slab = need > 0 ? slab : nullptr;
     return launch_gemm_tn(t, (hipStream_t)stream);
 }
 int v1t_attention_forward(const void* qkv, int B, int H, int T, int DP, const float* scale, int scale_per_head, int mask_diag,

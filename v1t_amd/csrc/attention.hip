@@ -39,37 +39,6 @@ struct Geo {
     static constexpr int ITERS = (CHUNKS + 255) / 256;
 };
 
-// One LDS-DMA wave-instruction: 16 B per lane from each lane's own global address to lds_base + 16*lane.
-// Issued through inline asm ON PURPOSE: for the builtin, hipcc cannot tell which LDS buffer a pending DMA
-// writes and drains vmcnt(0) in front of the next ds_read of ANY buffer, which serialises the prefetch of
-// tile t+1 with the compute of tile t. The asm form is invisible to its wait-count bookkeeping; dma_wait()
-// (vmcnt(0)) in front of the tile-end barrier orders it. M0 is saved/restored inside the same statement.
-DEVFN void lds_dma16(const void* gsrc, const void* lds_dst_wave_uniform) {
-    unsigned keep;
-    const unsigned dst = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_dst_wave_uniform;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
-}
-DEVFN void lds_dma4(const void* gsrc, const void* lds_dst_wave_uniform) {
-    unsigned keep;
-    const unsigned dst = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_dst_wave_uniform;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
-}
-// Pin the wait for prologue loads in front of the main loop: otherwise hipcc places its vmcnt(0) at their
-// first use INSIDE the loop, where it would also drain the (invisible to it) DMA queue on every iteration.
-template <int N>
-DEVFN void touch(const bf16x8 (&x)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" ::"v"(x[i]));
-}
-DEVFN void touch(float x) { asm volatile("" ::"v"(x)); }
-
-DEVFN void dma_wait_and_barrier() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
 // Global -> LDS tile staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
 // The LDS image of a [ROWS][STR] bf16 tile is a linear array of 16-B chunks (STR/8 per row, the last
 // (STR-DP)/8 of each row are padding); one wave-instruction fills 64 consecutive chunks (1 KiB) with each

@@ -50,7 +50,11 @@ struct GemmTNArgs {
     // bias gradient for free: if X carries a column of ones at padded index `ones_col` (the LayerNorm kernel
     // writes it into a pad column), output column ones_col = column sums of Y -> atomicAdd into dbias
     float* dbias; int ones_col;
+    // optional fp32 scratch of gemm_tn_slab_bytes() bytes: partial tiles go there with plain stores and a
+    // reduce kernel adds them into dW (float atomics run at ~1.3 TB/s chip-wide and bound this GEMM otherwise)
+    float* slab;
 };
+size_t gemm_tn_slab_bytes(int M, int NY, int NX, int m_chunk);
 
 int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s);
 int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s);

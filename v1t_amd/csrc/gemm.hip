@@ -393,7 +393,175 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs g) {
     }
 }
 
+// gemm_tn2: the production weight-gradient kernel. Wave tile = (32*YB) output rows x (32*XB) output
+// columns with YB*XB = 5 accumulator blocks; two shapes:
+//   <1,5>: 4 waves stacked over Y -> workgroup 128 x 160 (dWqkv, dW1: wide Y, X = one padded LN row)
+//   <5,1>: 4 waves side by side over X -> workgroup 160 x 128 (dWo, dW2: Y is the 160-wide residual grad)
+// so no wave idles on a 160-wide operand. 64 contraction rows per stage, staged by LDS-DMA into two
+// [64][160] images per operand (row stride 320 B = 64 B x 5: conflict-free transposed reads), double
+// buffered; rows past the end of the chunk are clamped for the fetch and masked in the 1-block operand.
+constexpr int TN2_ROWS = 64, TN2_STR = 160, TN2_CPR = TN2_STR / 8;
+
+template <int YB, int XB>
+__global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs g) {
+    constexpr int WY = (YB == 1) ? 4 : 1, WX = 4 / WY;
+    constexpr int YW = 32 * YB * WY, XW = 32 * XB * WX;
+    static_assert(YW <= TN2_STR && XW <= TN2_STR, "tile");
+    constexpr int NI = TN2_ROWS * TN2_CPR / 64 / 4;  // DMA instructions per wave per operand tile (5)
+    __shared__ __attribute__((aligned(16))) bf16_t sY[2][TN2_ROWS * TN2_STR];
+    __shared__ __attribute__((aligned(16))) bf16_t sX[2][TN2_ROWS * TN2_STR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = (WY == 4) ? wave : 0, wx = (WX == 4) ? wave : 0;
+    const int n0 = blockIdx.x * YW, x0 = blockIdx.y * XW;
+    const int mb = blockIdx.z * g.m_chunk;
+    const int me = min(g.M, mb + g.m_chunk);
+    const int nt = (me - mb + TN2_ROWS - 1) / TN2_ROWS;
+    const int yw0 = n0 + 32 * YB * wy, xw0 = x0 + 32 * XB * wx;
+    const bool wave_on = yw0 < g.NY && xw0 < g.NX;  // wave-uniform (launcher guarantees whole wave tiles)
+
+    int drow[NI], dyc[NI], dxc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = 64 * (wave + 4 * i) + lane;
+        drow[i] = c / TN2_CPR;
+        const int cc = c % TN2_CPR;
+        dyc[i] = min(n0 + 8 * min(cc, YW / 8 - 1), g.NY - 8);
+        dxc[i] = min(x0 + 8 * min(cc, XW / 8 - 1), g.NX - 8);
+    }
+    auto issue = [&](int t, int buf) {
+        const int mt = mb + TN2_ROWS * t;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const size_t m = (size_t)min(mt + drow[i], me - 1);
+            lds_dma16(g.Y + m * g.ldy + dyc[i], &sY[buf][512 * (wave + 4 * i)]);
+            lds_dma16(g.X + m * g.ldx + dxc[i], &sX[buf][512 * (wave + 4 * i)]);
+        }
+    };
+
+    f32x16 acc[YB * XB];
+#pragma unroll
+    for (int i = 0; i < YB * XB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    auto compute = [&](auto ragged_c, int buf, int valid) {
+        constexpr bool RAGGED = decltype(ragged_c)::value;
+#pragma unroll
+        for (int s = 0; s < TN2_ROWS / 16; ++s) {
+            bf16x8 a[YB], b[XB];
+#pragma unroll
+            for (int yb = 0; yb < YB; ++yb) a[yb] = lds_tr_frag_nat(sY[buf], TN2_STR, 16 * s, 32 * (YB * wy + yb), lane);
+#pragma unroll
+            for (int xb = 0; xb < XB; ++xb) b[xb] = lds_tr_frag_nat(sX[buf], TN2_STR, 16 * s, 32 * (XB * wx + xb), lane);
+            if constexpr (RAGGED) {
+                const int k0 = 16 * s + 8 * (lane >> 5);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k0 + j >= valid) {
+                        if constexpr (YB == 1) a[0][j] = 0; else b[0][j] = 0;
+                    }
+            }
+#pragma unroll
+            for (int yb = 0; yb < YB; ++yb)
+#pragma unroll
+                for (int xb = 0; xb < XB; ++xb) acc[yb * XB + xb] = mfma32(a[yb], b[xb], acc[yb * XB + xb]);
+        }
+    };
+
+    if (nt > 0) issue(0, 0);
+    dma_wait_and_barrier();
+    for (int t = 0; t < nt - 1; ++t) {
+        const int buf = t & 1;
+        issue(t + 1, buf ^ 1);
+        if (wave_on) compute(std::false_type{}, buf, TN2_ROWS);
+        dma_wait_and_barrier();
+    }
+    if (!wave_on || nt <= 0) return;
+    {
+        const int valid = me - mb - TN2_ROWS * (nt - 1);
+        if (valid < TN2_ROWS) compute(std::true_type{}, (nt - 1) & 1, valid);
+        else compute(std::false_type{}, (nt - 1) & 1, TN2_ROWS);
+    }
+    if (g.slab) {
+        // partial tile -> slab in accumulator-fragment order (16 floats per lane per block, plain 16-B stores);
+        // tn_reduce_kernel sums the chunks and applies the index maps. ~3x cheaper than 41 MB of fp32 atomics.
+        float* sl = g.slab + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * (YB * XB * 1024) + lane * 16;
+#pragma unroll
+        for (int i = 0; i < YB * XB; ++i)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *(f32x4*)(sl + i * 1024 + 4 * r4) = f32x4{acc[i][4 * r4], acc[i][4 * r4 + 1], acc[i][4 * r4 + 2], acc[i][4 * r4 + 3]};
+        return;
+    }
+#pragma unroll
+    for (int yb = 0; yb < YB; ++yb)
+#pragma unroll
+        for (int xb = 0; xb < XB; ++xb) {
+            const f32x16& c = acc[yb * XB + xb];
+            const int xc = xw0 + 32 * xb + (lane & 31);
+            const int xs = xc / g.xseg_pad, xr = xc % g.xseg_pad;
+            const bool xok = xr < g.xseg_valid;
+            const bool isb = g.dbias != nullptr && xc == g.ones_col;
+            const int ncol = xs * g.xseg_valid + xr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int yr = yw0 + 32 * yb + acc_row(r, lane);
+                const int ys = yr / g.yseg_pad, yy = yr % g.yseg_pad;
+                if (yy < g.yseg_valid) {
+                    if (xok) atomicAdd(&g.dW[(size_t)(ys * g.yseg_valid + yy) * g.ldw + ncol], c[r] * g.alpha);
+                    else if (isb) atomicAdd(&g.dbias[ys * g.yseg_valid + yy], c[r] * g.alpha);
+                }
+            }
+        }
+}
+
+
+// Sums the partial tiles gemm_tn2 left in the slab over the m-chunks and adds them into dW / dbias (plain
+// read-modify-write: exactly one thread owns each output element). Thread = 4 accumulator registers of one
+// lane of one block: consecutive threads read consecutive 16 B of each chunk's slab.
+template <int YB, int XB>
+__global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTNArgs g, int gx, int gy, int gz) {
+    constexpr int WY = (YB == 1) ? 4 : 1, WX = 4 / WY;
+    constexpr int YW = 32 * YB * WY, XW = 32 * XB * WX;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int total = gx * gy * 4 * YB * XB * 256;
+    if (t >= total) return;
+    const int r4 = t & 3, lane = (t >> 2) & 63, rest = t >> 8;
+    const int blk = rest % (YB * XB), wave = (rest / (YB * XB)) & 3, tile = rest / (YB * XB * 4);
+    const int bx = tile % gx, by = tile / gx;
+    const int wy = (WY == 4) ? wave : 0, wx = (WX == 4) ? wave : 0;
+    const int yw0 = bx * YW + 32 * YB * wy, xw0 = by * XW + 32 * XB * wx;
+    if (yw0 >= g.NY || xw0 >= g.NX) return;
+    const size_t zs = (size_t)total * 4;
+    const float* p = g.slab + (size_t)t * 4;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+    int z = 0;
+    for (; z + 4 <= gz; z += 4) {
+        const f32x4 a = *(const f32x4*)(p + (size_t)z * zs), b = *(const f32x4*)(p + (size_t)(z + 1) * zs);
+        const f32x4 c = *(const f32x4*)(p + (size_t)(z + 2) * zs), d = *(const f32x4*)(p + (size_t)(z + 3) * zs);
+        s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; z < gz; ++z) s0 += *(const f32x4*)(p + (size_t)z * zs);
+    s0 += s1; s2 += s3; s0 += s2;
+    const int yb = blk / XB, xb = blk % XB;
+    const int xc = xw0 + 32 * xb + (lane & 31);
+    const int xs = xc / g.xseg_pad, xr = xc % g.xseg_pad;
+    const bool xok = xr < g.xseg_valid;
+    const bool isb = g.dbias != nullptr && xc == g.ones_col;
+    const int ncol = xs * g.xseg_valid + xr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yr = yw0 + 32 * yb + acc_row(4 * r4 + i, lane);
+        const int ys = yr / g.yseg_pad, yy = yr % g.yseg_pad;
+        if (yy < g.yseg_valid) {
+            if (xok) g.dW[(size_t)(ys * g.yseg_valid + yy) * g.ldw + ncol] += s0[i] * g.alpha;
+            else if (isb) g.dbias[ys * g.yseg_valid + yy] += s0[i] * g.alpha;
+        }
+    }
+}
+
 }  // namespace
+
 
 int launch_gemm_nt(const GemmNTArgs& a_, int epi, hipStream_t s) {
     GemmNTArgs a = a_;
@@ -406,10 +574,31 @@ int launch_gemm_nt(const GemmNTArgs& a_, int epi, hipStream_t s) {
     return launch_nt_n<1>(a, epi, s);
 }
 
+size_t gemm_tn_slab_bytes(int M, int NY, int NX, int m_chunk) {
+    if (M <= 0 || m_chunk <= 0 || m_chunk % TN2_ROWS != 0) return 0;
+    const size_t gz = (size_t)(M + m_chunk - 1) / m_chunk;
+    if (NY % 160 == 0 && NX % 128 == 0 && NY <= 320) return gz * (NY / 160) * (NX / 128) * 4 * 5 * 1024 * sizeof(float);
+    if (NX % 160 == 0) return gz * ((NY + 127) / 128) * (NX / 160) * 4 * 5 * 1024 * sizeof(float);
+    return 0;
+}
+
 int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s) {
     if (a.NY % 32 != 0 || a.NX % 32 != 0 || a.m_chunk % 32 != 0 || (a.ldy % 8) || (a.ldx % 8)) return V1T_ERR_ARG;
     if (a.M <= 0) return V1T_OK;
-    const int gy = (a.NY + 127) / 128, gz = (a.M + a.m_chunk - 1) / a.m_chunk;
+    const int gz = (a.M + a.m_chunk - 1) / a.m_chunk;
+    if (a.m_chunk % TN2_ROWS == 0 && a.NY % 160 == 0 && a.NX % 128 == 0 && a.NY <= 320) {
+        const int gx = a.NY / 160, gy2 = a.NX / 128;
+        hipLaunchKernelGGL((gemm_tn2_kernel<5, 1>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+        if (a.slab) hipLaunchKernelGGL((tn_reduce_kernel<5, 1>), dim3(gx * gy2 * 20), dim3(256), 0, s, a, gx, gy2, gz);
+        return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    }
+    if (a.m_chunk % TN2_ROWS == 0 && a.NX % 160 == 0) {
+        const int gx = (a.NY + 127) / 128, gy2 = a.NX / 160;
+        hipLaunchKernelGGL((gemm_tn2_kernel<1, 5>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+        if (a.slab) hipLaunchKernelGGL((tn_reduce_kernel<1, 5>), dim3(gx * gy2 * 20), dim3(256), 0, s, a, gx, gy2, gz);
+        return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    }
+    const int gy = (a.NY + 127) / 128;
 #define TN_LAUNCH(XB)                                                                                       \
     hipLaunchKernelGGL((gemm_tn_kernel<XB>), dim3(gy, a.NX / (32 * XB), gz), dim3(256), 0, s, a)
     if (a.NX % 160 == 0) TN_LAUNCH(5);
