@@ -136,10 +136,11 @@ def main():
     if rank == 0:
         images = sharding.images_per_step() * a.steps
         fl = algorithmic_flops(args, a.neurons)
-        # dominant kernel: attention backward dK/dV — 4 of the 5 algorithmic products of flash backward
-        # (S, dP, dV, dK; the dQ kernel's recomputed S/dP are NOT counted) = 2 x forward attention FLOPs
-        names = {0: "attn_fwd", 1: "attn_bwd_dq", 2: "attn_bwd_dkv"}
-        mult = {0: 1.0, 1: 0.5, 2: 2.0}[a.profile_class] if a.profile_class in (0, 1, 2) else 0.0
+        # dominant kernel: attention backward, the dQ and dK/dV bodies in one launch — the 5 algorithmic products
+        # of flash backward (S, dP, dV, dK, dQ) = 2.5 x forward attention FLOPs; the second evaluation of S and dP
+        # (each body recomputes them: 7 executed products) is NOT counted
+        names = {0: "attn_fwd", 1: "attn_bwd_dq (split launches only)", 2: "attn_bwd_fused (dQ + dK/dV bodies)"}
+        mult = {0: 1.0, 1: 0.5, 2: 2.5}[a.profile_class] if a.profile_class in (0, 1, 2) else 0.0
         per_launch = mult * fl["attn_fwd_per_image_block"] * args.batch_size
         avg_ms = total_ms.value / max(launches.value, 1)
         achieved = per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0

@@ -36,6 +36,8 @@ for p in (0.0, 0.2544):
         torch.cuda.synchronize()
         n, ms = C.c_int(), C.c_double()
         L.check(lib.v1t_profile_read(C.byref(n), C.byref(ms)))
-        avg = ms.value / max(n.value, 1)
+        if n.value == 0:
+            continue
+        avg = ms.value / n.value
         print(f"p={p:<6} {name:8s} {avg * 1e3:8.1f} us  executed {mult * flops_fwd / avg / 1e9:7.1f} TFLOP/s ({n.value} launches)", flush=True)
 lib.v1t_profile_enable(-1, 0)

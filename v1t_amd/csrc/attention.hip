@@ -21,7 +21,34 @@
 // epilogue, and the dropout mask costs one 32-bit hash per 2x2 (query, key) block (common.h).
 #include <type_traits>
 
+#include <cstdlib>
 #include "attention.h"
+
+#ifdef V1T_KPROF
+// dev-only in-kernel timeline (tools/kprof.py): s_memtime stamps of one workgroup's waves, KP_T0 <= tile < KP_T0 + KP_NT
+#define KP_T0 8
+#define KP_NT 8
+#define KP_NP 16
+__device__ unsigned long long g_kprof[4 * KP_NT * KP_NP];
+#define KP_DECL unsigned long long kp_t[KP_NP] = {}
+#define KP_STAMP(i)                                            \
+    do {                                                       \
+        __builtin_amdgcn_sched_barrier(0);                     \
+        asm volatile("s_memtime %0" : "=s"(kp_t[i])::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+#define KP_FLUSH(kt, wave, lane)                                                                      \
+    do {                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        if (blockIdx.x == KP_BLOCK && (kt) >= KP_T0 && (kt) < KP_T0 + KP_NT && (lane) == 0)           \
+            for (int i_ = 0; i_ < KP_NP; ++i_) g_kprof[((wave) * KP_NT + (kt) - KP_T0) * KP_NP + i_] = kp_t[i_]; \
+    } while (0)
+#define KP_BLOCK 300
+#else
+#define KP_DECL
+#define KP_STAMP(i)
+#define KP_FLUSH(kt, wave, lane)
+#endif
 
 namespace {
 
@@ -41,37 +68,80 @@ struct Geo {
 
 // Global -> LDS tile staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
 // The LDS image of a [ROWS][STR] bf16 tile is a linear array of 16-B chunks (STR/8 per row, the last
-// (STR-DP)/8 of each row are padding); one wave-instruction fills 64 consecutive chunks (1 KiB) with each
-// lane's own global source address, so the row padding costs nothing but a dummy fetch. Instruction n of a
-// tile is issued by wave n % 4. Rows beyond T are clamped to row T-1 (finite data; every consumer masks them).
+// (STR-DP)/8 of each row are padding); one wave-instruction ("piece") fills 64 consecutive chunks (1 KiB) with
+// each lane's own global source address, so the row padding costs nothing but a dummy fetch.
+// Issue cost is what matters (in-kernel s_memtime timeline, tools/kprof.py): with per-piece 64-bit address
+// arithmetic, M0 juggling and EXEC masking a piece cost its wave ~150 cycles, 850 per 32-key tile of the forward
+// kernel. Here a piece is ONE instruction: wave w owns PW consecutive pieces, the tile's row-0 address is a
+// scalar base (saddr form), the lane's byte offset is loop-invariant, and pieces 1..3 of a group of four reuse
+// the group's M0 through the instruction offset (it advances the LDS and the global address alike, so the lane
+// offset carries 3072 - imm and the base is biased by -3072). The last piece of a tile may be partial: its
+// surplus lanes re-fetch the last row into slack behind the tile (size buffers with LDS_ELEMS).
+// Rows beyond T are clamped to row T-1 (finite data; every consumer masks them): only the ragged last tile
+// takes that path, recomputing its offsets.
 template <int DP, int STR, int ROWS = 32>
 struct TileDma {
     static constexpr int CPR = STR / 8;                 // chunks per LDS row
     static constexpr int NCH = ROWS * CPR;              // chunks per tile
-    static constexpr int NINST = (NCH + 63) / 64;       // wave-instructions per tile
-    static constexpr int SLOTS = (NINST + 3) / 4;       // per wave
-    int row[SLOTS], c8[SLOTS];
-    bool on[SLOTS];
-    int wave;
-    DEVFN void init(int lane, int wave_uniform) {
-        wave = wave_uniform;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int n = wave + 4 * s, p = 64 * n + lane;
-            on[s] = n < NINST && p < NCH;
-            row[s] = p / CPR;
-            c8[s] = 8 * min(p % CPR, DP / 8 - 1);
-        }
+    static constexpr int NINST = (NCH + 63) / 64;       // pieces per tile
+    static constexpr int PW = (NINST + 3) / 4;          // pieces per wave
+    static constexpr int NG = (PW + 3) / 4;             // M0 groups per wave
+    static constexpr int LDS_ELEMS = NINST * 512;       // tile + slack of the partial last piece
+    static constexpr int BIAS = 3072;
+    unsigned voff[PW];
+    int wave, lane, ld;
+    DEVFN unsigned lane_off(int i, int max_row) const {
+        const int p = 64 * (wave * PW + i) + lane;
+        const int r = min(p / CPR, max_row), cc = min(p % CPR, DP / 8 - 1);
+        return (unsigned)((r * ld + 8 * cc) * 2 + BIAS - 1024 * (i & 3));
     }
-    // img: element (row 0, col 0) of this (image, head) slice; ld in elements; lds: tile base
-    DEVFN void issue(const bf16_t* img, int ld, int t0, int T, bf16_t* lds) const {
+    DEVFN void init(int lane_, int wave_uniform, int ld_elems) {
+        wave = wave_uniform; lane = lane_; ld = ld_elems;
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int n = wave + 4 * s;
-            if (n < NINST) {  // wave-uniform
-                const bf16_t* src = img + (size_t)min(t0 + row[s], T - 1) * ld + c8[s];
-                if (on[s]) lds_dma16(src, lds + 512 * n);
-            }
+        for (int i = 0; i < PW; ++i) voff[i] = lane_off(i, ROWS - 1);
+    }
+    template <int CNT>
+    DEVFN static void group(const char* base, unsigned m0v, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+        unsigned keep;
+        if constexpr (CNT == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\tglobal_load_lds_dwordx4 %3, %6 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %4, %6 offset:2048\n\tglobal_load_lds_dwordx4 %5, %6 offset:3072\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base) : "memory");
+        else if constexpr (CNT == 3)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\tglobal_load_lds_dwordx4 %3, %5 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %4, %5 offset:2048\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "v"(v2), "s"(base) : "memory");
+        else if constexpr (CNT == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %3, %4 offset:1024\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "s"(base) : "memory");
+        else if constexpr (CNT == 1)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "s"(base) : "memory");
+    }
+    // img: element (row 0, col 0) of this (image, head) slice; t0: first row of the tile; lds: tile base (LDS_ELEMS elements)
+    DEVFN void issue(const bf16_t* img, int t0, int T, bf16_t* lds) const {
+        const char* base = (const char*)(img + (size_t)t0 * ld) - BIAS;
+        const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds);
+        const bool ragged = t0 + ROWS > T;  // wave-uniform
+        unsigned v[PW];
+#pragma unroll
+        for (int i = 0; i < PW; ++i) v[i] = voff[i];
+        if (ragged) {
+            asm volatile("; ragged tile: clamp rows" ::: "memory");  // keeps this a branch (no if-conversion into the hot path)
+#pragma unroll
+            for (int i = 0; i < PW; ++i) v[i] = lane_off(i, T - 1 - t0);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int n0 = wave * PW + 4 * g;                       // wave-uniform
+            const int cnt = min(min(4, PW - 4 * g), NINST - n0);    // pieces of this group that exist
+            const unsigned m0v = l0 + 1024u * (unsigned)n0;
+            auto at = [&](int k) { return v[4 * g + k < PW ? 4 * g + k : PW - 1]; };
+            if (cnt >= 4) group<4>(base, m0v, at(0), at(1), at(2), at(3));
+            else if (cnt == 3) group<3>(base, m0v, at(0), at(1), at(2), 0);
+            else if (cnt == 2) group<2>(base, m0v, at(0), at(1), 0, 0);
+            else if (cnt == 1) group<1>(base, m0v, at(0), 0, 0, 0);
         }
     }
 };
@@ -111,9 +181,9 @@ DEVFN void drop4(uint32_t x0, uint32_t step, uint32_t sh_even, uint32_t sh_odd, 
 
 // 1-D grid over (row block, head, image), XCD-aware: the row blocks of one (image, head) get consecutive
 // logical ids and each XCD owns a contiguous chunk of ids, so a head's K/V (or Q/dO) stays in ONE L2.
-DEVFN void decode_block(const AttnArgs& a, int& rb, int& h, int& b) {
+DEVFN void decode_block(const AttnArgs& a, int bid, int nblk, int& rb, int& h, int& b) {
     const int nrb = (a.T + 127) / 128;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int lid = xcd_remap(bid, nblk);
     rb = lid % nrb;
     const int bh = lid / nrb;
     h = bh % a.H;
@@ -124,11 +194,13 @@ DEVFN void decode_block(const AttnArgs& a, int& rb, int& h, int& b) {
 template <int DP, bool DROP, bool DIAG>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     using G = Geo<DP>;
-    __shared__ __attribute__((aligned(16))) bf16_t sK[2][32 * G::RSTR];
-    __shared__ __attribute__((aligned(16))) bf16_t sV[2][32 * G::TSTR];
+    using DmaK = TileDma<DP, G::RSTR>;
+    using DmaV = TileDma<DP, G::TSTR>;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][DmaK::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[2][DmaV::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, h, b;
-    decode_block(a, rb, h, b);
+    decode_block(a, blockIdx.x, gridDim.x, rb, h, b);
     const int q = rb * 128 + 32 * wave + (lane & 31);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
@@ -136,10 +208,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const bf16_t* kbase = qkv_b + HD + h * DP;
     const bf16_t* vbase = qkv_b + 2 * HD + h * DP;
     const float c = a.scale[a.scale_per_head ? h : 0] * LOG2E;
-    TileDma<DP, G::RSTR> dmaK;
-    TileDma<DP, G::TSTR> dmaV;
-    dmaK.init(lane, wave);
-    dmaV.init(lane, wave);
+    DmaK dmaK;
+    DmaV dmaV;
+    dmaK.init(lane, wave, a.ldqkv);
+    dmaV.init(lane, wave, a.ldqkv);
 
     bf16x8 qf[G::KS];
 #pragma unroll
@@ -161,8 +233,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const int voff = tr_lane_off(lane, G::TSTR);
     const int nt = (a.T + 31) / 32;
 
+    KP_DECL;
     auto tile = [&](auto tail_tag, int kt, int buf) {
         constexpr bool TAIL = decltype(tail_tag)::value;
+        KP_STAMP(0);
         f32x16 s;
         zero16(s);
         const bf16_t* kp = &sK[buf][koff];
@@ -188,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x100, 4 * G::DB / G::KS, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        KP_STAMP(1);
         if constexpr (TAIL || DIAG) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -202,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 2; r < 16; ++r) pmax = fmaxf(pmax, s[r]);
         pmax = fmaxf(pmax, __shfl_xor(pmax, 32)) * c;
+        KP_STAMP(2);
         if (!__all(pmax <= m2 + RESCALE_THR)) {
             const float mn = fmaxf(m2, pmax);
             const float alpha = fast_exp2(m2 - mn);
@@ -213,6 +289,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             m2 = mn;
         }
         const float negm = -m2;
+        // next tile's LDS-DMA is issued HERE, in the VALU-only stretch: a piece costs its wave 100-185 cycles of
+        // issue while ds_reads are in flight (tile start) but 25-60 when the LDS is quiet (kprof timeline)
+        if constexpr (!TAIL) {
+            dmaK.issue(kbase, 32 * (kt + 1), a.T, sK[buf ^ 1]);
+            dmaV.issue(vbase, 32 * (kt + 1), a.T, sV[buf ^ 1]);
+        }
+        KP_STAMP(3);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             bool keep[4] = {true, true, true, true};
@@ -225,24 +308,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             }
         }
         const bf16x8 p0 = acc_to_b(s, 0), p1 = acc_to_b(s, 1);
+        KP_STAMP(4);
 #pragma unroll
         for (int d = 0; d < G::DB; ++d) {
             o[d] = mfma32(vfr[2 * d], p0, o[d]);
             o[d] = mfma32(vfr[2 * d + 1], p1, o[d]);
         }
+#ifdef V1T_KPROF
+        KP_STAMP(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KP_STAMP(6);
+        KP_FLUSH(kt, wave, lane);
+#endif
     };
 
-    dmaK.issue(kbase, a.ldqkv, 0, a.T, sK[0]);
-    dmaV.issue(vbase, a.ldqkv, 0, a.T, sV[0]);
+    dmaK.issue(kbase, 0, a.T, sK[0]);
+    dmaV.issue(vbase, 0, a.T, sV[0]);
     touch(qf);
     touch(c);
     dma_wait_and_barrier();
     for (int kt = 0; kt < nt - 1; ++kt) {
         const int buf = kt & 1;
-        dmaK.issue(kbase, a.ldqkv, 32 * (kt + 1), a.T, sK[buf ^ 1]);
-        dmaV.issue(vbase, a.ldqkv, 32 * (kt + 1), a.T, sV[buf ^ 1]);
         tile(std::false_type{}, kt, buf);
         dma_wait_and_barrier();
+        KP_STAMP(7);
     }
     tile(std::true_type{}, nt - 1, (nt - 1) & 1);
 
@@ -292,17 +381,27 @@ __global__ void attn_delta_kernel(AttnArgs a, float* delta) {
 // ------------------------------------------------------------------------------------------
 // DP >= 128: Q + dO fragments (2*DP/4 VGPRs) + the dQ accumulator (DP/2) + S/dP/staging exceed 256
 // registers, so that shape runs one wave per SIMD with the 512-register budget (no spills).
+constexpr int BWD_TR = 64;  // rows per staged tile of the backward kernels
+template <int DP>
+struct BwdLds {  // one layout for both backward bodies, so that they can share a launch
+    static constexpr int TE = TileDma<DP, Geo<DP>::RSTR, BWD_TR>::LDS_ELEMS;
+    bf16_t a[2][TE];      // dQ body: K tiles;  dK/dV body: Q tiles
+    bf16_t b[2][TE];      // dQ body: V tiles;  dK/dV body: dO tiles
+    float l[2][BWD_TR];   // dK/dV body: lse2 of the tile's queries
+    float d[2][BWD_TR];   // dK/dV body: delta * keep_prob
+};
+
 template <int DP, bool DROP, bool DIAG>
-__global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(AttnArgs a) {
+DEVFN void attn_bwd_dq_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& lds) {
     using G = Geo<DP>;
     // 64-key tiles processed as two independent 32-key halves: with one wave per SIMD the element-wise
     // work of one half is issued while the MFMAs of the other half execute (the matrix pipe is asynchronous)
-    constexpr int TR = 64;
-    __shared__ __attribute__((aligned(16))) bf16_t sK[2][TR * G::RSTR];
-    __shared__ __attribute__((aligned(16))) bf16_t sV[2][TR * G::RSTR];
+    constexpr int TR = BWD_TR;
+    auto& sK = lds.a;
+    auto& sV = lds.b;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, h, b;
-    decode_block(a, rb, h, b);
+    decode_block(a, bid, nblk, rb, h, b);
     const int q = rb * 128 + 32 * wave + (lane & 31);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
@@ -310,7 +409,7 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
     const bf16_t* kbase = qkv_b + HD + h * DP;
     const bf16_t* vbase = qkv_b + 2 * HD + h * DP;
     TileDma<DP, G::RSTR, TR> dma;
-    dma.init(lane, wave);
+    dma.init(lane, wave, a.ldqkv);
     const float sc = a.scale[a.scale_per_head ? h : 0];
     const float c = sc * LOG2E;
     const bool qok = q < a.T;
@@ -428,8 +527,8 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    dma.issue(kbase, a.ldqkv, 0, a.T, sK[0]);
-    dma.issue(vbase, a.ldqkv, 0, a.T, sV[0]);
+    dma.issue(kbase, 0, a.T, sK[0]);
+    dma.issue(vbase, 0, a.T, sV[0]);
     touch(qf);
     touch(dof);
     touch(neglse);
@@ -438,8 +537,8 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
     dma_wait_and_barrier();
     for (int kt = 0; kt < nt - 1; ++kt) {
         const int buf = kt & 1;
-        dma.issue(kbase, a.ldqkv, TR * (kt + 1), a.T, sK[buf ^ 1]);
-        dma.issue(vbase, a.ldqkv, TR * (kt + 1), a.T, sV[buf ^ 1]);
+        dma.issue(kbase, TR * (kt + 1), a.T, sK[buf ^ 1]);
+        dma.issue(vbase, TR * (kt + 1), a.T, sV[buf ^ 1]);
         tile(std::false_type{}, kt, buf);
         dma_wait_and_barrier();
     }
@@ -469,19 +568,20 @@ __global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(A
 
 // ------------------------------------------------------------------------------------------
 template <int DP, bool DROP, bool DIAG>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
+DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& lds) {
     using G = Geo<DP>;
-    constexpr int TR = 64;  // 64-query tiles = two independent 32-query halves (see the dQ kernel)
-    __shared__ __attribute__((aligned(16))) bf16_t sQ[2][TR * G::RSTR];
-    __shared__ __attribute__((aligned(16))) bf16_t sD[2][TR * G::RSTR];
-    __shared__ __attribute__((aligned(16))) float sL[2][TR];   // lse2 of the tile's queries
-    __shared__ __attribute__((aligned(16))) float sDl[2][TR];  // delta * keep_prob
+    constexpr int TR = BWD_TR;  // 64-query tiles = two independent 32-query halves (see the dQ kernel)
+    auto& sQ = lds.a;
+    auto& sD = lds.b;
+    auto& sL = lds.l;
+    auto& sDl = lds.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, h, b;
-    decode_block(a, rb, h, b);
+    decode_block(a, bid, nblk, rb, h, b);
     const int key = rb * 128 + 32 * wave + (lane & 31);
-    TileDma<DP, G::RSTR, TR> dma;
-    dma.init(lane, wave);
+    TileDma<DP, G::RSTR, TR> dma, dmaD;
+    dma.init(lane, wave, a.ldqkv);
+    dmaD.init(lane, wave, a.lddo);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
@@ -519,8 +619,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     // lse2 and delta (pre-scaled by keep_prob in the delta kernel) of the tile's 64 queries go to LDS by DMA too
     // (an ordinary load inside the loop would make hipcc drain the whole vmcnt queue at its first use)
     auto stage = [&](int t, int buf) {
-        dma.issue(qbase, a.ldqkv, TR * t, a.T, sQ[buf]);
-        dma.issue(dobase, a.lddo, TR * t, a.T, sD[buf]);
+        dma.issue(qbase, TR * t, a.T, sQ[buf]);
+        dmaD.issue(dobase, TR * t, a.T, sD[buf]);
         const int qq = min(TR * t + lane, a.T - 1);
         if (wave == 0) lds_dma4(lbase + qq, sL[buf]);
         if (wave == 1) lds_dma4(dbase_ + qq, sDl[buf]);
@@ -682,8 +782,42 @@ int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 template <int DP, bool DROP, bool DIAG>
+__global__ __launch_bounds__(256, (DP >= 128 ? 1 : 2)) void attn_bwd_dq_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) BwdLds<DP> lds;
+    attn_bwd_dq_body<DP, DROP, DIAG>(a, blockIdx.x, gridDim.x, lds);
+}
+template <int DP, bool DROP, bool DIAG>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) BwdLds<DP> lds;
+    attn_bwd_dkv_body<DP, DROP, DIAG>(a, blockIdx.x, gridDim.x, lds);
+}
+// Both backward bodies in ONE launch (DP >= 128, where both run one workgroup per CU): n = 832 workgroups of each
+// on 256 CUs are 3.25 rounds, i.e. 4 per kernel (8 in all, the last of each a quarter full); together they are
+// 6.5 rounds of mixed length, the longer dK/dV workgroups dispatched first. nblk8 = n rounded up to 8 keeps
+// blockIdx % 8 (the XCD) equal to the body-local id % 8 that xcd_remap() assumes.
+template <int DP, bool DROP, bool DIAG>
+__global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(AttnArgs a, int nblk, int nblk8) {
+    __shared__ __attribute__((aligned(16))) BwdLds<DP> lds;
+    const int bid = blockIdx.x;
+    if (bid < nblk8) {
+        if (bid < nblk) attn_bwd_dkv_body<DP, DROP, DIAG>(a, bid, nblk, lds);
+    } else {
+        attn_bwd_dq_body<DP, DROP, DIAG>(a, bid - nblk8, nblk, lds);
+    }
+}
+
+template <int DP, bool DROP, bool DIAG>
 int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
-    dim3 grid(((a.T + 127) / 128) * a.H * a.B);
+    const int n = ((a.T + 127) / 128) * a.H * a.B;
+    static const bool split = std::getenv("V1T_ATTN_BWD_SPLIT") != nullptr;  // dev switch: time the two bodies separately
+    if (DP >= 128 && !split) {
+        const int n8 = (n + 7) / 8 * 8;
+        prof_begin(PROF_ATTN_DKV, s);
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<DP, DROP, DIAG>), dim3(n8 + n), dim3(256), 0, s, a, n, n8);
+        prof_end(PROF_ATTN_DKV, s);
+        return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    }
+    dim3 grid(n);
     prof_begin(PROF_ATTN_DQ, s);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DROP, DIAG>), grid, dim3(256), 0, s, a);
     prof_end(PROF_ATTN_DQ, s);
@@ -722,7 +856,7 @@ int bwd_flags(const AttnArgs& a, hipStream_t s) {
 template <int DP, int HH>
 __global__ __launch_bounds__(256, 1) void rollout_headmax_kernel(AttnArgs a, float* A, int TP, float* rowsum) {
     using G = Geo<DP>;
-    __shared__ __attribute__((aligned(16))) bf16_t sK[2][HH][32 * G::RSTR];
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][HH][TileDma<DP, G::RSTR>::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
     const int q = blockIdx.x * 128 + 32 * wave + (lane & 31);
@@ -730,7 +864,7 @@ __global__ __launch_bounds__(256, 1) void rollout_headmax_kernel(AttnArgs a, flo
     const int HD = HH * DP;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
     TileDma<DP, G::RSTR> dma;
-    dma.init(lane, wave);
+    dma.init(lane, wave, a.ldqkv);
     const bool qok = q < a.T;
     bf16x8 qf[HH][G::KS];
     float cs[HH], nl[HH];
@@ -749,7 +883,7 @@ __global__ __launch_bounds__(256, 1) void rollout_headmax_kernel(AttnArgs a, flo
     float rs = 0.f;
     auto stage = [&](int t, int buf) {
 #pragma unroll
-        for (int h = 0; h < HH; ++h) dma.issue(qkv_b + HD + h * DP, a.ldqkv, 32 * t, a.T, sK[buf][h]);
+        for (int h = 0; h < HH; ++h) dma.issue(qkv_b + HD + h * DP, 32 * t, a.T, sK[buf][h]);
     };
     stage(0, 0);
 #pragma unroll
@@ -860,3 +994,12 @@ int launch_rollout_vecmat(const float* A, const float* rowsum, const float* v, f
     hipLaunchKernelGGL(rollout_vecmat_kernel, grid, dim3(256), sizeof(float) * T, s, A, rowsum, v, u, T, TP);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
+
+#ifdef V1T_KPROF
+extern "C" int v1t_kprof_read(unsigned long long* out, int n) {
+    const int total = 4 * KP_NT * KP_NP;
+    if (n < total) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kprof), sizeof(unsigned long long) * total) != hipSuccess) return -2;
+    return total;
+}
+#endif
