@@ -112,6 +112,14 @@ int v1t_gaussian2d_backward(const float* z, long long zsb, long long zsc, int B,
                             int N, const float* grid, const float* feat, int FS, const float* gout,
                             float* dz, long long dzsb, long long dzsc, float* dgrid, float* dfeat,
                             float* dbias, void* stream);
+/* Same with `ws` = v1t_gaussian2d_backward_ws_bytes() bytes of scratch: the taps are counting-sorted by cell (per image)
+ * into the scratch and dz is summed per run of equal cells, one atomic row per run (~20 MB) instead of 4*C*N*B
+ * float atomics (317 MB at N = 8000, B = 16). The form the training path uses. */
+long long v1t_gaussian2d_backward_ws_bytes(int B, int H, int W, int N);
+int v1t_gaussian2d_backward_ws(const float* z, long long zsb, long long zsc, int B, int C, int H, int W,
+                               int N, const float* grid, const float* feat, int FS, const float* gout,
+                               float* dz, long long dzsb, long long dzsc, float* dgrid, float* dfeat,
+                               float* dbias, void* ws, long long ws_bytes, void* stream);
 
 /* Readout sample positions (gaussian2d.py:188-235, 265-268): mu from the grid predictor
  * (Linear(gd,30) -> ELU -> Linear(30,2) -> tanh on the normalised cortical coordinates src (N,gd); gd == 0:

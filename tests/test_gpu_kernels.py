@@ -107,7 +107,7 @@ def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
         assert rel_to_max(dscale.cpu(), gs.cpu()) < 2e-2
 
 
-@pytest.mark.parametrize("B,C,H,W,N", [(3, 155, 29, 57, 1000), (2, 64, 29, 57, 257), (1, 40, 15, 29, 3)])
+@pytest.mark.parametrize("B,C,H,W,N", [(3, 155, 29, 57, 1000), (2, 64, 29, 57, 257), (1, 40, 15, 29, 3), (2, 155, 5, 7, 900)])
 def test_readout(ctx, B, C, H, W, N):
     from oracle import v1t_oracle as O
 
@@ -136,6 +136,17 @@ def test_readout(ctx, B, C, H, W, N):
     assert rel_to_max(dgrid.cpu(), gg.cpu()) < 5e-6
     assert rel_to_max(dfeat[:, :C].cpu(), gf.cpu()) < 5e-6
     assert rel_to_max(dbias.cpu(), go.sum(0).cpu()) < 5e-6
+    # scratch form: dz gathered through the inverted tap index (the 5x7 map overflows the 64-entry cell lists,
+    # which exercises the atomic overflow path as well)
+    nb = lib.v1t_gaussian2d_backward_ws_bytes(B, H, W, N)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    dz2, dgrid2, dfeat2, dbias2 = torch.zeros_like(zl), torch.empty_like(grid), torch.zeros_like(feat), torch.zeros_like(bias)
+    L.check(lib.v1t_gaussian2d_backward_ws(zl.data_ptr(), H * W * C, C, B, C, H, W, N, grid.data_ptr(), feat.data_ptr(), FS, go.data_ptr(), dz2.data_ptr(), H * W * C, C,
+                                           dgrid2.data_ptr(), dfeat2.data_ptr(), dbias2.data_ptr(), ws.data_ptr(), nb, L.stream()))
+    assert rel_to_max(dz2.permute(0, 3, 1, 2).cpu(), gz.cpu()) < 5e-6
+    assert rel_to_max(dgrid2.cpu(), gg.cpu()) < 5e-6
+    assert rel_to_max(dfeat2[:, :C].cpu(), gf.cpu()) < 5e-6
+    assert rel_to_max(dbias2.cpu(), go.sum(0).cpu()) < 5e-6
 
 
 @pytest.mark.parametrize("B,T,D,DP", [(2, 1654, 64, 64), (2, 1654, 155, 160), (3, 100, 40, 64)])

@@ -724,15 +724,21 @@ int v1t_gaussian2d_forward(const float* z, long long zsb, long long zsc, int B, 
     return launch_readout_fwd(a, (hipStream_t)stream);
 }
 
-int v1t_gaussian2d_backward(const float* z, long long zsb, long long zsc, int B, int C, int H, int W, int N, const float* grid,
-                            const float* feat, int FS, const float* gout, float* dz, long long dzsb, long long dzsc,
-                            float* dgrid, float* dfeat, float* dbias, void* stream) {
-    if (!z || !grid || !feat || !gout) return V1T_ERR_ARG;
+int v1t_gaussian2d_backward_ws(const float* z, long long zsb, long long zsc, int B, int C, int H, int W, int N, const float* grid,
+                               const float* feat, int FS, const float* gout, float* dz, long long dzsb, long long dzsc,
+                               float* dgrid, float* dfeat, float* dbias, void* ws, long long ws_bytes, void* stream) {
+    if (!z || !grid || !feat || !gout || ws_bytes < 0) return V1T_ERR_ARG;
     ReadoutArgs a{};
     a.z = z; a.zsb = zsb; a.zsc = zsc; a.B = B; a.C = C; a.H = H; a.W = W; a.N = N; a.grid = grid; a.feat = feat; a.FS = FS;
     a.gout = gout; a.dz = dz; a.dzsb = dzsb; a.dzsc = dzsc; a.dgrid = dgrid; a.dfeat = dfeat; a.dbias = dbias;
-    return launch_readout_bwd(a, (hipStream_t)stream);
+    return launch_readout_bwd(a, ws, (size_t)ws_bytes, (hipStream_t)stream);
 }
+int v1t_gaussian2d_backward(const float* z, long long zsb, long long zsc, int B, int C, int H, int W, int N, const float* grid,
+                            const float* feat, int FS, const float* gout, float* dz, long long dzsb, long long dzsc,
+                            float* dgrid, float* dfeat, float* dbias, void* stream) {
+    return v1t_gaussian2d_backward_ws(z, zsb, zsc, B, C, H, W, N, grid, feat, FS, gout, dz, dzsb, dzsc, dgrid, dfeat, dbias, nullptr, 0, stream);
+}
+long long v1t_gaussian2d_backward_ws_bytes(int B, int H, int W, int N) { return (long long)readout_bwd_ws_bytes(B, H, W, N); }
 
 int v1t_readout_grid_forward(int B, int N, int gd, const float* src, const float* W0, const float* b0, const float* W2, const float* b2,
                              const float* mu_free, const float* sigma, const float* eps, const float* shift, float* grid, void* stream) {

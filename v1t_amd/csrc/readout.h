@@ -21,4 +21,6 @@ struct ReadoutArgs {
 };
 
 int launch_readout_fwd(const ReadoutArgs& a, hipStream_t s);
-int launch_readout_bwd(const ReadoutArgs& a, hipStream_t s);
+// ws: optional scratch of readout_bwd_ws_bytes() bytes; with it dz is gathered through per-cell lists (no float atomics)
+size_t readout_bwd_ws_bytes(int B, int H, int W, int N);
+int launch_readout_bwd(const ReadoutArgs& a, void* ws, size_t ws_bytes, hipStream_t s);

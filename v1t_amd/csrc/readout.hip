@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(ReadoutArgs a) {
             df[i] += G * (t.w[0] * zv[0] + t.w[1] * zv[1] + t.w[2] * zv[2] + t.w[3] * zv[3]);
             sx += f[i] * ((1.f - t.ay) * (zv[1] - zv[0]) + t.ay * (zv[3] - zv[2]));
             sy += f[i] * ((1.f - t.ax) * (zv[2] - zv[0]) + t.ax * (zv[3] - zv[1]));
-            if (dzb && c < a.C) {
+            if (dzb && c < a.C) {  // no-scratch form only (launch_readout_bwd without ws)
                 const float gf = G * f[i];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -128,25 +128,189 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(ReadoutArgs a) {
     if (a.dbias && lane == 0) a.dbias[n] += gsum;
 }
 
+// dz without a flood of global float atomics (4 x C x N x B adds = 317 MB at N = 8000, B = 16: ~250 us at the chip-wide
+// 1.3 TB/s atomic rate; LDS float atomics are slower still, ~1 lane per clock per CU): invert the sampling.
+//   sort  : workgroup (slice s of the neurons, image b) counting-sorts its taps by cell in LDS (histogram, scan,
+//           scatter: integer LDS atomics only) into its region of the scratch: (cell, tap id, bilinear weight),
+//           taps outside the map and the padding of the region carry the sentinel cell `cells` and sort last
+//   gather: one wave per 64 consecutive sorted taps sums G[b][n] * w * F[n][:] (coalesced feature rows) while the
+//           cell stays the same and adds the finished row to dz with ONE atomic row (620 B) per (chunk, cell) run:
+//           ~20 MB of atomics for any distribution of the neurons over the map - including the freshly initialised
+//           model, whose 8000 neurons all sit on a handful of cells, which per-cell lists could not balance.
+constexpr int DZ_SLICES = 4;       // neuron slices per image (parallelism of the sort pass)
+constexpr int DZ_MAX_CELLS = 4096; // LDS histogram capacity; larger maps use the atomic form
+struct DzSort {
+    unsigned* cell;  // [B * DZ_SLICES][R]
+    unsigned* id;    // tap id = 4 * (b * N + n) + k
+    float* wt;
+    int ns, R;       // neurons per slice, region stride (multiple of 64)
+};
+
+__global__ __launch_bounds__(1024) void readout_sort_kernel(ReadoutArgs a, DzSort ix) {
+    __shared__ int hist[DZ_MAX_CELLS + 1];
+    __shared__ int wsum[16];
+    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cells = a.H * a.W;
+    const int n0 = s * ix.ns, n1 = min(a.N, n0 + ix.ns);
+    for (int i = tid; i <= cells; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int n = n0 + tid; n < n1; n += 1024) {
+        const size_t i = (size_t)b * a.N + n;
+        const Taps t = make_taps(a.grid[2 * i], a.grid[2 * i + 1], a.W, a.H);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd(&hist[t.in[q] ? t.cell[q] : cells], 1);
+    }
+    __syncthreads();
+    // exclusive scan of hist[0..cells]: each thread owns a contiguous run of PER entries
+    const int PER = (cells + 1 + 1023) / 1024;
+    int run[(DZ_MAX_CELLS + 1 + 1023) / 1024], tot = 0;
+#pragma unroll
+    for (int e = 0; e < (DZ_MAX_CELLS + 1 + 1023) / 1024; ++e) {
+        const int idx = tid * PER + e;
+        run[e] = (e < PER && idx <= cells) ? hist[idx] : 0;
+        tot += run[e];
+    }
+    int inc = tot;  // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = inc - tot;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < (DZ_MAX_CELLS + 1 + 1023) / 1024; ++e) {
+        const int idx = tid * PER + e;
+        if (e < PER && idx <= cells) {
+            hist[idx] = base;
+            base += run[e];
+        }
+    }
+    __syncthreads();
+    const size_t reg = ((size_t)b * DZ_SLICES + s) * ix.R;
+    for (int n = n0 + tid; n < n1; n += 1024) {
+        const size_t i = (size_t)b * a.N + n;
+        const Taps t = make_taps(a.grid[2 * i], a.grid[2 * i + 1], a.W, a.H);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = t.in[q] ? t.cell[q] : cells;
+            const int slot = atomicAdd(&hist[c], 1);
+            ix.cell[reg + slot] = (unsigned)c;
+            ix.id[reg + slot] = 4u * (unsigned)i + q;
+            ix.wt[reg + slot] = t.w[q];
+        }
+    }
+    for (int p = 4 * (n1 - n0) + tid; p < ix.R; p += 1024) ix.cell[reg + p] = (unsigned)cells;  // padding
+}
+
 template <int NE>
-int launch_t(const ReadoutArgs& a, bool bwd, hipStream_t s) {
+__global__ __launch_bounds__(256) void readout_dz_gather_kernel(ReadoutArgs a, DzSort ix) {
+    const int lane = threadIdx.x & 63;
+    const size_t chunk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t total = (size_t)a.B * DZ_SLICES * ix.R;
+    if (chunk * 64 >= total) return;
+    const unsigned cells = a.H * a.W;
+    const unsigned rowb = (unsigned)(chunk * 64 / ((size_t)DZ_SLICES * ix.R)) * cells;  // image of this chunk's region
+    const unsigned rows = rowb + cells;
+    // lane j holds tap j of the chunk; key = global row (image * cells + cell), >= rows for sentinels
+    const size_t me = chunk * 64 + lane;
+    const unsigned key = rowb + ix.cell[me];
+    const unsigned id = key < rows ? ix.id[me] : 0u;
+    const float gw = key < rows ? ix.wt[me] * a.gout[id >> 2] : 0.f;
+    const unsigned nn = (id >> 2) % (unsigned)a.N;
+    float acc[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) acc[j] = 0.f;
+    unsigned cur = __builtin_amdgcn_readfirstlane(key);
+    auto flush = [&](unsigned row) {
+        float* dzr = a.dz + (size_t)(row / cells) * a.dzsb + (size_t)(row % cells) * a.dzsc;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int c = lane + 64 * j;
+            if (c < a.C) atomicAdd(&dzr[c], acc[j]);
+            acc[j] = 0.f;
+        }
+    };
+    for (int t0 = 0; t0 < 64; t0 += 4) {  // four feature rows in flight
+        unsigned kq[4], nq[4], gq[4];
+        float f[4][NE];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            kq[u] = __builtin_amdgcn_readlane(key, t0 + u);
+            nq[u] = __builtin_amdgcn_readlane(nn, t0 + u);
+            gq[u] = __builtin_amdgcn_readlane(__float_as_uint(gw), t0 + u);
+        }
+        if (kq[0] >= rows) break;  // sentinels and padding sort to the end of the region
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int c = lane + 64 * j;
+                f[u][j] = (c < a.C) ? a.feat[(size_t)nq[u] * a.FS + c] : 0.f;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (kq[u] >= rows) break;
+            if (kq[u] != cur) {
+                flush(cur);
+                cur = kq[u];
+            }
+            const float g = __uint_as_float(gq[u]);
+#pragma unroll
+            for (int j = 0; j < NE; ++j) acc[j] += g * f[u][j];
+        }
+    }
+    if (cur < rows) flush(cur);
+}
+
+DzSort sort_plan(void* ws, int B, int N) {
+    DzSort d;
+    d.ns = (N + DZ_SLICES - 1) / DZ_SLICES;
+    d.R = (4 * d.ns + 63) / 64 * 64;
+    const size_t arr = (size_t)B * DZ_SLICES * d.R * 4;
+    char* p = (char*)ws;
+    d.cell = (unsigned*)p; d.id = (unsigned*)(p + arr); d.wt = (float*)(p + 2 * arr);
+    return d;
+}
+
+template <int NE>
+int launch_t(const ReadoutArgs& a, bool bwd, void* ws, size_t ws_bytes, hipStream_t s) {
     const dim3 grid((a.N + 3) / 4);
-    if (bwd) hipLaunchKernelGGL(readout_bwd_kernel<NE>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(readout_fwd_kernel<NE>, grid, dim3(256), 0, s, a);
+    if (!bwd) {
+        hipLaunchKernelGGL(readout_fwd_kernel<NE>, grid, dim3(256), 0, s, a);
+    } else if (a.dz && ws && a.H * a.W <= DZ_MAX_CELLS && ws_bytes >= readout_bwd_ws_bytes(a.B, a.H, a.W, a.N)) {
+        const DzSort ix = sort_plan(ws, a.B, a.N);
+        ReadoutArgs a2 = a;
+        a2.dz = nullptr;
+        hipLaunchKernelGGL(readout_sort_kernel, dim3(DZ_SLICES, a.B), dim3(1024), 0, s, a, ix);
+        hipLaunchKernelGGL(readout_bwd_kernel<NE>, grid, dim3(256), 0, s, a2);
+        const size_t chunks = (size_t)a.B * DZ_SLICES * ix.R / 64;
+        hipLaunchKernelGGL(readout_dz_gather_kernel<NE>, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, a, ix);
+    } else {
+        hipLaunchKernelGGL(readout_bwd_kernel<NE>, grid, dim3(256), 0, s, a);
+    }
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 
-int dispatch(const ReadoutArgs& a, bool bwd, hipStream_t s) {
+int dispatch(const ReadoutArgs& a, bool bwd, void* ws, size_t ws_bytes, hipStream_t s) {
     if (a.C > 256 || a.N <= 0) return a.N <= 0 ? V1T_OK : V1T_ERR_UNSUPPORTED;
     switch ((a.C + 63) / 64) {
-        case 1: return launch_t<1>(a, bwd, s);
-        case 2: return launch_t<2>(a, bwd, s);
-        case 3: return launch_t<3>(a, bwd, s);
-        default: return launch_t<4>(a, bwd, s);
+        case 1: return launch_t<1>(a, bwd, ws, ws_bytes, s);
+        case 2: return launch_t<2>(a, bwd, ws, ws_bytes, s);
+        case 3: return launch_t<3>(a, bwd, ws, ws_bytes, s);
+        default: return launch_t<4>(a, bwd, ws, ws_bytes, s);
     }
 }
 
 }  // namespace
 
-int launch_readout_fwd(const ReadoutArgs& a, hipStream_t s) { return dispatch(a, false, s); }
-int launch_readout_bwd(const ReadoutArgs& a, hipStream_t s) { return dispatch(a, true, s); }
+size_t readout_bwd_ws_bytes(int B, int H, int W, int N) {
+    (void)H; (void)W;
+    const DzSort d = sort_plan(nullptr, B, N);
+    return 3 * (size_t)B * DZ_SLICES * d.R * 4 + 256;
+}
+int launch_readout_fwd(const ReadoutArgs& a, hipStream_t s) { return dispatch(a, false, nullptr, 0, s); }
+int launch_readout_bwd(const ReadoutArgs& a, void* ws, size_t ws_bytes, hipStream_t s) { return dispatch(a, true, ws, ws_bytes, s); }

@@ -113,10 +113,13 @@ class _Gaussian2dFn(torch.autograd.Function):
         need_feat = ctx.needs_input_grad[2]
         dfeat = torch.zeros_like(feat_st) if need_feat else None
         dbias = torch.zeros_like(bias) if (bias is not None and need_bias) else None
+        lib = L.load()
+        ws_bytes = lib.v1t_gaussian2d_backward_ws_bytes(B, H, W, N) if need_z else 0
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=zbuf.device) if ws_bytes else None  # inverted tap index (csrc/readout.hip)
         L.check(
-            L.load().v1t_gaussian2d_backward(zbuf.data_ptr() + 4 * zoff, zsb, zsc, B, Cc, H, W, N, grid.data_ptr(), feat_st.data_ptr(), FS,
-                                             gout.data_ptr(), (dz.data_ptr() + 4 * zoff) if need_z else None, zsb, zsc,
-                                             L.ptr(dgrid), L.ptr(dfeat), L.ptr(dbias), L.stream()),
+            lib.v1t_gaussian2d_backward_ws(zbuf.data_ptr() + 4 * zoff, zsb, zsc, B, Cc, H, W, N, grid.data_ptr(), feat_st.data_ptr(), FS,
+                                           gout.data_ptr(), (dz.data_ptr() + 4 * zoff) if need_z else None, zsb, zsc,
+                                           L.ptr(dgrid), L.ptr(dfeat), L.ptr(dbias), L.ptr(ws), ws_bytes, L.stream()),
             "gaussian2d_backward",
         )
         # d features is returned through the storage-shaped tensor; the parameter is a view of it
