@@ -11,12 +11,10 @@
 
 namespace {
 
-constexpr int BM = 128;
-constexpr int BK = 32;
-constexpr int LS = BK + 8;  // LDS row stride in elements (80 B)
+constexpr int FRAG_BM = 128;  // row tile of the kernels that read / write fragment-order buffers (NW = 4)
 
 DEVFN size_t frag_index(const GemmNTArgs& g, int m0, int n0, int nb, int wave, int lane) {
-    return ((((size_t)(m0 / BM) * (g.N / 32) + (n0 / 32 + nb)) * 4 + wave) * 64 + lane) * 16;
+    return ((((size_t)(m0 / FRAG_BM) * (g.N / 32) + (n0 / 32 + nb)) * 4 + wave) * 64 + lane) * 16;
 }
 
 template <int NBLK, int EPI>
@@ -88,11 +86,17 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
 }
 
 
-template <int NBLK, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs g) {
+// NW waves per workgroup = 32*NW rows (only 4 is launched: 64-row workgroups measured the same time on the
+// single-column-tile GEMMs, which are bound by how they read A, not by workgroups in flight).
+template <int NBLK, int EPI, int NW, int BK>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
+    constexpr int BM = 32 * NW, NT = 64 * NW;
+    constexpr int LS = BK + 8, KC = BK / 8;  // LDS row stride (16-B pad: 80 / 144 B), 16-B chunks per row
+    constexpr int A_ITERS = BM * KC / NT;
     constexpr int BN = 32 * NBLK;
-    constexpr int B_CHUNKS = BN * 4;                  // 16-B chunks in a B tile
-    constexpr int B_ITERS = (B_CHUNKS + 255) / 256;
+    constexpr int B_CHUNKS = BN * KC;                 // 16-B chunks in a B tile
+    constexpr int B_ITERS = (B_CHUNKS + NT - 1) / NT;
+    static_assert(NW == 4 || (EPI != EPI_BIAS_GELU && EPI != EPI_DGELU), "fragment-order buffers assume 128-row tiles");
     __shared__ __attribute__((aligned(16))) bf16_t sA[2][BM * LS];
     __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LS];
 
@@ -116,30 +120,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs g) {
                 resv[nb][r] = (row < g.M) ? g.res[(size_t)row * g.ldres + n0 + 32 * nb + (lane & 31)] : 0.f;
             }
     }
-    u32x4 ra[2], rb[B_ITERS];
+    u32x4 ra[A_ITERS], rb[B_ITERS];
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int c = tid + NT * i, row = c / KC, kc = c % KC;
             const int gr = m0 + row;
             ra[i] = (gr < g.M) ? *(const u32x4*)(g.A + (size_t)gr * g.lda + k0 + 8 * kc) : u32x4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            const int c = tid + NT * i, row = c / KC, kc = c % KC;
             if (c < B_CHUNKS) rb[i] = *(const u32x4*)(g.B + (size_t)(n0 + row) * g.ldb + k0 + 8 * kc);
         }
     };
     auto swrite = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int c = tid + NT * i, row = c / KC, kc = c % KC;
             *(u32x4*)(&sA[buf][row * LS + 8 * kc]) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            const int c = tid + NT * i, row = c / KC, kc = c % KC;
             if (c < B_CHUNKS) *(u32x4*)(&sB[buf][row * LS + 8 * kc]) = rb[i];
         }
     };
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs g) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             const bf16x8 a = *(const bf16x8*)(&sA[buf][32 * wave * LS + frag_off + 16 * ks]);
 #pragma unroll
             for (int nb = 0; nb < NBLK; ++nb) {
@@ -176,11 +180,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs g) {
 
 // Split-bf16 variant (see GemmNTArgs): single LDS buffer (hi + lo planes of A and B), next tile's global
 // loads in flight during the MFMAs, two barriers per K-tile.
-template <int NBLK, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_split_kernel(GemmNTArgs g) {
+template <int NBLK, int EPI, int NW, int BK>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_split_kernel(GemmNTArgs g) {
+    constexpr int BM = 32 * NW, NT = 64 * NW;
+    constexpr int LS = BK + 8, KC = BK / 8;
+    constexpr int A_ITERS = BM * KC / NT;
     constexpr int BN = 32 * NBLK;
-    constexpr int B_CHUNKS = BN * 4;
-    constexpr int B_ITERS = (B_CHUNKS + 255) / 256;
+    constexpr int B_CHUNKS = BN * KC;
+    constexpr int B_ITERS = (B_CHUNKS + NT - 1) / NT;
+    static_assert(NW == 4 || (EPI != EPI_BIAS_GELU && EPI != EPI_DGELU), "fragment-order buffers assume 128-row tiles");
     __shared__ __attribute__((aligned(16))) bf16_t sA[2][BM * LS];   // [plane]
     __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,12 +210,12 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(GemmNTArgs g) {
                 resv[nb][r] = (row < g.M) ? g.res[(size_t)row * g.ldres + n0 + 32 * nb + (lane & 31)] : 0.f;
             }
     }
-    u32x4 ra[2][2], rb[2][B_ITERS];
+    u32x4 ra[2][A_ITERS], rb[2][B_ITERS];
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int c = tid + NT * i, row = c / KC, kc = c % KC;
             const int gr = m0 + row;
             const size_t off = (size_t)gr * g.lda + k0 + 8 * kc;
             ra[0][i] = (gr < g.M) ? *(const u32x4*)(g.A + off) : u32x4{0, 0, 0, 0};
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(GemmNTArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            const int c = tid + NT * i, row = c / KC, kc = c % KC;
             if (c < B_CHUNKS) {
                 const size_t off = (size_t)(n0 + row) * g.ldb + k0 + 8 * kc;
                 rb[0][i] = *(const u32x4*)(g.B + off);
@@ -227,13 +235,13 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(GemmNTArgs g) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            for (int i = 0; i < A_ITERS; ++i) {
+                const int c = tid + NT * i, row = c / KC, kc = c % KC;
                 *(u32x4*)(&sA[pl][row * LS + 8 * kc]) = ra[pl][i];
             }
 #pragma unroll
             for (int i = 0; i < B_ITERS; ++i) {
-                const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+                const int c = tid + NT * i, row = c / KC, kc = c % KC;
                 if (c < B_CHUNKS) *(u32x4*)(&sB[pl][row * LS + 8 * kc]) = rb[pl][i];
             }
         }
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(GemmNTArgs g) {
         __syncthreads();
         if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             const bf16x8 ah = *(const bf16x8*)(&sA[0][32 * wave * LS + frag_off + 16 * ks]);
             const bf16x8 al = *(const bf16x8*)(&sA[1][32 * wave * LS + frag_off + 16 * ks]);
 #pragma unroll
@@ -267,31 +275,45 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(GemmNTArgs g) {
     gemm_epilogue<NBLK, EPI>(g, acc, resv, m0, n0, wave, lane);
 }
 
-template <int NBLK>
-int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
-    const int BN = 32 * NBLK;
-    const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
+template <int NBLK, int NW, int BK>
+int launch_nt_nw(const GemmNTArgs& a, int epi, hipStream_t s) {
+    const int BN = 32 * NBLK, BMW = 32 * NW;
+    const int grid = ((a.M + BMW - 1) / BMW) * (a.N / BN);
     if (grid <= 0) return V1T_OK;
+    const dim3 blk(64 * NW);
     if (a.A_lo) {
         if (!a.B_lo) return V1T_ERR_ARG;
         switch (epi) {
-            case EPI_BF16: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BF16>), dim3(grid), dim3(256), 0, s, a); break;
-            case EPI_F32: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_F32>), dim3(grid), dim3(256), 0, s, a); break;
-            case EPI_BIAS_RES: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BIAS_RES>), dim3(grid), dim3(256), 0, s, a); break;
-            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, a); break;
+            case EPI_BF16: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BF16, NW, BK>), dim3(grid), blk, 0, s, a); break;
+            case EPI_F32: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_F32, NW, BK>), dim3(grid), blk, 0, s, a); break;
+            case EPI_BIAS_RES: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BIAS_RES, NW, BK>), dim3(grid), blk, 0, s, a); break;
+            case EPI_BIAS_GELU:
+                if constexpr (NW == 4) { hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BIAS_GELU, 4, BK>), dim3(grid), blk, 0, s, a); break; }
+                return V1T_ERR_ARG;
             default: return V1T_ERR_ARG;
         }
         return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
     }
     switch (epi) {
-        case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BF16>), dim3(grid), dim3(256), 0, s, a); break;
-        case EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_F32>), dim3(grid), dim3(256), 0, s, a); break;
-        case EPI_BIAS_RES: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_RES>), dim3(grid), dim3(256), 0, s, a); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, a); break;
-        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_DGELU>), dim3(grid), dim3(256), 0, s, a); break;
+        case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BF16, NW, BK>), dim3(grid), blk, 0, s, a); break;
+        case EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_F32, NW, BK>), dim3(grid), blk, 0, s, a); break;
+        case EPI_BIAS_RES: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_RES, NW, BK>), dim3(grid), blk, 0, s, a); break;
+        case EPI_BIAS_GELU:
+            if constexpr (NW == 4) { hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_GELU, 4, BK>), dim3(grid), blk, 0, s, a); break; }
+            return V1T_ERR_ARG;
+        case EPI_DGELU:
+            if constexpr (NW == 4) { hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_DGELU, 4, BK>), dim3(grid), blk, 0, s, a); break; }
+            return V1T_ERR_ARG;
         default: return V1T_ERR_ARG;
     }
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+template <int NBLK>
+int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
+    // K-tile 64 where K allows: 128 B (a whole line) of every A row per tile instead of 64 B and half the barriers
+    static const int force_bk = std::getenv("V1T_GEMM_BK") ? atoi(std::getenv("V1T_GEMM_BK")) : 0;  // dev switch
+    const bool bk64 = a.K % 64 == 0 && force_bk != 32;
+    return bk64 ? launch_nt_nw<NBLK, 4, 64>(a, epi, s) : launch_nt_nw<NBLK, 4, 32>(a, epi, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -567,7 +589,7 @@ int launch_gemm_nt(const GemmNTArgs& a_, int epi, hipStream_t s) {
     GemmNTArgs a = a_;
     static const int dbg = std::getenv("V1T_DBG_GEMM") ? std::atoi(std::getenv("V1T_DBG_GEMM")) : 0;
     a.dbg = dbg;
-    if (a.K % BK != 0 || a.N % 32 != 0 || (a.lda % 8) || (a.ldb % 8)) return V1T_ERR_ARG;
+    if (a.K % 32 != 0 || a.N % 32 != 0 || (a.lda % 8) || (a.ldb % 8)) return V1T_ERR_ARG;
     if (a.N % 160 == 0) return launch_nt_n<5>(a, epi, s);
     if (a.N % 128 == 0) return launch_nt_n<4>(a, epi, s);
     if (a.N % 64 == 0) return launch_nt_n<2>(a, epi, s);
