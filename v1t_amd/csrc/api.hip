@@ -129,7 +129,8 @@ struct ScratchLayout {
 };
 // contraction rows per workgroup of the weight-gradient GEMMs: aim at >= ~512 workgroups
 int tn_mchunk(long long R, int tiles) {
-    const int want = std::max(1, 512 / std::max(tiles, 1));
+    static const int target = std::getenv("V1T_TN_WGS") ? atoi(std::getenv("V1T_TN_WGS")) : 512;  // dev switch
+    const int want = std::max(1, target / std::max(tiles, 1));
     const int mc = (int)round_up((R + want - 1) / want, 64);
     return std::max(mc, 128);
 }

@@ -48,9 +48,16 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
                 if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = resv[nb][r] + v;
             } else if constexpr (EPI == EPI_BIAS_GELU) {
                 v += bias;
-                // gelu and gelu' share erf / exp: the backward only needs gelu'(v), stored in place of v
-                const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
-                const float gp = cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+                // gelu and gelu' share one exp: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below the 2^-17 of the
+                // hi + lo activation planes) on E = exp(-v^2/2), which is also the pdf factor of gelu'(v); libm's erff
+                // alone cost ~35 instructions per element and made this epilogue longer than the K loop
+                const float ax = fabsf(v) * 0.70710678118654752f;
+                const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+                const float E = __expf(-0.5f * v * v);
+                const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+                const float erfa = fmaf(-poly, E, 1.0f);                    // erf(|v| / sqrt 2)
+                const float cdf = 0.5f * (1.0f + copysignf(erfa, v));
+                const float gp = cdf + v * 0.3989422804014327f * E;
                 float a = v * cdf;
                 if (g.drop.thresh) a = drop_keep(g.drop.key, row, col, g.drop.thresh) ? a * g.drop.inv_keep : 0.f;
                 if (r < 8) gp0[r & 7] = (bf16_t)(ok ? gp : 0.f); else gp1[r & 7] = (bf16_t)(ok ? gp : 0.f);
