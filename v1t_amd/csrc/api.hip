@@ -54,6 +54,8 @@ struct v1t_vit {
     std::vector<TensorInfo> tensors;
     long long arena_floats, param_floats;
     long long o_cls, o_pos, o_pw, o_pb;
+    long long s_pw, s_pw_lo, s_pb;  // patch weights: bf16 hi / lo planes [DP][PD], fp32 bias [DP] (-1: VALU patch kernels)
+    int PDX;                        // row stride of the unfolded-patch matrix U (PD + ones column, padded to 128)
     std::vector<BlockOff> blk;
     long long shadow_bytes;
     std::vector<PackDesc> pack;
@@ -78,7 +80,7 @@ namespace {
 
 // -------------------------------------------------------------------------- workspace layout
 struct WsLayout {
-    long long x0, beta, hid;
+    long long x0, beta, hid, u_hi, u_lo;
     // per block
     long long blk_stride, xa, xm, xo, z1, qkv, o, lse2, mean1, rstd1, z2, mean2, rstd2, hpre, hact;
     long long z1_lo, o_lo, z2_lo, hact_lo;  // low planes (forward-only consumers)
@@ -97,6 +99,8 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
     w.x0 = take(R * h->DP * 4);
     w.beta = take((long long)h->NB * B * h->DP * 4);
     w.hid = take((long long)h->NB * B * std::max(h->J, 1) * 4);
+    w.u_hi = take(h->s_pw >= 0 ? R * h->PDX * 2 : 0);
+    w.u_lo = take(h->s_pw >= 0 ? R * h->PDX * 2 : 0);
     const long long b0 = cur;
     w.xa = take(R * h->DP * 4) - b0;
     w.xm = take(R * h->DP * 4) - b0;
@@ -125,7 +129,7 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
 }
 
 struct ScratchLayout {
-    long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, slab, total;
+    long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, slab, pu, pgd, total;
 };
 // contraction rows per workgroup of the weight-gradient GEMMs: aim at >= ~512 workgroups
 int tn_mchunk(long long R, int tiles) {
@@ -134,7 +138,7 @@ int tn_mchunk(long long R, int tiles) {
     const int mc = (int)round_up((R + want - 1) / want, 64);
     return std::max(mc, 128);
 }
-struct TnPlan { int mc_fc2, mc_fc1, mc_proj, mc_qkv; size_t slab; };
+struct TnPlan { int mc_fc2, mc_fc1, mc_proj, mc_qkv, mc_patch; size_t slab; };
 TnPlan tn_plan(const v1t_vit* h, long long R) {
     TnPlan p;
     const int DP = h->DP, MP = h->MP, HDP = h->HDP;
@@ -142,8 +146,10 @@ TnPlan tn_plan(const v1t_vit* h, long long R) {
     p.mc_fc1 = tn_mchunk(R, (MP + 127) / 128);
     p.mc_proj = tn_mchunk(R, ((DP + 127) / 128) * h->H);
     p.mc_qkv = tn_mchunk(R, (3 * HDP + 127) / 128);
+    p.mc_patch = tn_mchunk(R, ((DP + 159) / 160) * (h->PDX / 128));
     p.slab = std::max(std::max(gemm_tn_slab_bytes((int)R, DP, MP, p.mc_fc2), gemm_tn_slab_bytes((int)R, MP, DP, p.mc_fc1)),
                       std::max(gemm_tn_slab_bytes((int)R, DP, HDP, p.mc_proj), gemm_tn_slab_bytes((int)R, 3 * HDP, DP, p.mc_qkv)));
+    if (h->s_pw >= 0) p.slab = std::max(p.slab, gemm_tn_slab_bytes((int)R, DP, h->PDX, p.mc_patch));
     return p;
 }
 
@@ -165,6 +171,8 @@ ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     s.dqkv = take(R * 3 * h->HDP * 2);
     s.dbeta = take((long long)h->NB * B * h->DP * 4);
     s.slab = take((long long)tn_plan(h, R).slab);
+    s.pu = take(h->s_pw >= 0 ? R * h->PDX * 2 : 0);
+    s.pgd = take(h->s_pw >= 0 ? R * h->DP * 2 : 0);
     s.total = cur;
     return s;
 }
@@ -382,6 +390,13 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
             b.s_fc2b = stake(DP * 4);  desc(b.fc2b, D, b.s_fc2b, 1, DP, 1, 1, DP, D, 0, 1);
         }
     }
+    h->s_pw = h->s_pw_lo = h->s_pb = -1;
+    h->PDX = (h->PD + 1 + 127) / 128 * 128;
+    if (h->PD % 32 == 0) {  // MFMA patch embedding (both patch modes store the weight as [D][C*P*P])
+        h->s_pw = stake((long long)h->DP * h->PD * 2);    desc(h->o_pw, h->PD, h->s_pw, h->DP, h->PD, h->DP, h->D, h->PD, h->PD, 0, 0);
+        h->s_pw_lo = stake((long long)h->DP * h->PD * 2); desc(h->o_pw, h->PD, h->s_pw_lo, h->DP, h->PD, h->DP, h->D, h->PD, h->PD, 0, 2);
+        h->s_pb = stake(h->DP * 4);                       desc(h->o_pb, h->D, h->s_pb, 1, h->DP, 1, 1, h->DP, h->D, 0, 1);
+    }
     h->shadow_bytes = std::max<long long>(sc, 256);
     h->d_pack = nullptr;
     *out = h;
@@ -473,7 +488,19 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
     float* xcur = (h->NB == 0) ? out : (float*)(ws + w.x0);
     pa.x = xcur;
     pa.drop = make_drop(train, h->c.p_dropout, seed, 0xFFFFu);
-    CHECK(launch_patch_embed_fwd(pa, s));
+    if (h->s_pw >= 0) {  // unfold -> split-bf16 MFMA GEMM with the bias / position / class-token / dropout epilogue
+        bf16_t* u_hi = (bf16_t*)(ws + w.u_hi);
+        bf16_t* u_lo = (bf16_t*)(ws + w.u_lo);
+        CHECK(launch_patch_unfold(pa, u_hi, u_lo, h->PDX, s));
+        GemmNTArgs g{};
+        g.A = u_hi; g.A_lo = u_lo; g.lda = h->PDX; g.B = (const bf16_t*)(sh + h->s_pw); g.B_lo = (const bf16_t*)(sh + h->s_pw_lo); g.ldb = h->PD;
+        g.M = R; g.N = DP; g.K = h->PD; g.C = xcur; g.ldc = DP;
+        g.bias = (const float*)(sh + h->s_pb); g.pos = arena + h->o_pos; g.cls = arena + h->o_cls; g.T = h->T; g.n_valid = D;
+        g.drop = pa.drop;
+        CHECK(launch_gemm_nt(g, EPI_PATCH, s));
+    } else {
+        CHECK(launch_patch_embed_fwd(pa, s));
+    }
 
     if (h->inject)
         for (int k = 0; k < h->NB; ++k) {
@@ -681,7 +708,20 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
     pa.D = D; pa.DP = DP; pa.x = (float*)gin;
     pa.drop = make_drop(train, h->c.p_dropout, seed, 0xFFFFu);
     pa.dW = grads + h->o_pw; pa.dbias = grads + h->o_pb; pa.dcls = grads + h->o_cls; pa.dpos = grads + h->o_pos;
-    CHECK(launch_patch_embed_bwd(pa, s));
+    if (h->s_pw >= 0) {  // dpos / dcls + bf16 gradient, U recomputed from the images, then dW (+ dbias through the ones column)
+        bf16_t* gd = (bf16_t*)(sc + sl.pgd);
+        bf16_t* u = (bf16_t*)(sc + sl.pu);
+        CHECK(launch_patch_bwd_pos_cast(pa, gd, s));
+        CHECK(launch_patch_unfold(pa, u, nullptr, h->PDX, s));
+        GemmTNArgs t{};
+        t.Y = gd; t.ldy = DP; t.X = u; t.ldx = h->PDX; t.M = R; t.NY = DP; t.NX = h->PDX; t.dW = grads + h->o_pw; t.ldw = h->PD;
+        t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->PDX; t.xseg_valid = h->PD; t.alpha = 1.f;
+        t.dbias = grads + h->o_pb; t.ones_col = h->PD;
+        t.m_chunk = tp.mc_patch; t.slab = slab;
+        CHECK(launch_gemm_tn(t, s));
+    } else {
+        CHECK(launch_patch_embed_bwd(pa, s));
+    }
     // ---- BehaviorMLP backward
     if (h->inject) {
         for (int k0 = 0; k0 < h->NB; k0 += BMLP_MAX_BLOCKS) {

@@ -34,6 +34,12 @@ struct PatchArgs {
 };
 int launch_patch_embed_fwd(const PatchArgs& a, hipStream_t s);
 int launch_patch_embed_bwd(const PatchArgs& a, hipStream_t s);
+// MFMA form of the patch embedding (C*P*P % 32 == 0): the unfolded patches as a bf16 matrix U [B*T][ldu]
+// (row b*T is the class token: zeros; columns >= C*P*P: a 1 in column C*P*P of every patch row, then zeros - the
+// ones column hands the bias gradient to the weight-gradient GEMM), hi and optional lo plane.
+int launch_patch_unfold(const PatchArgs& a, bf16_t* u_hi, bf16_t* u_lo, int ldu, hipStream_t s);
+// backward prologue: dpos / dcls sums over the batch and gd = bf16(dropout_bwd(g)) [B*T][DP] for the dW GEMM
+int launch_patch_bwd_pos_cast(const PatchArgs& a, bf16_t* gd, hipStream_t s);
 
 struct LnFwdArgs {
     const float* x;      // [rows][DP]

@@ -103,6 +103,59 @@ __global__ void patch_bwd_pos_kernel(PatchArgs a) {
     if (t == 0) a.dcls[d] += s;
 }
 
+// U[b*T + t][j]: thread = one 16-B chunk (8 columns) of one row
+__global__ __launch_bounds__(256) void patch_unfold_kernel(PatchArgs a, bf16_t* u_hi, bf16_t* u_lo, int ldu) {
+    const int PD = a.C * a.P * a.P, PP = a.P * a.P, L = a.NH * a.NW, T = L + 1, cpr = ldu / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.B * T * cpr) return;
+    const int jc = (int)(idx % cpr);
+    const long long row = idx / cpr;
+    const int t = (int)(row % T), b = (int)(row / T);
+    bf16x8 hi = {}, lo = {};
+    if (t > 0) {
+        const int l = t - 1, y0 = (l / a.NW) * a.stride, x0 = (l % a.NW) * a.stride;
+        const float* img = a.img + (size_t)b * a.C * a.IH * a.IW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 8 * jc + e;
+            float v = 0.f;
+            if (j < PD) {
+                const int c = j / PP, kh = (j % PP) / a.P, kw = j % a.P;
+                v = img[((size_t)c * a.IH + y0 + kh) * a.IW + x0 + kw];
+            } else if (j == PD) {
+                v = 1.f;
+            }
+            hi[e] = (bf16_t)v;
+            lo[e] = (bf16_t)(v - (float)hi[e]);
+        }
+    }
+    *(bf16x8*)(u_hi + row * ldu + 8 * jc) = hi;
+    if (u_lo) *(bf16x8*)(u_lo + row * ldu + 8 * jc) = lo;
+}
+
+// dpos / dcls as patch_bwd_pos_kernel, plus the bf16 copy of the masked gradient (pad columns zero)
+__global__ void patch_bwd_pos_cast_kernel(PatchArgs a, bf16_t* gd) {
+    const int L = a.NH * a.NW, T = L + 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * a.DP) return;
+    const int t = idx / a.DP, d = idx % a.DP;
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        const int row = b * T + t;
+        float g = 0.f;
+        if (d < a.D) {
+            g = a.x[(size_t)row * a.DP + d];
+            if (a.drop.thresh) g = drop_keep(a.drop.key, row, d, a.drop.thresh) ? g * a.drop.inv_keep : 0.f;
+        }
+        gd[(size_t)row * a.DP + d] = (bf16_t)g;
+        s += g;
+    }
+    if (d < a.D) {
+        a.dpos[(size_t)t * a.D + d] += s;
+        if (t == 0) a.dcls[d] += s;
+    }
+}
+
 // dWp[d][j] += sum_{b,l} gd[b][1+l][d] * U[b][l][j]; dbp[d] += sum gd.  Workgroup = 64 patches of one
 // image, thread = d, 16 j's at a time in registers; results are transposed through LDS so each
 // atomic wave-instruction covers 64-B runs instead of 64 different rows.
@@ -614,4 +667,15 @@ int launch_attn_dropout_mask(uint8_t* out, long long rows, long long T, AttnDrop
 int launch_dropout_mask(uint8_t* out, long long rows, long long cols, DropCfg d, hipStream_t s) {
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(nblocks(rows * cols, 4096)), dim3(256), 0, s, out, rows, cols, d);
     return ok();
+}
+
+int launch_patch_unfold(const PatchArgs& a, bf16_t* u_hi, bf16_t* u_lo, int ldu, hipStream_t s) {
+    const long long n = (long long)a.B * (a.NH * a.NW + 1) * (ldu / 8);
+    hipLaunchKernelGGL(patch_unfold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, u_hi, u_lo, ldu);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_patch_bwd_pos_cast(const PatchArgs& a, bf16_t* gd, hipStream_t s) {
+    const int T = a.NH * a.NW + 1;
+    hipLaunchKernelGGL(patch_bwd_pos_cast_kernel, dim3((T * a.DP + 255) / 256), dim3(256), 0, s, a, gd);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }

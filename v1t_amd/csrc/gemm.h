@@ -12,6 +12,8 @@ enum GemmEpi {
     EPI_BIAS_RES = 2,   // C fp32 = res + dropout(acc + bias)                       (proj, FC2)
     EPI_BIAS_GELU = 3,  // v = acc + bias; C bf16 = gelu'(v) in ACCUMULATOR-FRAGMENT order (below); C2 bf16 = dropout(gelu(v)) (FC1)
     EPI_DGELU = 4,      // C bf16 = acc * mask/keep * aux (aux = saved gelu', fragment order)          (dX of FC2)
+    EPI_PATCH = 5,      // C fp32 = dropout(acc + bias + pos[row % T]); rows with row % T == 0 are the class token:
+                        // dropout(cls + pos[0]) (their A rows are zero)                               (patch embedding)
     // Fragment order: the 16 accumulator values a lane holds for one 32x32 block are stored contiguously,
     // index (((tile_m * (N/32) + col_block) * 4 + wave) * 64 + lane) * 16 + reg. Producer (FC1) and consumer
     // (dX of FC2) share M, N and the 128-row tile, so both sides move 2 x 16 B per lane per block instead of 16
@@ -35,7 +37,7 @@ struct GemmNTArgs {
     const bf16_t* aux; int ldaux;
     float* colsum; int n_valid;   // fp32 atomics, natural column index < n_valid
     DropCfg drop;
-    int dbg;  // ablation switches (env V1T_DBG_GEMM), 0 in production
+    const float* pos; const float* cls; int T;  // EPI_PATCH: natural [T][n_valid] position table, [n_valid] class token
 };
 
 struct GemmTNArgs {

@@ -42,6 +42,14 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
                 if (ok) ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = (bf16_t)v;
             } else if constexpr (EPI == EPI_F32) {
                 if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = v;
+            } else if constexpr (EPI == EPI_PATCH) {
+                const int t = row % g.T;
+                const bool cok = col < g.n_valid;
+                if (ok) {
+                    v = cok ? (t == 0 ? g.cls[col] + g.pos[col] : v + g.bias[col] + g.pos[(size_t)t * g.n_valid + col]) : 0.f;
+                    if (g.drop.thresh && cok) v = drop_keep(g.drop.key, row, col, g.drop.thresh) ? v * g.drop.inv_keep : 0.f;
+                    ((float*)g.C)[(size_t)row * g.ldc + col] = v;
+                }
             } else if constexpr (EPI == EPI_BIAS_RES) {
                 v += bias;
                 if (g.drop.thresh) v = drop_keep(g.drop.key, row, col, g.drop.thresh) ? v * g.drop.inv_keep : 0.f;
@@ -294,6 +302,7 @@ int launch_nt_nw(const GemmNTArgs& a, int epi, hipStream_t s) {
             case EPI_BF16: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BF16, NW, BK>), dim3(grid), blk, 0, s, a); break;
             case EPI_F32: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_F32, NW, BK>), dim3(grid), blk, 0, s, a); break;
             case EPI_BIAS_RES: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BIAS_RES, NW, BK>), dim3(grid), blk, 0, s, a); break;
+            case EPI_PATCH: hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_PATCH, NW, BK>), dim3(grid), blk, 0, s, a); break;
             case EPI_BIAS_GELU:
                 if constexpr (NW == 4) { hipLaunchKernelGGL((gemm_nt_split_kernel<NBLK, EPI_BIAS_GELU, 4, BK>), dim3(grid), blk, 0, s, a); break; }
                 return V1T_ERR_ARG;
@@ -592,10 +601,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTNArgs g, int gx, in
 }  // namespace
 
 
-int launch_gemm_nt(const GemmNTArgs& a_, int epi, hipStream_t s) {
-    GemmNTArgs a = a_;
-    static const int dbg = std::getenv("V1T_DBG_GEMM") ? std::atoi(std::getenv("V1T_DBG_GEMM")) : 0;
-    a.dbg = dbg;
+int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 != 0 || a.N % 32 != 0 || (a.lda % 8) || (a.ldb % 8)) return V1T_ERR_ARG;
     if (a.N % 160 == 0) return launch_nt_n<5>(a, epi, s);
     if (a.N % 128 == 0) return launch_nt_n<4>(a, epi, s);
