@@ -166,10 +166,23 @@ DEVFN float gelu_erf_grad(float x) {
     const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+// Sum over the 64 lanes, returned to every lane. DPP adds (quad swaps, half-row and row mirrors, row broadcasts)
+// leave the total in lane 63, one v_readlane hands it back: 6 VALU + 1, no LDS traffic. The __shfl_xor butterfly
+// it replaces compiles to six ds_bpermute round trips (~100 cycles each on an otherwise idle wave).
+// EXEC must be all ones (every caller reduces with inactive lanes contributing zeros).
+template <int CTRL, int ROW_MASK>
+DEVFN float dpp_add(float v) {
+    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(x);
+}
 DEVFN float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);  // row_mirror: every lane holds its row's sum
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 DEVFN float wave_max(float v) {
 #pragma unroll

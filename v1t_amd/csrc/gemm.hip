@@ -21,6 +21,11 @@ template <int NBLK, int EPI>
 DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 (&resv)[NBLK], int m0, int n0, int wave, int lane) {
     // ---- epilogue: col = n0 + 32nb + (lane&31); row = m0 + 32wave + acc_row(r, lane)
     const int rbase = m0 + 32 * wave;
+    int trow[16] = {};  // EPI_PATCH: token index of each accumulator row (one modulo per row, not per element)
+    if constexpr (EPI == EPI_PATCH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) trow[r] = (rbase + acc_row(r, lane)) % g.T;
+    }
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb) {
         const int col = n0 + 32 * nb + (lane & 31);
@@ -43,7 +48,7 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
             } else if constexpr (EPI == EPI_F32) {
                 if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = v;
             } else if constexpr (EPI == EPI_PATCH) {
-                const int t = row % g.T;
+                const int t = trow[r];
                 const bool cok = col < g.n_valid;
                 if (ok) {
                     v = cok ? (t == 0 ? g.cls[col] + g.pos[col] : v + g.bias[col] + g.pos[(size_t)t * g.n_valid + col]) : 0.f;

@@ -85,31 +85,40 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
     float s00 = 0, s01 = 0, s10 = 0, s11 = 0;
     if (ok) { s00 = a.sigma[4 * n]; s01 = a.sigma[4 * n + 1]; s10 = a.sigma[4 * n + 2]; s11 = a.sigma[4 * n + 3]; }
     float dmu0 = 0.f, dmu1 = 0.f, ds00 = 0.f, ds01 = 0.f, ds10 = 0.f, ds11 = 0.f;
-    for (int b = 0; b < a.B; ++b) {
-        float d0 = 0.f, d1 = 0.f;
-        if (ok) {
-            d0 = a.dgrid[((size_t)b * a.N + n) * 2];
-            d1 = a.dgrid[((size_t)b * a.N + n) * 2 + 1];
+    // images in chunks of 8: all loads of a chunk are issued before the first wave reduction / atomic, which the
+    // compiler may not move loads across (32 workgroups: this kernel runs at the latency of its own chain)
+    for (int b0 = 0; b0 < a.B; b0 += 8) {
+        float dd0[8], dd1[8], ee0[8], ee1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + u;
+            const bool v = ok && b < a.B;
+            const size_t i2 = ((size_t)(v ? b : 0) * a.N + (v ? n : 0)) * 2;
+            dd0[u] = v ? a.dgrid[i2] : 0.f;
+            dd1[u] = v ? a.dgrid[i2 + 1] : 0.f;
+            ee0[u] = (v && a.eps) ? a.eps[i2] : 0.f;
+            ee1[u] = (v && a.eps) ? a.eps[i2 + 1] : 0.f;
         }
-        if (a.dshift) {  // d shift[b] = sum_n d grid (the shift is added after the clamp)
-            const float t0 = wave_sum(d0), t1 = wave_sum(d1);
-            if (lane == 0) {
-                atomicAdd(&a.dshift[2 * b], t0);
-                atomicAdd(&a.dshift[2 * b + 1], t1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + u;
+            if (b >= a.B) break;
+            const float d0 = dd0[u], d1 = dd1[u], e0 = ee0[u], e1 = ee1[u];
+            if (a.dshift) {  // d shift[b] = sum_n d grid (the shift is added after the clamp)
+                const float t0 = wave_sum(d0), t1 = wave_sum(d1);
+                if (lane == 0) {
+                    atomicAdd(&a.dshift[2 * b], t0);
+                    atomicAdd(&a.dshift[2 * b + 1], t1);
+                }
             }
+            const float p0 = mu[0] + s00 * e0 + s01 * e1;
+            const float p1 = mu[1] + s10 * e0 + s11 * e1;
+            // torch.clamp passes the gradient on the closed interval [-1, 1]
+            const float g0 = (p0 >= -1.f && p0 <= 1.f) ? d0 : 0.f;
+            const float g1 = (p1 >= -1.f && p1 <= 1.f) ? d1 : 0.f;
+            dmu0 += g0; dmu1 += g1;
+            ds00 += g0 * e0; ds01 += g0 * e1; ds10 += g1 * e0; ds11 += g1 * e1;
         }
-        float e0 = 0.f, e1 = 0.f, p0 = mu[0], p1 = mu[1];
-        if (a.eps && ok) {
-            e0 = a.eps[((size_t)b * a.N + n) * 2];
-            e1 = a.eps[((size_t)b * a.N + n) * 2 + 1];
-            p0 += s00 * e0 + s01 * e1;
-            p1 += s10 * e0 + s11 * e1;
-        }
-        // torch.clamp passes the gradient on the closed interval [-1, 1]
-        const float g0 = (p0 >= -1.f && p0 <= 1.f) ? d0 : 0.f;
-        const float g1 = (p1 >= -1.f && p1 <= 1.f) ? d1 : 0.f;
-        dmu0 += g0; dmu1 += g1;
-        ds00 += g0 * e0; ds01 += g0 * e1; ds10 += g1 * e0; ds11 += g1 * e1;
     }
     if (ok && a.dsigma) {
         a.dsigma[4 * n] = ds00; a.dsigma[4 * n + 1] = ds01; a.dsigma[4 * n + 2] = ds10; a.dsigma[4 * n + 3] = ds11;
@@ -123,9 +132,12 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
     const float q1 = ok ? dmu1 * (1.f - mu[1] * mu[1]) : 0.f;
     float x[3] = {0.f, 0.f, 0.f};
     if (ok) for (int i = 0; i < a.gd; ++i) x[i] = a.src[(size_t)n * a.gd + i];
+    // per-wave sums go to LDS; one atomic per accumulator per workgroup after the loop
+    __shared__ float sacc[4][GRID_HID][6];
+    __shared__ float sq[4][2];
     {
         const float t0 = wave_sum(q0), t1 = wave_sum(q1);
-        if (lane == 0) { atomicAdd(&a.db2[0], t0); atomicAdd(&a.db2[1], t1); }
+        if (lane == 0) { sq[wave][0] = t0; sq[wave][1] = t1; }
     }
 #pragma unroll 2
     for (int j = 0; j < GRID_HID; ++j) {
@@ -134,16 +146,24 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
         const float de = p > 0.f ? 1.f : e + 1.f;  // ELU'
         const float dh = (q0 * sW2[j] + q1 * sW2[GRID_HID + j]) * de;
         const float w20 = wave_sum(q0 * e), w21 = wave_sum(q1 * e), bb = wave_sum(dh);
-        float wx[3];
+        float wx[3] = {0.f, 0.f, 0.f};
         for (int i = 0; i < a.gd; ++i) wx[i] = wave_sum(dh * x[i]);
         if (lane == 0) {
-            atomicAdd(&a.dW2[j], w20);
-            atomicAdd(&a.dW2[GRID_HID + j], w21);
-            atomicAdd(&a.db0[j], bb);
-            for (int i = 0; i < a.gd; ++i) atomicAdd(&a.dW0[j * a.gd + i], wx[i]);
+            sacc[wave][j][0] = w20; sacc[wave][j][1] = w21; sacc[wave][j][2] = bb;
+            sacc[wave][j][3] = wx[0]; sacc[wave][j][4] = wx[1]; sacc[wave][j][5] = wx[2];
         }
     }
-    (void)sred; (void)wave;
+    __syncthreads();
+    if (tid < 2) atomicAdd(&a.db2[tid], sq[0][tid] + sq[1][tid] + sq[2][tid] + sq[3][tid]);
+    if (tid < GRID_HID * 6) {
+        const int j = tid / 6, c = tid % 6;
+        const float v = sacc[0][j][c] + sacc[1][j][c] + sacc[2][j][c] + sacc[3][j][c];
+        if (c == 0) atomicAdd(&a.dW2[j], v);
+        else if (c == 1) atomicAdd(&a.dW2[GRID_HID + j], v);
+        else if (c == 2) atomicAdd(&a.db0[j], v);
+        else if (c - 3 < a.gd) atomicAdd(&a.dW0[j * a.gd + c - 3], v);
+    }
+    (void)sred;
 }
 
 // shifter: one workgroup; thread b handles sample b (B <= 1024 -> loop)
