@@ -68,7 +68,7 @@ def cpu_baseline(seconds_budget: float = 30.0) -> dict:
     while True:
         step()
         n += 1
-        if time.time() - t0 > seconds_budget * 0.5 or n >= 2:
+        if time.time() - t0 > seconds_budget * 0.5 or n >= 8:  # about 10-15 s of CPU work
             break
     dt = (time.time() - t0) / n
     return {"value": round(B / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
@@ -142,6 +142,11 @@ def main():
         names = {0: "attn_fwd", 1: "attn_bwd_dq (split launches only)", 2: "attn_bwd_fused (dQ + dK/dV bodies)"}
         mult = {0: 1.0, 1: 0.5, 2: 2.5}[a.profile_class] if a.profile_class in (0, 1, 2) else 0.0
         per_launch = mult * fl["attn_fwd_per_image_block"] * args.batch_size
+        # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, KiB, separate --pmc
+        # passes: profiles/r01_pmc_attention_fetch_write.txt, tools/pmc_attn.sh); recorded, not collected live, and
+        # only valid for the shape it was measured on (16 images x 4 heads x 1654 tokens x 160 padded head dim)
+        default_shape = args.batch_size == 16 and a.neurons == 8000
+        traffic = {0: (2 * 57173.5 + 33975.5) * 1024, 2: (2 * 166139.7 + 104235.2) * 1024}.get(a.profile_class) if default_shape else None
         avg_ms = total_ms.value / max(launches.value, 1)
         achieved = per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         line = {
@@ -164,7 +169,7 @@ def main():
             "model_tflops_per_s": round(fl["train_per_image"] * images / dt / 1e12, 2),
             "model_frac_of_bf16_peak": round(fl["train_per_image"] * images / dt / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": {"kernel": names.get(a.profile_class, str(a.profile_class)), "bound": "mfma", "achieved": round(achieved, 2),
-                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches": launches.value, "avg_ms": round(avg_ms, 4), "flops_per_launch": per_launch},
         }
         if world == 1 and not a.no_cpu_baseline:
