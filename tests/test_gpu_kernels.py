@@ -83,6 +83,10 @@ def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
     lse = torch.empty(B, H, T, device=dev)
     seed, sid = 4242, 16  # attention-P streams are 8*block + 0 (include/v1t_amd.h)
     L.check(lib.v1t_attention_forward(qkv.data_ptr(), B, H, T, DP, scale.data_ptr(), int(lsa), int(lsa), p, seed, sid, o.data_ptr(), lse.data_ptr(), L.stream()))
+    # bit-reproducible (guards the hand-placed MFMA -> VALU wait states: a missing one shows up as run-to-run noise)
+    o_again, lse_again = torch.empty_like(o), torch.empty_like(lse)
+    L.check(lib.v1t_attention_forward(qkv.data_ptr(), B, H, T, DP, scale.data_ptr(), int(lsa), int(lsa), p, seed, sid, o_again.data_ptr(), lse_again.data_ptr(), L.stream()))
+    assert torch.equal(o, o_again) and torch.equal(lse, lse_again)
     mask = None
     if p > 0:
         mask = torch.empty(B * H * T, T, device=dev, dtype=torch.uint8)

@@ -79,12 +79,12 @@ struct Geo {
 // surplus lanes re-fetch the last row into slack behind the tile (size buffers with LDS_ELEMS).
 // Rows beyond T are clamped to row T-1 (finite data; every consumer masks them): only the ragged last tile
 // takes that path, recomputing its offsets.
-template <int DP, int STR, int ROWS = 32>
+template <int DP, int STR, int ROWS = 32, int NWAVES = 4>
 struct TileDma {
     static constexpr int CPR = STR / 8;                 // chunks per LDS row
     static constexpr int NCH = ROWS * CPR;              // chunks per tile
     static constexpr int NINST = (NCH + 63) / 64;       // pieces per tile
-    static constexpr int PW = (NINST + 3) / 4;          // pieces per wave
+    static constexpr int PW = (NINST + NWAVES - 1) / NWAVES;  // pieces per wave
     static constexpr int NG = (PW + 3) / 4;             // M0 groups per wave
     static constexpr int LDS_ELEMS = NINST * 512;       // tile + slack of the partial last piece
     static constexpr int BIAS = 3072;
@@ -146,6 +146,41 @@ struct TileDma {
     }
 };
 
+// Single-instruction helpers: plain fmaxf() on MFMA outputs makes hipcc emit a canonicalising v_max(x, x) per operand,
+// and element-wise (bf16_t) casts of accumulator values come out as one v_cvt_pk per ELEMENT plus v_perm to pair them.
+// HAZARD: hipcc does not see inline asm as a reader of MFMA results and inserts no wait states for it (the hardware
+// does not interlock: the max of a just-finished S tile came out different from run to run). The max helpers are
+// volatile so that they stay behind mfma_result_fence(), which every use on fresh MFMA output must be preceded by.
+DEVFN void mfma_result_fence() { asm volatile("s_nop 11" ::: "memory"); }  // 12 wait states: 8-pass XDL write -> VALU read
+DEVFN float vmax3(float a, float b, float c) {
+    float r;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+DEVFN float vmax2(float a, float b) {
+    float r;
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+DEVFN uint32_t pack_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// acc_to_b() (common.h) with explicit packed conversions
+DEVFN bf16x8 acc_to_b_pk(const f32x16& x, int s) {
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = pack_bf16(x[8 * s + 2 * j], x[8 * s + 2 * j + 1]);
+    return *(bf16x8*)&r;
+}
+// max over the two half-waves (lane l and l + 32 hold the same query): one v_permlane32_swap instead of a ds_bpermute
+DEVFN float half_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 DEVFN void zero16(f32x16& x) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = 0.f;
@@ -181,8 +216,8 @@ DEVFN void drop4(uint32_t x0, uint32_t step, uint32_t sh_even, uint32_t sh_odd, 
 
 // 1-D grid over (row block, head, image), XCD-aware: the row blocks of one (image, head) get consecutive
 // logical ids and each XCD owns a contiguous chunk of ids, so a head's K/V (or Q/dO) stays in ONE L2.
-DEVFN void decode_block(const AttnArgs& a, int bid, int nblk, int& rb, int& h, int& b) {
-    const int nrb = (a.T + 127) / 128;
+DEVFN void decode_block(const AttnArgs& a, int bid, int nblk, int& rb, int& h, int& b, int rows_per_block = 128) {
+    const int nrb = (a.T + rows_per_block - 1) / rows_per_block;
     const int lid = xcd_remap(bid, nblk);
     rb = lid % nrb;
     const int bh = lid / nrb;
@@ -191,17 +226,18 @@ DEVFN void decode_block(const AttnArgs& a, int bid, int nblk, int& rb, int& h, i
 }
 
 // ------------------------------------------------------------------------------------------
+constexpr int FWD_WAVES = 8;  // 256 queries per workgroup share each K/V tile: half the LDS-DMA pieces per wave of a 4-wave workgroup
 template <int DP, bool DROP, bool DIAG>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a) {
     using G = Geo<DP>;
-    using DmaK = TileDma<DP, G::RSTR>;
-    using DmaV = TileDma<DP, G::TSTR>;
+    using DmaK = TileDma<DP, G::RSTR, 32, FWD_WAVES>;
+    using DmaV = TileDma<DP, G::TSTR, 32, FWD_WAVES>;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][DmaK::LDS_ELEMS];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2][DmaV::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, h, b;
-    decode_block(a, blockIdx.x, gridDim.x, rb, h, b);
-    const int q = rb * 128 + 32 * wave + (lane & 31);
+    decode_block(a, blockIdx.x, gridDim.x, rb, h, b, 32 * FWD_WAVES);
+    const int q = rb * (32 * FWD_WAVES) + 32 * wave + (lane & 31);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
@@ -273,10 +309,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 s[r] = dead ? NEG_BIG : s[r];
             }
         }
-        float pmax = fmaxf(s[0], s[1]);
+        mfma_result_fence();
+        float pmax = vmax3(s[0], s[1], s[2]);
 #pragma unroll
-        for (int r = 2; r < 16; ++r) pmax = fmaxf(pmax, s[r]);
-        pmax = fmaxf(pmax, __shfl_xor(pmax, 32)) * c;
+        for (int r = 3; r < 15; r += 2) pmax = vmax3(pmax, s[r], s[r + 1]);
+        pmax = half_max(vmax2(pmax, s[15])) * c;
         KP_STAMP(2);
         if (!__all(pmax <= m2 + RESCALE_THR)) {
             const float mn = fmaxf(m2, pmax);
@@ -307,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 s[4 * g + j] = keep[j] ? p : 0.f;
             }
         }
-        const bf16x8 p0 = acc_to_b(s, 0), p1 = acc_to_b(s, 1);
+        const bf16x8 p0 = acc_to_b_pk(s, 0), p1 = acc_to_b_pk(s, 1);
         KP_STAMP(4);
 #pragma unroll
         for (int d = 0; d < G::DB; ++d) {
@@ -684,7 +721,7 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
         }
     };
     auto phase3_v = [&](const bf16x8 (&tdf)[2 * G::DB], const f32x16& dp) {
-        const bf16x8 p0 = acc_to_b(dp, 0), p1 = acc_to_b(dp, 1);
+        const bf16x8 p0 = acc_to_b_pk(dp, 0), p1 = acc_to_b_pk(dp, 1);
 #pragma unroll
         for (int d = 0; d < G::DB; ++d) {
             dv[d] = mfma32(tdf[2 * d], p0, dv[d]);
@@ -692,7 +729,7 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
         }
     };
     auto phase3_k = [&](const bf16x8 (&tqf)[2 * G::DB], const f32x16& s) {
-        const bf16x8 s0 = acc_to_b(s, 0), s1 = acc_to_b(s, 1);
+        const bf16x8 s0 = acc_to_b_pk(s, 0), s1 = acc_to_b_pk(s, 1);
 #pragma unroll
         for (int d = 0; d < G::DB; ++d) {
             dk[d] = mfma32(tqf[2 * d], s0, dk[d]);
@@ -775,9 +812,9 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
 
 template <int DP, bool DROP, bool DIAG>
 int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
-    dim3 grid(((a.T + 127) / 128) * a.H * a.B);
+    dim3 grid(((a.T + 32 * FWD_WAVES - 1) / (32 * FWD_WAVES)) * a.H * a.B);
     prof_begin(PROF_ATTN_FWD, s);
-    hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG>), grid, dim3(64 * FWD_WAVES), 0, s, a);
     prof_end(PROF_ATTN_FWD, s);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
