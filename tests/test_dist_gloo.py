@@ -69,5 +69,23 @@ def test_two_ranks_seven_mice():
     _run(2, list("ABCDEFG"))
 
 
+def test_four_ranks_seven_mice_quarter_cuts():
+    # 7 mice on 4 ranks: 28 images each, mice B, D and F cut 12+4 / 8+8 / 4+12 across neighbouring ranks
+    loads = []
+    for r in range(4):
+        sh = MouseSharding(list("ABCDEFG"), rank=r, world=4, batch_size=16, make_groups=False)
+        loads.append(sum(16 if sl is None else sl.stop - sl.start for _, sl in sh.local_units()))
+    assert loads == [28, 28, 28, 28]
+    _run(4, list("ABCDEFG"))
+
+
+def test_two_ranks_balanced_halves():
+    loads = []
+    for r in range(2):
+        sh = MouseSharding(list("ABCDEFG"), rank=r, world=2, batch_size=16, make_groups=False)
+        loads.append(sum(16 if sl is None else sl.stop - sl.start for _, sl in sh.local_units()))
+    assert loads == [56, 56]
+
+
 def test_replica_rank_shares_a_mouse():
     _run(2, ["A"])  # world > n_mice: both ranks own mouse A and split its batch 8 + 8

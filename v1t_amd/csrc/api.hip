@@ -192,6 +192,8 @@ DropCfg make_drop(bool training, float p, uint64_t seed, uint32_t stream) {
     return d;
 }
 
+// V1T_NOSPLIT=<mask> (dev, numerics ablation): bit 0/1/2/3 runs QKV / proj / FC1 / FC2 of the forward in plain bf16
+static const int g_nosplit = std::getenv("V1T_NOSPLIT") ? atoi(std::getenv("V1T_NOSPLIT")) : 0;
 // V1T_DEBUG_SYNC=1: print the launch about to be made and synchronise after it (fault localisation).
 static const bool g_debug_sync = std::getenv("V1T_DEBUG_SYNC") != nullptr;
  AttnDrop make_adrop(bool training, float p, uint64_t seed, uint32_t stream) {
@@ -537,6 +539,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         GemmNTArgs g{};
         g.A = z1; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_qkv); g.ldb = DP; g.M = R; g.N = 3 * HDP; g.K = DP; g.C = qkv; g.ldc = 3 * HDP;
         g.A_lo = (const bf16_t*)(wb + w.z1_lo); g.B_lo = (const bf16_t*)(sh + b.s_qkv_lo);
+        if (g_nosplit & 1) g.A_lo = g.B_lo = nullptr;
         CHECK(launch_gemm_nt(g, EPI_BF16, s));
 
         AttnArgs at{};
@@ -548,6 +551,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         g = GemmNTArgs{};
         g.A = o; g.lda = HDP; g.B = (const bf16_t*)(sh + b.s_proj); g.ldb = HDP; g.M = R; g.N = DP; g.K = HDP; g.C = xm; g.ldc = DP;
         g.A_lo = (const bf16_t*)(wb + w.o_lo); g.B_lo = (const bf16_t*)(sh + b.s_proj_lo);
+        if (g_nosplit & 2) g.A_lo = g.B_lo = nullptr;
         g.bias = b.s_projb >= 0 ? (const float*)(sh + b.s_projb) : nullptr; g.res = xa; g.ldres = DP;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 1);
         CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));
@@ -562,6 +566,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         g = GemmNTArgs{};
         g.A = z2; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_fc1); g.ldb = DP; g.M = R; g.N = MP; g.K = DP; g.C = hpre; g.ldc = MP;
         g.A_lo = (const bf16_t*)(wb + w.z2_lo); g.B_lo = (const bf16_t*)(sh + b.s_fc1_lo); g.C2_lo = (bf16_t*)(wb + w.hact_lo);
+        if (g_nosplit & 4) g.A_lo = g.B_lo = nullptr;
         g.C2 = hact; g.ldc2 = MP; g.bias = b.s_fc1b >= 0 ? (const float*)(sh + b.s_fc1b) : nullptr;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
         CHECK(launch_gemm_nt(g, EPI_BIAS_GELU, s));
@@ -569,6 +574,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         g = GemmNTArgs{};
         g.A = hact; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc2); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = xo; g.ldc = DP;
         g.A_lo = (const bf16_t*)(wb + w.hact_lo); g.B_lo = (const bf16_t*)(sh + b.s_fc2_lo);
+        if (g_nosplit & 8) g.A_lo = g.B_lo = nullptr;
         g.bias = b.s_fc2b >= 0 ? (const float*)(sh + b.s_fc2b) : nullptr; g.res = xm; g.ldres = DP;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 3);
         CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));

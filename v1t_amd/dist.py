@@ -3,8 +3,9 @@ core replicated. One training step = sum over mice of independent passes through
 private readout/shifter (train.py:97-111), so the only exchange is ONE all-reduce(SUM — the reference
 accumulates, never averages) of the core's flat gradient arena per optimizer step (9.86 MB fp32 for the
 default V1T) over RCCL/xGMI. Readout / shifter parameters live only on their owner ranks and are never
-communicated, except when world > n_mice: the surplus ranks replicate mice (config C3 "one mouse per
-GPU + replica"), split that mouse's batch, and all-reduce that mouse's arena inside a 2-rank group.
+communicated, except for a mouse that two ranks share (the work is dealt in half mouse-batches so that the ranks
+are balanced, and config C3 "one mouse per GPU + replica"): they split that mouse's batch and all-reduce that
+mouse's arena inside a 2-rank group.
 """
 from __future__ import annotations
 
@@ -22,12 +23,48 @@ class MouseSharding:
         n = len(self.mouse_ids)
         # owners[m] = ranks that process mouse m
         self.owners: t.Dict[str, t.List[int]] = {m: [] for m in self.mouse_ids}
-        if world <= n:
-            for i, m in enumerate(self.mouse_ids):
-                self.owners[m].append(i % world)
+        # slices[m][rank] = the part of mouse m's batch that rank runs (None = all of it)
+        self.slices: t.Dict[str, t.Dict[int, t.Optional[slice]]] = {m: {} for m in self.mouse_ids}
+        plan = None
+        if world <= 2 * n:
+            # balanced dealing: every mouse-batch is cut into g equal parts (g = 1, 2 or 4: the smallest that gives the
+            # smallest maximum load), and the n*g parts are dealt to the ranks in order, as evenly as possible
+            # (7 mice: 3.5 + 3.5 on 2 ranks instead of 4 + 3; 28 images each on 4 ranks instead of 32/32/32/16; one
+            # mouse each on 8 ranks with the last one split 8 + 8). A mouse dealt to two ranks is shared: each runs
+            # its part of the batch and the mouse's arena is all-reduced inside that 2-rank group.
+            best = None
+            for g in (1, 2, 4):
+                if batch_size % g:
+                    continue
+                units = n * g
+                quota = [units // world + (1 if r < units % world else 0) for r in range(world)]
+                key = (max(quota) * (batch_size // g), sum(q == 0 for q in quota), g)  # smallest maximum, no idle rank, fewest cuts
+                if best is None or key < best[0]:
+                    best = (key, g, quota)
+            _, g, quota = best
+            per = batch_size // g
+            plan, r, left = {m: {} for m in self.mouse_ids}, 0, quota[0]
+            for m in self.mouse_ids:
+                for u in range(g):
+                    while left == 0:
+                        r += 1
+                        left = quota[r]
+                    lo, hi = plan[m].get(r, (u, u))
+                    plan[m][r] = (lo, u + 1)
+                    left -= 1
+            for m in self.mouse_ids:
+                for r, (lo, hi) in plan[m].items():
+                    self.owners[m].append(r)
+                    self.slices[m][r] = None if (lo, hi) == (0, g) else slice(lo * per, hi * per)
         else:
             for r in range(world):
                 self.owners[self.mouse_ids[r % n]].append(r)
+            for m in self.mouse_ids:
+                own = self.owners[m]
+                k = len(own)
+                per = (batch_size + k - 1) // k
+                for i, r in enumerate(own):
+                    self.slices[m][r] = None if k == 1 else slice(i * per, min(batch_size, (i + 1) * per))
         self.groups: t.Dict[str, t.Any] = {}
         if make_groups and world > 1 and dist.is_initialized():
             for m in self.mouse_ids:  # every rank must create every group, in the same order
@@ -43,16 +80,7 @@ class MouseSharding:
 
     def local_units(self) -> t.List[t.Tuple[str, t.Optional[slice]]]:
         """(mouse, batch slice) pairs this rank runs; slice None = the whole batch."""
-        out = []
-        for m in self.local_mice():
-            own = self.owners[m]
-            if len(own) == 1:
-                out.append((m, None))
-            else:
-                k, i = len(own), own.index(self.rank)
-                per = (self.batch_size + k - 1) // k
-                out.append((m, slice(i * per, min(self.batch_size, (i + 1) * per))))
-        return out
+        return [(m, self.slices[m][self.rank]) for m in self.local_mice()]
 
     def images_per_step(self) -> int:
         return self.batch_size * len(self.mouse_ids)
