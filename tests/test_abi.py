@@ -122,4 +122,6 @@ def test_mouse_sharding_assignment():
                 seen[m] += 16 if sl is None else len(range(16)[sl])
         assert all(v == 16 for v in seen.values()), (world, seen)
     s8 = MouseSharding(ids, rank=7, world=8, make_groups=False)
-    assert s8.local_units() == [("A", slice(8, 16))] and s8.shared_mice() == ["A"]
+    assert s8.local_units() == [("G", slice(8, 16))] and s8.shared_mice() == ["G"]  # 8th rank replicates the last mouse
+    s2 = MouseSharding(ids, rank=1, world=2, make_groups=False)
+    assert s2.local_units() == [("D", slice(8, 16)), ("E", None), ("F", None), ("G", None)]  # 3.5 mice per rank
