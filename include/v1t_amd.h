@@ -137,6 +137,7 @@ int v1t_readout_grid_backward(int B, int N, int gd, const float* src, const floa
 /* CoreShifter MLP 2->5->5->2, tanh after every layer (core_shifter.py:24-40; model.py:86-92) */
 int v1t_core_shifter_forward(int B, const float* pupil, const float* W0, const float* b0, const float* W2,
                              const float* b2, const float* W4, const float* b4, float* shift, void* stream);
+/* the six parameter gradients are ACCUMULATED (+=): hand in the gradient arena views, or zeroed buffers */
 int v1t_core_shifter_backward(int B, const float* pupil, const float* W0, const float* b0, const float* W2,
                               const float* b2, const float* W4, const float* b4, const float* dshift,
                               float* dW0, float* db0, float* dW2, float* db2, float* dW4, float* db4,

@@ -243,12 +243,12 @@ __global__ __launch_bounds__(256) void shifter_bwd_kernel(ShifterArgs a) {
     }
     __syncthreads();
     const int t = threadIdx.x;
-    if (t < 10) a.dW0[t] = acc[t];
-    else if (t < 15) a.db0[t - 10] = acc[t];
-    else if (t < 40) a.dW2[t - 15] = acc[t];
-    else if (t < 45) a.db2[t - 40] = acc[t];
-    else if (t < 55) a.dW4[t - 45] = acc[t];
-    else if (t < 57) a.db4[t - 55] = acc[t];
+    if (t < 10) a.dW0[t] += acc[t];
+    else if (t < 15) a.db0[t - 10] += acc[t];
+    else if (t < 40) a.dW2[t - 15] += acc[t];
+    else if (t < 45) a.db2[t - 40] += acc[t];
+    else if (t < 55) a.dW4[t - 45] += acc[t];
+    else if (t < 57) a.db4[t - 55] += acc[t];
 }
 
 inline int ok() { return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH; }

@@ -116,3 +116,16 @@ def stream() -> int:
 def require_cuda(x: torch.Tensor, what: str) -> None:
     if not x.is_cuda:
         raise RuntimeError(f"v1t_amd {what}: tensor is on {x.device}; the HIP path needs a GPU tensor (no CPU fallback).")
+
+
+def grad_sink(p):
+    """Where a backward kernel that ACCUMULATES (+=) should write the gradient of leaf tensor `p`, and what the
+    autograd Function should return for it: straight into ``p.grad`` when that exists as a dense fp32 tensor (the
+    flat-arena views the trainer attaches: no zero-fill, no AccumulateGrad add kernel), else a fresh zeroed buffer."""
+    import torch
+
+    g = getattr(p, "grad", None)
+    if p.is_leaf and g is not None and g.dtype == torch.float32 and g.shape == p.shape and g.is_contiguous() and g.device == p.device:
+        return g, None
+    z = torch.zeros_like(p)
+    return z, z

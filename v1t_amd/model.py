@@ -62,12 +62,12 @@ class _ShifterFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dshift):
         pupil, W0, b0, W2, b2, W4, b4 = ctx.saved_tensors
-        g = [torch.empty_like(t_) for t_ in (W0, b0, W2, b2, W4, b4)]
+        sinks = [L.grad_sink(t_) for t_ in (W0, b0, W2, b2, W4, b4)]  # the kernel accumulates (+=)
         dshift = dshift.contiguous()
         L.check(L.load().v1t_core_shifter_backward(pupil.shape[0], pupil.data_ptr(), W0.data_ptr(), b0.data_ptr(), W2.data_ptr(), b2.data_ptr(),
-                                                   W4.data_ptr(), b4.data_ptr(), dshift.data_ptr(), *[x.data_ptr() for x in g], L.stream()),
+                                                   W4.data_ptr(), b4.data_ptr(), dshift.data_ptr(), *[x[0].data_ptr() for x in sinks], L.stream()),
                 "core_shifter_backward")
-        return (None, *g)
+        return (None, *[x[1] for x in sinks])
 
 
 class CoreShifter(nn.Module):

@@ -111,8 +111,19 @@ class _Gaussian2dFn(torch.autograd.Function):
         dz = torch.zeros_like(zbuf) if need_z else None
         dgrid = torch.empty_like(grid) if need_grid else None
         need_feat = ctx.needs_input_grad[2]
-        dfeat = torch.zeros_like(feat_st) if need_feat else None
-        dbias = torch.zeros_like(bias) if (bias is not None and need_bias) else None
+        # d features / d bias are accumulated (+=) by the kernel: straight into the gradient arena when the parameter's
+        # .grad is the attached arena view (same neuron-major layout as the storage), else into fresh zeroed buffers
+        dfeat = dfeat_ret = None
+        if need_feat:
+            fp, FSn = ctx.feat_param, feat_st.shape[1]
+            fg = getattr(fp, "grad", None)
+            if fg is not None and fg.dtype == torch.float32 and fg.shape == fp.shape and fg.stride(1) == 1 and fg.stride(3) == FSn and fg.device == feat_st.device:
+                dfeat = fg  # (1, C, 1, N) view of an [N][FS] gradient storage: element (0,0,0,0) is its first float
+            else:
+                dfeat = dfeat_ret = torch.zeros_like(feat_st)
+        dbias = dbias_ret = None
+        if bias is not None and need_bias:
+            dbias, dbias_ret = L.grad_sink(bias)
         lib = L.load()
         ws_bytes = lib.v1t_gaussian2d_backward_ws_bytes(B, H, W, N) if need_z else 0
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=zbuf.device) if ws_bytes else None  # inverted tap index (csrc/readout.hip)
@@ -122,8 +133,8 @@ class _Gaussian2dFn(torch.autograd.Function):
                                            L.ptr(dgrid), L.ptr(dfeat), L.ptr(dbias), L.ptr(ws), ws_bytes, L.stream()),
             "gaussian2d_backward",
         )
-        # d features is returned through the storage-shaped tensor; the parameter is a view of it
-        return dz, dgrid, dfeat, dbias, None, None
+        # d features (when not accumulated in place) is returned through the storage-shaped tensor; the parameter is a view of it
+        return dz, dgrid, dfeat_ret, dbias_ret, None, None
 
 
 class _GridFn(torch.autograd.Function):
@@ -149,15 +160,15 @@ class _GridFn(torch.autograd.Function):
         B, N = ctx.B, sigma.shape[1]
         gd = 0 if src is None else src.shape[1]
         dgrid = dgrid.contiguous()
-        z = lambda t: None if t is None else torch.zeros_like(t)
-        dW0, db0, dW2, db2 = z(W0), z(b0), z(W2), z(b2)
+        # the predictor gradients are accumulated (+=) by the kernel: straight into the arena views when attached
+        sinks = [(None, None) if t_ is None else L.grad_sink(t_) for t_ in (W0, b0, W2, b2)]
         dmu = None if mu_free is None else torch.empty_like(mu_free)
         dsigma = torch.empty_like(sigma) if eps is not None else torch.zeros_like(sigma)
-        dshift = z(shift)
+        dshift = None if shift is None else torch.zeros_like(shift)
         L.check(L.load().v1t_readout_grid_backward(B, N, gd, L.ptr(src), L.ptr(W0), L.ptr(b0), L.ptr(W2), L.ptr(b2), L.ptr(mu_free), sigma.data_ptr(),
-                                                   L.ptr(eps), dgrid.data_ptr(), L.ptr(dW0), L.ptr(db0), L.ptr(dW2), L.ptr(db2), L.ptr(dmu),
+                                                   L.ptr(eps), dgrid.data_ptr(), *[L.ptr(x[0]) for x in sinks], L.ptr(dmu),
                                                    dsigma.data_ptr() if eps is not None else None, L.ptr(dshift), L.stream()), "readout_grid_backward")
-        return None, None, dW0, db0, dW2, db2, dmu, dsigma, None, dshift
+        return (None, None, *[x[1] for x in sinks], dmu, dsigma, None, dshift)
 
 
 @register("gaussian2d")
