@@ -103,6 +103,11 @@ def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
     dscale = torch.zeros(H if lsa else 1, device=dev)
     L.check(lib.v1t_attention_backward(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), int(lsa), int(lsa), p, seed,
                                        sid, delta.data_ptr(), dqkv.data_ptr(), dscale.data_ptr(), L.stream()))
+    # bit-reproducible backward as well (no float atomics on dq / dk / dv; hand-placed instruction order and hazards)
+    dqkv_again = torch.zeros_like(dqkv)
+    L.check(lib.v1t_attention_backward(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), int(lsa), int(lsa), p, seed,
+                                       sid, delta.data_ptr(), dqkv_again.data_ptr(), torch.zeros_like(dscale).data_ptr(), L.stream()))
+    assert torch.equal(dqkv, dqkv_again)
     gq, d = gq.view(B * T, 3, H * DP), dqkv.float().view(B * T, 3, H * DP)
     for i, nm in enumerate("qkv"):
         if float(gq[:, i].abs().max()) > 0:

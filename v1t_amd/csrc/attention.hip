@@ -162,17 +162,21 @@ DEVFN float vmax2(float a, float b) {
     asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-DEVFN uint32_t pack_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-// acc_to_b() (common.h) with explicit packed conversions
+// acc_to_b() (common.h) with explicit PACKED conversions: a 2-vector fptrunc selects v_cvt_pk_bf16_f32 directly. (Not
+// inline asm: hipcc inserts no wait states between an asm-written VGPR and the MFMA that reads it as an operand - the
+// dV of a 64-wide head came out NaN from run to run that way.)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) bf16_t bf16x2_t;
 DEVFN bf16x8 acc_to_b_pk(const f32x16& x, int s) {
-    u32x4 r;
+    bf16x8 r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = pack_bf16(x[8 * s + 2 * j], x[8 * s + 2 * j + 1]);
-    return *(bf16x8*)&r;
+    for (int j = 0; j < 4; ++j) {
+        const f32x2_t v = {x[8 * s + 2 * j], x[8 * s + 2 * j + 1]};
+        const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+        r[2 * j] = b[0];
+        r[2 * j + 1] = b[1];
+    }
+    return r;
 }
 // max over the two half-waves (lane l and l + 32 hold the same query): one v_permlane32_swap instead of a ds_bpermute
 DEVFN float half_max(float x) {
