@@ -143,6 +143,10 @@ int v1t_core_shifter_backward(int B, const float* pupil, const float* W0, const 
                               float* dW0, float* db0, float* dW2, float* db2, float* dW4, float* db4,
                               void* stream);
 
+/* ImageCropper resize (image_cropper.py:96-99,134-135): torchvision Resize(antialias=False) = bilinear, half-pixel
+ * centres, on `planes` = B*C images of IH x IW -> OH x OW (144x256 -> 36x64 for Sensorium). */
+int v1t_resize_bilinear(const float* in, int planes, int IH, int IW, float* out, int OH, int OW, void* stream);
+
 /* ELU1 (models/utils.py:109-118) + PoissonLoss (losses.py:153-166, scale_ds :114-119).
  * yhat/du/loss may be NULL; y may be NULL (inference: only yhat). loss is += (zero it first). */
 int v1t_elu1_poisson(const float* u, const float* y, long long n, float loss_scale, float gscale,

@@ -3,6 +3,7 @@
 bf16 rounding of internal operands / outputs only)."""
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -235,3 +236,18 @@ def test_elu1_poisson_edge_vs_reference_golden(ctx, golden):
     assert torch.allclose(yh.cpu(), torch.from_numpy(golden["elu_edge/yhat"]), rtol=1e-6, atol=1.2e-7)
     assert abs(float(loss) - float(golden["elu_edge/loss"])) <= 1e-5 * abs(float(golden["elu_edge/loss"]))
     assert rel_to_max(du.cpu(), golden["elu_edge/du"]) < 1e-5
+
+
+@pytest.mark.parametrize("shape,out", [((2, 1, 144, 256), (36, 64)), ((3, 2, 37, 50), (36, 64)), ((1, 1, 36, 64), (36, 64)), ((2, 1, 20, 30), (45, 77))])
+def test_resize_bilinear(ctx, shape, out):
+    """ImageCropper resize (image_cropper.py:96-99) against the oracle's explicit half-pixel taps (pinned to
+    F.interpolate / the reference by tests/golden: resize/out_sample)."""
+    from oracle import v1t_oracle as O
+
+    lib, L, dev = ctx
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal(shape).astype(np.float32))
+    ref = O.resize_bilinear(x, out)
+    xd = x.to(dev)
+    y = torch.empty(shape[0], shape[1], *out, device=dev)
+    L.check(lib.v1t_resize_bilinear(xd.data_ptr(), shape[0] * shape[1], shape[2], shape[3], y.data_ptr(), out[0], out[1], L.stream()))
+    assert float((y.cpu() - ref).abs().max()) < 1e-5  # fp32 tap weights: (dst + 0.5) * scale - 0.5 rounds differently at non-integer scales

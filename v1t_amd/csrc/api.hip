@@ -787,6 +787,10 @@ int v1t_gaussian2d_backward(const float* z, long long zsb, long long zsc, int B,
 }
 long long v1t_gaussian2d_backward_ws_bytes(int B, int H, int W, int N) { return (long long)readout_bwd_ws_bytes(B, H, W, N); }
 
+int v1t_resize_bilinear(const float* in, int planes, int IH, int IW, float* out, int OH, int OW, void* stream) {
+    if (!in || !out || planes < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return V1T_ERR_ARG;
+    return launch_resize_bilinear(in, out, planes, IH, IW, OH, OW, (hipStream_t)stream);
+}
 int v1t_readout_grid_forward(int B, int N, int gd, const float* src, const float* W0, const float* b0, const float* W2, const float* b2,
                              const float* mu_free, const float* sigma, const float* eps, const float* shift, float* grid, void* stream) {
     if (!sigma || !grid || (gd > 0 && (!src || !W0 || !b0 || !W2 || !b2)) || (gd == 0 && !mu_free)) return V1T_ERR_ARG;

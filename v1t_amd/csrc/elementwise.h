@@ -124,3 +124,4 @@ int launch_elu1_poisson(const LossArgs& a, hipStream_t s);
 
 int launch_dropout_mask(uint8_t* out, long long rows, long long cols, DropCfg d, hipStream_t s);
 int launch_attn_dropout_mask(uint8_t* out, long long rows, long long T, AttnDrop d, hipStream_t s);
+int launch_resize_bilinear(const float* in, float* out, int planes, int IH, int IW, int OH, int OW, hipStream_t s);

@@ -550,6 +550,25 @@ __global__ void attn_dropout_mask_kernel(uint8_t* out, long long rows, long long
     }
 }
 
+// ImageCropper's resize (image_cropper.py:96-99,134-135): torchvision Resize(antialias=False) on a tensor = bilinear with
+// half-pixel centres (align_corners=False), source index clamped at 0, taps clamped at the edge. HBM-bound: one thread
+// per output pixel (144x256 -> 36x64 reads a 2x2 block per pixel).
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* in, float* out, int planes, int IH, int IW, int OH, int OW) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)planes * OH * OW) return;
+    const int x = (int)(i % OW), y = (int)((i / OW) % OH);
+    const long long pl = i / ((long long)OW * OH);
+    const float sy = fmaxf(((float)y + 0.5f) * ((float)IH / (float)OH) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)x + 0.5f) * ((float)IW / (float)OW) - 0.5f, 0.f);
+    const int y0 = min((int)sy, IH - 1), x0 = min((int)sx, IW - 1);
+    const int y1 = min(y0 + 1, IH - 1), x1 = min(x0 + 1, IW - 1);
+    const float fy = sy - (float)y0, fx = sx - (float)x0;
+    const float* p = in + pl * IH * IW;
+    const float top = p[(size_t)y0 * IW + x0] * (1.f - fx) + p[(size_t)y0 * IW + x1] * fx;
+    const float bot = p[(size_t)y1 * IW + x0] * (1.f - fx) + p[(size_t)y1 * IW + x1] * fx;
+    out[i] = top * (1.f - fy) + bot * fy;
+}
+
 inline int ok() { return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH; }
 inline int nblocks(long long n, int cap = 2048) { return (int)std::min<long long>((n + 255) / 256, cap); }
 
@@ -677,5 +696,11 @@ int launch_patch_unfold(const PatchArgs& a, bf16_t* u_hi, bf16_t* u_lo, int ldu,
 int launch_patch_bwd_pos_cast(const PatchArgs& a, bf16_t* gd, hipStream_t s) {
     const int T = a.NH * a.NW + 1;
     hipLaunchKernelGGL(patch_bwd_pos_cast_kernel, dim3((T * a.DP + 255) / 256), dim3(256), 0, s, a, gd);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_resize_bilinear(const float* in, float* out, int planes, int IH, int IW, int OH, int OW, hipStream_t s) {
+    const long long n = (long long)planes * OH * OW;
+    if (n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, planes, IH, IW, OH, OW);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }

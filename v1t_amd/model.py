@@ -152,7 +152,14 @@ class ImageCropper(nn.Module):
         if self.crop_scale < 1:
             outputs = F.grid_sample(inputs, grid=grid, mode="nearest", align_corners=True)
         if self.resize is not None:
-            outputs = F.interpolate(outputs, size=self.resize, mode="bilinear", align_corners=False, antialias=False)
+            if outputs.is_cuda and outputs.dtype == torch.float32 and not outputs.requires_grad:
+                src = outputs.contiguous()
+                b, c, ih, iw = src.shape
+                outputs = torch.empty((b, c, *self.resize), dtype=torch.float32, device=src.device)
+                L.check(L.load().v1t_resize_bilinear(src.data_ptr(), b * c, ih, iw, outputs.data_ptr(), self.resize[0], self.resize[1], L.stream()),
+                        "resize_bilinear")
+            else:  # gradient w.r.t. the image (learned image shifter) is not on the native path
+                outputs = F.interpolate(outputs, size=self.resize, mode="bilinear", align_corners=False, antialias=False)
         if self.behavior_mode == 1:
             h, w = outputs.size(2), outputs.size(3)
             outputs = torch.concat((outputs, behaviors[:, :, None, None].expand(-1, -1, h, w)), dim=1)
