@@ -69,14 +69,23 @@ def test_two_ranks_seven_mice():
     _run(2, list("ABCDEFG"))
 
 
-def test_four_ranks_seven_mice_quarter_cuts():
-    # 7 mice on 4 ranks: 28 images each, mice B, D and F cut 12+4 / 8+8 / 4+12 across neighbouring ranks
+def test_three_ranks_one_mouse_cut():
+    # 7 mice on 3 ranks: 40 / 40 / 32 images, mouse C cut 8 + 8 across ranks 0 and 1 (its arena reduced in that 2-rank group)
+    loads = []
+    for r in range(3):
+        sh = MouseSharding(list("ABCDEFG"), rank=r, world=3, batch_size=16, make_groups=False)
+        loads.append(sum(16 if sl is None else sl.stop - sl.start for _, sl in sh.local_units()))
+    assert loads == [40, 40, 32]
+    _run(3, list("ABCDEFG"))
+
+
+def test_four_ranks_whole_mice():
+    # on 4 ranks cutting does not pay (a piece costs ~6.6 images of fixed work: 3 pieces of 28 images lose to 2 whole mice)
     loads = []
     for r in range(4):
         sh = MouseSharding(list("ABCDEFG"), rank=r, world=4, batch_size=16, make_groups=False)
         loads.append(sum(16 if sl is None else sl.stop - sl.start for _, sl in sh.local_units()))
-    assert loads == [28, 28, 28, 28]
-    _run(4, list("ABCDEFG"))
+    assert loads == [32, 32, 32, 16]
 
 
 def test_two_ranks_balanced_halves():

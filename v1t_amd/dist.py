@@ -17,6 +17,8 @@ import torch.distributed as dist
 
 
 class MouseSharding:
+    PIECE_COST = 6.6  # images; see cost() below
+
     def __init__(self, mouse_ids: t.Sequence[str], rank: int = 0, world: int = 1, batch_size: int = 16, make_groups: bool = True):
         self.mouse_ids = list(mouse_ids)
         self.rank, self.world = rank, world
@@ -32,26 +34,41 @@ class MouseSharding:
             # (7 mice: 3.5 + 3.5 on 2 ranks instead of 4 + 3; 28 images each on 4 ranks instead of 32/32/32/16; one
             # mouse each on 8 ranks with the last one split 8 + 8). A mouse dealt to two ranks is shared: each runs
             # its part of the batch and the mouse's arena is all-reduced inside that 2-rank group.
+            def deal(g):
+                units = n * g
+                quota = [units // world + (1 if r < units % world else 0) for r in range(world)]
+                plan_, r_, left = {m: {} for m in self.mouse_ids}, 0, quota[0]
+                for m in self.mouse_ids:
+                    for u in range(g):
+                        while left == 0:
+                            r_ += 1
+                            left = quota[r_]
+                        lo, _ = plan_[m].get(r_, (u, u))
+                        plan_[m][r_] = (lo, u + 1)
+                        left -= 1
+                return plan_
+
+            def cost(plan_, g):
+                # step time of the most loaded rank in image-equivalents: a piece of a mouse-batch costs its images plus
+                # PIECE_COST for what does not shrink with the batch (readout optimizer step, neuron-indexed kernels,
+                # launch-bound small kernels; measured with tools/sim_scaling.py: 16 images 6.0 ms, 8 images 3.9 ms)
+                per = batch_size // g
+                load = [0.0] * world
+                for m in self.mouse_ids:
+                    for r_, (lo, hi) in plan_[m].items():
+                        load[r_] += self.PIECE_COST + (hi - lo) * per
+                return max(load), sum(1 for x in load if x == 0.0)
+
             best = None
             for g in (1, 2, 4):
                 if batch_size % g:
                     continue
-                units = n * g
-                quota = [units // world + (1 if r < units % world else 0) for r in range(world)]
-                key = (max(quota) * (batch_size // g), sum(q == 0 for q in quota), g)  # smallest maximum, no idle rank, fewest cuts
+                plan_ = deal(g)
+                key = (*cost(plan_, g), g)  # cheapest most-loaded rank, then no idle rank, then fewest cuts
                 if best is None or key < best[0]:
-                    best = (key, g, quota)
-            _, g, quota = best
+                    best = (key, g, plan_)
+            _, g, plan = best
             per = batch_size // g
-            plan, r, left = {m: {} for m in self.mouse_ids}, 0, quota[0]
-            for m in self.mouse_ids:
-                for u in range(g):
-                    while left == 0:
-                        r += 1
-                        left = quota[r]
-                    lo, hi = plan[m].get(r, (u, u))
-                    plan[m][r] = (lo, u + 1)
-                    left -= 1
             for m in self.mouse_ids:
                 for r, (lo, hi) in plan[m].items():
                     self.owners[m].append(r)
