@@ -203,46 +203,68 @@ __global__ __launch_bounds__(256) void patch_bwd_w_kernel(PatchArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm forward (one wave per row) fused with the BehaviorMLP injection x += beta[b] (vit.py:356-359).
-template <int NE>
+// LayerNorm kernels. Layout for both: a wave works on 8 rows at once, 8 lanes per row; lane j of a row owns the 16-B
+// chunks j, j + 8, ... (CPL = DP / 32 of them), so one load instruction reads a 128-B line of each of 8 rows and every
+// access is 16 B (fp32) or 8 B (bf16). (One wave per row with lanes striding single elements issued 4-B loads and 2-B
+// stores: 2.2-2.4 TB/s.) Row statistics are 3 DPP adds over the 8 lanes of a row.
+DEVFN float row8_sum(float v) {
+    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    return dpp_add<0x141, 0xF>(v);  // row_half_mirror: lanes i <-> 7 - i of each group of 8
+}
+typedef __attribute__((ext_vector_type(4))) bf16_t bf16x4_t;
+
+// LayerNorm forward fused with the BehaviorMLP injection x += beta[b] (vit.py:356-359).
+template <int CPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= a.rows) return;
-    const int b = row / a.T;
-    float v[NE];
+    const int j = lane & 7;
+    const int row = (blockIdx.x * 4 + wave) * 8 + (lane >> 3);
+    const bool rok = row < a.rows;
+    const int rr = rok ? row : a.rows - 1;
+    const int b = rr / a.T;
+    f32x4 v[CPL];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = 0.f;
-        if (c < a.D) {
-            v[i] = a.x[(size_t)row * a.DP + c];
-            if (a.inject) v[i] += a.inject[(size_t)b * a.DP + c];
+    for (int k = 0; k < CPL; ++k) {
+        const int c = 4 * (j + 8 * k);
+        v[k] = *(const f32x4*)(a.x + (size_t)rr * a.DP + c);
+        if (a.inject) {
+            v[k] += *(const f32x4*)(a.inject + (size_t)b * a.DP + c);
+            if (rok) *(f32x4*)(a.xout + (size_t)row * a.DP + c) = v[k];
         }
-        if (a.inject && c < a.DP) a.xout[(size_t)row * a.DP + c] = v[i];
-        s += v[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c + e >= a.D) v[k][e] = 0.f;  // pad columns are zero in x; keep them out of the statistics regardless
+            s += v[k][e];
+        }
     }
-    const float mean = wave_sum(s) / a.D;
+    const float mean = row8_sum(s) / a.D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int c = lane + 64 * i;
-        const float dlt = (c < a.D) ? v[i] - mean : 0.f;
-        q += dlt * dlt;
-    }
-    const float rstd = rsqrtf(wave_sum(q) / a.D + a.eps);
+    for (int k = 0; k < CPL; ++k)
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int c = lane + 64 * i;
-        if (c < a.DP) {
-            const float z = (c < a.D) ? (v[i] - mean) * rstd * a.gamma[c] + a.beta[c] : (c == a.ones_col ? 1.f : 0.f);
-            const bf16_t zh = (bf16_t)z;
-            a.z[(size_t)row * a.DP + c] = zh;
-            if (a.z_lo) a.z_lo[(size_t)row * a.DP + c] = (bf16_t)(z - (float)zh);
+        for (int e = 0; e < 4; ++e) {
+            const float d = (4 * (j + 8 * k) + e < a.D) ? v[k][e] - mean : 0.f;
+            q += d * d;
         }
+    const float rstd = rsqrtf(row8_sum(q) / a.D + a.eps);
+    if (!rok) return;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c = 4 * (j + 8 * k);
+        bf16x4_t zh, zl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int cc = c + e;
+            const float z = (cc < a.D) ? (v[k][e] - mean) * rstd * a.gamma[cc] + a.beta[cc] : (cc == a.ones_col ? 1.f : 0.f);
+            zh[e] = (bf16_t)z;
+            zl[e] = (bf16_t)(z - (float)zh[e]);
+        }
+        *(bf16x4_t*)(a.z + (size_t)row * a.DP + c) = zh;
+        if (a.z_lo) *(bf16x4_t*)(a.z_lo + (size_t)row * a.DP + c) = zl;
     }
-    if (lane == 0) {
+    if (j == 0) {
         a.mean[row] = mean;
         a.rstd[row] = rstd;
     }
@@ -250,91 +272,107 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
 
 // LayerNorm backward + residual add + (optional) token-sum for the injection gradient +
 // (optional) dropout-backward/cast of the result for the next branch and its bias gradient.
-// Workgroup = 64 rows of one image (16 per wave, 4 at a time); column partials stay in registers across rows.
+// Workgroup = 64 rows of one image (two 8-row steps per wave); column partials stay in registers across rows and
+// are summed over the 8 row slots of a wave with lane swaps, over the waves through LDS, one atomic per column per WG.
 constexpr int LNB_ROWS = 64;
-constexpr int LNB_RPI = 4;  // rows per wave iteration: their loads are issued together (latency hiding by ILP)
-template <int NE>
+constexpr int LNB_RPI = 4;  // drop_cast_kernel: rows per wave iteration
+DEVFN float rowslot_sum(float v) {  // sum over the 8 row slots (lane bits 3, 4, 5); valid in lanes 0..7
+    v = dpp_add<0x128, 0xF>(v);  // row_ror:8 -> lane l += lane l ^ 8
+    {
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // rows 0<->1, 2<->3
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // halves
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return v;
+}
+template <int CPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     __shared__ float sred[4][4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 7, slot = lane >> 3;
     const int b = blockIdx.y, t0 = blockIdx.x * LNB_ROWS;
-    float gam[NE], adg[NE], adb[NE], ainj[NE], abn[NE];
+    f32x4 gam[CPL], adg[CPL], adb[CPL], ainj[CPL], abn[CPL];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int c = lane + 64 * i;
-        gam[i] = (c < a.D) ? a.gamma[c] : 0.f;
-        adg[i] = adb[i] = ainj[i] = abn[i] = 0.f;
-    }
-    for (int r0 = wave * (LNB_ROWS / 4); r0 < (wave + 1) * (LNB_ROWS / 4); r0 += LNB_RPI) {
-        if (t0 + r0 >= a.T) break;
-        float dz[LNB_RPI][NE], xv[LNB_RPI][NE], gi[LNB_RPI][NE], mean[LNB_RPI], rstd[LNB_RPI];
-        // issue the loads of LNB_RPI rows together
+    for (int k = 0; k < CPL; ++k) {
 #pragma unroll
-        for (int u = 0; u < LNB_RPI; ++u) {
-            const int t = min(t0 + r0 + u, a.T - 1);
-            const int row = b * a.T + t;
-            mean[u] = a.mean[row];
-            rstd[u] = a.rstd[row];
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int c = lane + 64 * i;
-                dz[u][i] = xv[u][i] = gi[u][i] = 0.f;
-                if (c < a.D) {
-                    dz[u][i] = a.dz[(size_t)row * a.DP + c];
-                    xv[u][i] = a.x[(size_t)row * a.DP + c];
-                    gi[u][i] = a.gin[(size_t)row * a.DP + c];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LNB_RPI; ++u) {
-            const int t = t0 + r0 + u;
-            if (t >= a.T) break;
-            const int row = b * a.T + t;
-            float xh[NE], dy[NE];
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int c = lane + 64 * i;
-                xh[i] = (c < a.D) ? (xv[u][i] - mean[u]) * rstd[u] : 0.f;
-                dy[i] = dz[u][i] * gam[i];
-                s1 += dy[i];
-                s2 += dy[i] * xh[i];
-            }
-            s1 = wave_sum(s1) / a.D;
-            s2 = wave_sum(s2) / a.D;
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int c = lane + 64 * i;
-                if (c < a.DP) {
-                    float go = 0.f;
-                    if (c < a.D) {
-                        go = gi[u][i] + rstd[u] * (dy[i] - s1 - xh[i] * s2);
-                        adg[i] += dz[u][i] * xh[i];
-                        adb[i] += dz[u][i];
-                        ainj[i] += go;
-                    }
-                    a.gout[(size_t)row * a.DP + c] = go;
-                    if (a.dy_next) {
-                        float v = go;
-                        if (a.drop_next.thresh && c < a.D)
-                            v = drop_keep(a.drop_next.key, row, c, a.drop_next.thresh) ? v * a.drop_next.inv_keep : 0.f;
-                        const bf16_t vb = (bf16_t)v;
-                        a.dy_next[(size_t)row * a.DP + c] = vb;
-                        abn[i] += (float)vb;
-                    }
-                }
-            }
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (j + 8 * k) + e;
+            gam[k][e] = (c < a.D) ? a.gamma[c] : 0.f;
+            adg[k][e] = adb[k][e] = ainj[k][e] = abn[k][e] = 0.f;
         }
     }
+#pragma unroll 1
+    for (int it = 0; it < LNB_ROWS / 32; ++it) {
+        const int t = t0 + 8 * (wave + 4 * it) + slot;
+        if (t0 + 8 * (wave + 4 * it) >= a.T) break;  // wave-uniform
+        const bool rok = t < a.T;
+        const int row = b * a.T + (rok ? t : a.T - 1);
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        f32x4 dz[CPL], xh[CPL], gi[CPL];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int c = lane + 64 * i;
-        sred[wave][0][c] = adg[i];
-        sred[wave][1][c] = adb[i];
-        sred[wave][2][c] = ainj[i];
-        sred[wave][3][c] = abn[i];
+        for (int k = 0; k < CPL; ++k) {
+            const size_t o = (size_t)row * a.DP + 4 * (j + 8 * k);
+            dz[k] = *(const f32x4*)(a.dz + o);
+            xh[k] = *(const f32x4*)(a.x + o);
+            gi[k] = *(const f32x4*)(a.gin + o);
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool cok = 4 * (j + 8 * k) + e < a.D;
+                xh[k][e] = cok ? (xh[k][e] - mean) * rstd : 0.f;
+                dz[k][e] = cok ? dz[k][e] : 0.f;
+                const float dy = dz[k][e] * gam[k][e];
+                s1 += dy;
+                s2 += dy * xh[k][e];
+            }
+        s1 = row8_sum(s1) / a.D;
+        s2 = row8_sum(s2) / a.D;
+        if (!rok) continue;  // the row reductions above need every lane
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int c = 4 * (j + 8 * k);
+            f32x4 go;
+            bf16x4_t vb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool cok = c + e < a.D;
+                go[e] = cok ? gi[k][e] + rstd * (dz[k][e] * gam[k][e] - s1 - xh[k][e] * s2) : 0.f;
+                adg[k][e] += dz[k][e] * xh[k][e];
+                adb[k][e] += dz[k][e];
+                ainj[k][e] += go[e];
+                float v = go[e];
+                if (a.dy_next && a.drop_next.thresh && cok)
+                    v = drop_keep(a.drop_next.key, row, c + e, a.drop_next.thresh) ? v * a.drop_next.inv_keep : 0.f;
+                vb[e] = (bf16_t)v;
+                abn[k][e] += (float)vb[e];
+            }
+            *(f32x4*)(a.gout + (size_t)row * a.DP + c) = go;
+            if (a.dy_next) *(bf16x4_t*)(a.dy_next + (size_t)row * a.DP + c) = vb;
+        }
     }
+    // EXEC is whole again here (the loop's `continue` only masks lanes inside an iteration)
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float r0 = rowslot_sum(adg[k][e]), r1 = rowslot_sum(adb[k][e]);
+            const float r2 = rowslot_sum(ainj[k][e]), r3 = rowslot_sum(abn[k][e]);
+            if (slot == 0) {
+                const int c = 4 * (j + 8 * k) + e;
+                sred[wave][0][c] = r0;
+                sred[wave][1][c] = r1;
+                sred[wave][2][c] = r2;
+                sred[wave][3][c] = r3;
+            }
+        }
     __syncthreads();
     const int c = threadIdx.x;
     if (c < a.D) {
@@ -613,27 +651,33 @@ int launch_patch_embed_bwd(const PatchArgs& a, hipStream_t s) {
 }
 
 int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
-    if (a.DP > 256) return V1T_ERR_UNSUPPORTED;
-    const dim3 grid((a.rows + 3) / 4);
-    const int ne = (a.DP + 63) / 64;
-    switch (ne) {
+    if (a.DP > 256 || a.DP % 32 != 0) return V1T_ERR_UNSUPPORTED;
+    const dim3 grid((a.rows + 31) / 32);
+    switch (a.DP / 32) {
         case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
         case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL(ln_fwd_kernel<5>, grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL(ln_fwd_kernel<6>, grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL(ln_fwd_kernel<7>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, s, a); break;
     }
     return ok();
 }
 
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
-    if (a.DP > 256) return V1T_ERR_UNSUPPORTED;
+    if (a.DP > 256 || a.DP % 32 != 0) return V1T_ERR_UNSUPPORTED;
     const dim3 grid((a.T + LNB_ROWS - 1) / LNB_ROWS, a.B);
-    const int ne = (a.DP + 63) / 64;
-    switch (ne) {
+    switch (a.DP / 32) {
         case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), 0, s, a); break;
         case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL(ln_bwd_kernel<5>, grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL(ln_bwd_kernel<6>, grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL(ln_bwd_kernel<7>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), 0, s, a); break;
     }
     return ok();
 }
