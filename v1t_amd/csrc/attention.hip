@@ -234,8 +234,10 @@ constexpr int FWD_WAVES = 8;  // 256 queries per workgroup share each K/V tile: 
 template <int DP, bool DROP, bool DIAG>
 __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a) {
     using G = Geo<DP>;
-    using DmaK = TileDma<DP, G::RSTR, 32, FWD_WAVES>;
-    using DmaV = TileDma<DP, G::TSTR, 32, FWD_WAVES>;
+    // K/V are staged 64 keys at a time (one barrier and one burst of LDS-DMA pieces per 64 keys) and consumed as two
+    // 32-key tiles
+    using DmaK = TileDma<DP, G::RSTR, 64, FWD_WAVES>;
+    using DmaV = TileDma<DP, G::TSTR, 64, FWD_WAVES>;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][DmaK::LDS_ELEMS];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2][DmaV::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -274,13 +276,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     const int nt = (a.T + 31) / 32;
 
     KP_DECL;
-    auto tile = [&](auto tail_tag, int kt, int buf) {
+    auto tile = [&](auto tail_tag, int kt, int buf, bool issue_next) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         KP_STAMP(0);
         f32x16 s;
         zero16(s);
-        const bf16_t* kp = &sK[buf][koff];
-        const bf16_t* vp = &sV[buf][voff];
+        const bf16_t* kp = &sK[buf][32 * (kt & 1) * G::RSTR + koff];
+        const bf16_t* vp = &sV[buf][32 * (kt & 1) * G::TSTR + voff];
         // all K fragments in flight, then the S chain; the V fragments (transposed reads) are issued right
         // behind it so they land while the softmax runs on the VALU
         bf16x8 kfr[G::KS], vfr[2 * G::DB];
@@ -332,9 +334,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
         const float negm = -m2;
         // next tile's LDS-DMA is issued HERE, in the VALU-only stretch: a piece costs its wave 100-185 cycles of
         // issue while ds_reads are in flight (tile start) but 25-60 when the LDS is quiet (kprof timeline)
-        if constexpr (!TAIL) {
-            dmaK.issue(kbase, 32 * (kt + 1), a.T, sK[buf ^ 1]);
-            dmaV.issue(vbase, 32 * (kt + 1), a.T, sV[buf ^ 1]);
+        if (issue_next) {  // wave-uniform: first tile of a stage that has a successor
+            dmaK.issue(kbase, 32 * (kt + 2), a.T, sK[buf ^ 1]);
+            dmaV.issue(vbase, 32 * (kt + 2), a.T, sV[buf ^ 1]);
         }
         KP_STAMP(3);
 #pragma unroll
@@ -368,13 +370,16 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     touch(qf);
     touch(c);
     dma_wait_and_barrier();
-    for (int kt = 0; kt < nt - 1; ++kt) {
-        const int buf = kt & 1;
-        tile(std::false_type{}, kt, buf);
+    const int ns = (nt + 1) / 2;  // 64-key stages
+    for (int st = 0; st < ns - 1; ++st) {
+        const int buf = st & 1;
+        tile(std::false_type{}, 2 * st, buf, true);
+        tile(std::false_type{}, 2 * st + 1, buf, false);
         dma_wait_and_barrier();
         KP_STAMP(7);
     }
-    tile(std::true_type{}, nt - 1, (nt - 1) & 1);
+    tile(std::true_type{}, 2 * (ns - 1), (ns - 1) & 1, false);
+    if (2 * (ns - 1) + 1 < nt) tile(std::true_type{}, 2 * (ns - 1) + 1, (ns - 1) & 1, false);
 
     const float ltot = lsum + __shfl_xor(lsum, 32);
     const float inv = (DROP ? a.adrop.inv_keep : 1.0f) / ltot;
