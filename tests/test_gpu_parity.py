@@ -88,7 +88,7 @@ def test_intermediate_taps_vs_reference_golden(golden, dev):
 VARIANTS = {
     "beh0": dict(behavior_mode=0), "beh2": dict(behavior_mode=2), "beh4": dict(behavior_mode=4), "franke": dict(input_shape=(2, 36, 64)),
     "nogridpred": dict(disable_grid_predictor=True), "grid3": dict(grid_predictor_dim=3), "lsa": dict(use_lsa=True), "nobias": dict(disable_bias=True),
-    "patch1": dict(patch_mode=1), "stride2": dict(patch_stride=2), "noshift": dict(shift_mode=0), "heads3_d40": dict(num_heads=3, emb_dim=40, mlp_dim=72),
+    "patch1": dict(patch_mode=1), "patch2": dict(patch_mode=2), "patch3": dict(patch_mode=3), "stride2": dict(patch_stride=2), "noshift": dict(shift_mode=0), "heads3_d40": dict(num_heads=3, emb_dim=40, mlp_dim=72),
 }
 
 
@@ -105,11 +105,45 @@ def test_variants_vs_reference_golden(golden, dev, vn):
         assert_close(f"{vn}.{mouse}", y.cpu().numpy(), golden[f"variant/{vn}/{mouse}/y"], Y_RTOL, Y_ATOL)
 
 
-@pytest.mark.parametrize("vn", ["patch2", "patch3"])
-def test_unsupported_variants_fail_loudly(dev, vn):
-    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, patch_mode=int(vn[-1]))
+def test_unsupported_variants_fail_loudly(dev):
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128)
+    import v1t_amd
+    from v1t_amd.synthetic import default_args, make_ds
+
+    args = default_args(input_shape=cfg.input_shape, resize_image=0, num_blocks=1, emb_dim=64, mlp_dim=128)
+    args.output_shapes = {"A": (8,)}
+    args.drop_path = 0.1  # stochastic depth has no native kernel: must raise, not fall back
     with pytest.raises(NotImplementedError):
-        build_native_model(cfg, W.make_state_dict(cfg, 77), dev)
+        v1t_amd.Model(args, make_ds({"A": 8}))
+
+
+@pytest.mark.parametrize("pm", [2, 3])
+def test_patch_modes_2_3_gradients_vs_oracle(dev, pm):
+    """SPT / dual-PatchNorm tokenisers (vit.py:83-100): every parameter gradient of the core against the oracle's
+    autograd (the forward of these variants is pinned to the reference by the golden variant vectors)."""
+    from v1t_amd.losses import elu1_poisson_loss
+
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 96}, patch_mode=pm)
+    sd = W.make_state_dict(cfg, 31)
+    batch = W.make_batch(cfg, "A", 2, 31)
+    model, _ = build_native_model(cfg, sd, dev)
+    model.train(False)
+    u = _fwd(model, batch, "A", dev, activate=False)
+    loss, _ = elu1_poisson_loss(u, batch["response"].to(dev), 4500.0, 2)
+    loss.backward()
+    sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ol, _, _ = O.total_loss(cfg, sdd, batch, "A", 4500.0)
+    ol.backward()
+    assert abs(float(loss) - float(ol)) <= 1e-4 * abs(float(ol))
+    n = 0
+    for k, p in model.named_parameters():
+        if not k.startswith("core.patch_embedding"):
+            continue
+        ref = sdd[k].grad
+        assert ref is not None and p.grad is not None, k
+        assert rel_to_max(p.grad.detach().cpu().reshape(ref.shape), ref) < G_TOL, k
+        n += 1
+    assert n >= (6 if pm == 2 else 8)
 
 
 def test_train_mode_readout_sampling_vs_reference_golden(golden, dev):

@@ -171,8 +171,8 @@ class ViTCore(Core):
             args.grad_checkpointing = False
         if args.patch_mode not in (0, 1, 2, 3):
             raise NotImplementedError(f"--patch_mode {args.patch_mode} not implemented.")
-        if args.patch_mode in (2, 3):
-            raise NotImplementedError(f"--patch_mode {args.patch_mode} (SPT / dual PatchNorm) has no gfx950 kernel yet.")
+        if args.patch_mode == 2 and input_shape[0] != 1:
+            raise NotImplementedError("--patch_mode 2 (Shifted Patch Tokenization) is defined for single-channel input only (vit.py:84).")
         if float(getattr(args, "drop_path", 0.0)) != 0.0:
             raise NotImplementedError("drop_path > 0 has no gfx950 kernel yet (reference default is 0).")
         assert 1 <= args.patch_stride <= args.patch_size
@@ -221,6 +221,12 @@ class ViTCore(Core):
         pe = _ParamBag()
         if args.patch_mode == 0:
             pe.projection = _seq(nn.Identity(), nn.Identity(), nn.Linear(c * P * P, D))  # key projection.2.* (vit.py:68-72)
+        elif args.patch_mode == 2:  # PatchShifting, Unfold, Rearrange, LayerNorm, Linear: keys projection.3.* / .4.* (vit.py:83-91)
+            pd = (c + 4) * P * P
+            pe.projection = _seq(nn.Identity(), nn.Identity(), nn.Identity(), nn.LayerNorm(pd), nn.Linear(pd, D))
+        elif args.patch_mode == 3:  # Unfold, Rearrange, LayerNorm, Linear, LayerNorm: keys projection.2.* / .3.* / .4.* (vit.py:92-100)
+            pd = c * P * P
+            pe.projection = _seq(nn.Identity(), nn.Identity(), nn.LayerNorm(pd), nn.Linear(pd, D), nn.LayerNorm(D))
         else:
             conv = nn.Conv2d(c, D, kernel_size=P, stride=args.patch_stride)  # key projection.0.* (vit.py:74-82)
             nn.init.kaiming_normal_(conv.weight)

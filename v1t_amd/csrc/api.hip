@@ -54,6 +54,8 @@ struct v1t_vit {
     std::vector<TensorInfo> tensors;
     long long arena_floats, param_floats;
     long long o_cls, o_pos, o_pw, o_pb;
+    long long o_pln_w, o_pln_b, o_pln2_w, o_pln2_b;  // patch modes 2/3: LayerNorm over the patch, mode 3: LayerNorm over D (-1: absent)
+    long long s_pw_t;               // patch modes 2/3: transposed hi plane [PD][DP] (dU = gd . W)
     long long s_pw, s_pw_lo, s_pb;  // patch weights: bf16 hi / lo planes [DP][PD], fp32 bias [DP] (-1: VALU patch kernels)
     int PDX;                        // row stride of the unfolded-patch matrix U (PD + ones column, padded to 128)
     std::vector<BlockOff> blk;
@@ -81,6 +83,7 @@ namespace {
 // -------------------------------------------------------------------------- workspace layout
 struct WsLayout {
     long long x0, beta, hid, u_hi, u_lo;
+    long long u32, pmean1, prstd1, py, pmean2, prstd2;  // patch modes 2/3 (0 bytes otherwise)
     // per block
     long long blk_stride, xa, xm, xo, z1, qkv, o, lse2, mean1, rstd1, z2, mean2, rstd2, hpre, hact;
     long long z1_lo, o_lo, z2_lo, hact_lo;  // low planes (forward-only consumers)
@@ -101,6 +104,13 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
     w.hid = take((long long)h->NB * B * std::max(h->J, 1) * 4);
     w.u_hi = take(h->s_pw >= 0 ? R * h->PDX * 2 : 0);
     w.u_lo = take(h->s_pw >= 0 ? R * h->PDX * 2 : 0);
+    const bool pln = h->c.patch_mode >= 2, pln2 = h->c.patch_mode == 3;
+    w.u32 = take(pln ? R * h->PDX * 4 : 0);
+    w.pmean1 = take(pln ? R * 4 : 0);
+    w.prstd1 = take(pln ? R * 4 : 0);
+    w.py = take(pln2 ? R * h->DP * 4 : 0);
+    w.pmean2 = take(pln2 ? R * 4 : 0);
+    w.prstd2 = take(pln2 ? R * 4 : 0);
     const long long b0 = cur;
     w.xa = take(R * h->DP * 4) - b0;
     w.xm = take(R * h->DP * 4) - b0;
@@ -129,7 +139,7 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
 }
 
 struct ScratchLayout {
-    long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, slab, pu, pgd, total;
+    long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, slab, pu, pgd, pdu, total;
 };
 // contraction rows per workgroup of the weight-gradient GEMMs: aim at >= ~512 workgroups
 int tn_mchunk(long long R, int tiles) {
@@ -173,6 +183,7 @@ ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     s.slab = take((long long)tn_plan(h, R).slab);
     s.pu = take(h->s_pw >= 0 ? R * h->PDX * 2 : 0);
     s.pgd = take(h->s_pw >= 0 ? R * h->DP * 2 : 0);
+    s.pdu = take(h->c.patch_mode >= 2 ? R * h->PD * 4 : 0);
     s.total = cur;
     return s;
 }
@@ -290,7 +301,8 @@ const char* v1t_error_string(int code) {
 
 int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     if (!cfg || !out) return V1T_ERR_ARG;
-    if (cfg->patch_mode != 0 && cfg->patch_mode != 1) return V1T_ERR_UNSUPPORTED;
+    if (cfg->patch_mode < 0 || cfg->patch_mode > 3) return V1T_ERR_UNSUPPORTED;
+    if (cfg->patch_mode == 2 && cfg->in_channels != 1) return V1T_ERR_UNSUPPORTED;  // vit.py:84 sizes the SPT patch as (c + 4) * P^2: single-channel only
     if (cfg->patch_stride < 1 || cfg->patch_stride > cfg->patch_size) return V1T_ERR_ARG;
     if (cfg->behavior_mode != 0 && cfg->behavior_mode != 2 && cfg->behavior_mode != 3 && cfg->behavior_mode != 4) return V1T_ERR_ARG;
     v1t_vit* h = new v1t_vit();
@@ -307,7 +319,7 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     h->inject = cfg->behavior_mode == 2 || cfg->behavior_mode == 3 || cfg->behavior_mode == 4;
     h->IN = cfg->behavior_mode == 2 ? 3 : 5;
     h->J = h->D / 2;
-    h->PD = h->C * h->P * h->P;
+    h->PD = (cfg->patch_mode == 2 ? h->C + 4 : h->C) * h->P * h->P;
     h->nbmlp = cfg->behavior_mode == 4 ? std::max(cfg->num_mice, 1) : 1;
     if (h->DP > 160 || (h->DP != 32 && h->DP != 64 && h->DP != 96 && h->DP != 128 && h->DP != 160)) { delete h; return V1T_ERR_UNSUPPORTED; }
     find_shape(h->L, &h->gh, &h->gw);
@@ -317,9 +329,22 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     const bool bias = cfg->use_bias != 0;
     h->o_cls = h->add("patch_embedding.cls_token", {1, 1, h->D}, true, cur);
     h->o_pos = h->add("patch_embedding.pos_embedding", {h->T, h->D}, true, cur);
+    h->o_pln_w = h->o_pln_b = h->o_pln2_w = h->o_pln2_b = -1;
     if (cfg->patch_mode == 0) {
         h->o_pw = h->add("patch_embedding.projection.2.weight", {h->D, h->PD}, true, cur);
         h->o_pb = h->add("patch_embedding.projection.2.bias", {h->D}, true, cur);
+    } else if (cfg->patch_mode == 2) {  // PatchShifting, Unfold, Rearrange, LayerNorm(patch), Linear (vit.py:83-91)
+        h->o_pln_w = h->add("patch_embedding.projection.3.weight", {h->PD}, true, cur);
+        h->o_pln_b = h->add("patch_embedding.projection.3.bias", {h->PD}, true, cur);
+        h->o_pw = h->add("patch_embedding.projection.4.weight", {h->D, h->PD}, true, cur);
+        h->o_pb = h->add("patch_embedding.projection.4.bias", {h->D}, true, cur);
+    } else if (cfg->patch_mode == 3) {  // Unfold, Rearrange, LayerNorm(patch), Linear, LayerNorm(D) (vit.py:92-100)
+        h->o_pln_w = h->add("patch_embedding.projection.2.weight", {h->PD}, true, cur);
+        h->o_pln_b = h->add("patch_embedding.projection.2.bias", {h->PD}, true, cur);
+        h->o_pw = h->add("patch_embedding.projection.3.weight", {h->D, h->PD}, true, cur);
+        h->o_pb = h->add("patch_embedding.projection.3.bias", {h->D}, true, cur);
+        h->o_pln2_w = h->add("patch_embedding.projection.4.weight", {h->D}, true, cur);
+        h->o_pln2_b = h->add("patch_embedding.projection.4.bias", {h->D}, true, cur);
     } else {
         h->o_pw = h->add("patch_embedding.projection.0.weight", {h->D, h->C, h->P, h->P}, true, cur);
         h->o_pb = h->add("patch_embedding.projection.0.bias", {h->D}, true, cur);
@@ -392,8 +417,12 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
             b.s_fc2b = stake(DP * 4);  desc(b.fc2b, D, b.s_fc2b, 1, DP, 1, 1, DP, D, 0, 1);
         }
     }
-    h->s_pw = h->s_pw_lo = h->s_pb = -1;
+    h->s_pw = h->s_pw_lo = h->s_pb = h->s_pw_t = -1;
     h->PDX = (h->PD + 1 + 127) / 128 * 128;
+    if (cfg->patch_mode >= 2 && (h->PD % 32 != 0 || h->PDX > 384)) { delete h; return V1T_ERR_UNSUPPORTED; }
+    if (cfg->patch_mode >= 2) {
+        h->s_pw_t = stake((long long)h->PD * h->DP * 2); desc(h->o_pw, h->PD, h->s_pw_t, h->PD, h->DP, h->DP, h->D, h->PD, h->PD, 1, 0);
+    }
     if (h->PD % 32 == 0) {  // MFMA patch embedding (both patch modes store the weight as [D][C*P*P])
         h->s_pw = stake((long long)h->DP * h->PD * 2);    desc(h->o_pw, h->PD, h->s_pw, h->DP, h->PD, h->DP, h->D, h->PD, h->PD, 0, 0);
         h->s_pw_lo = stake((long long)h->DP * h->PD * 2); desc(h->o_pw, h->PD, h->s_pw_lo, h->DP, h->PD, h->DP, h->D, h->PD, h->PD, 0, 2);
@@ -493,13 +522,37 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
     if (h->s_pw >= 0) {  // unfold -> split-bf16 MFMA GEMM with the bias / position / class-token / dropout epilogue
         bf16_t* u_hi = (bf16_t*)(ws + w.u_hi);
         bf16_t* u_lo = (bf16_t*)(ws + w.u_lo);
-        CHECK(launch_patch_unfold(pa, u_hi, u_lo, h->PDX, s));
+        const int pm = h->c.patch_mode;
+        if (pm >= 2) {  // fp32 patches (mode 2: + 4 diagonal shifts) -> LayerNorm over the patch -> bf16 hi / lo planes
+            float* u32 = (float*)(ws + w.u32);
+            CHECK(launch_patch_unfold_f32(pa, pm == 2, u32, h->PDX, s));
+            LnFwdArgs l{};
+            l.x = u32; l.gamma = arena + h->o_pln_w; l.beta = arena + h->o_pln_b; l.z = u_hi; l.z_lo = u_lo;
+            l.mean = (float*)(ws + w.pmean1); l.rstd = (float*)(ws + w.prstd1);
+            l.rows = R; l.T = h->T; l.D = h->PD; l.DP = h->PDX; l.eps = 1e-5f; l.ones_col = h->PD;
+            CHECK(launch_ln_fwd(l, s));
+        } else {
+            CHECK(launch_patch_unfold(pa, u_hi, u_lo, h->PDX, s));
+        }
         GemmNTArgs g{};
         g.A = u_hi; g.A_lo = u_lo; g.lda = h->PDX; g.B = (const bf16_t*)(sh + h->s_pw); g.B_lo = (const bf16_t*)(sh + h->s_pw_lo); g.ldb = h->PD;
-        g.M = R; g.N = DP; g.K = h->PD; g.C = xcur; g.ldc = DP;
-        g.bias = (const float*)(sh + h->s_pb); g.pos = arena + h->o_pos; g.cls = arena + h->o_cls; g.T = h->T; g.n_valid = D;
-        g.drop = pa.drop;
-        CHECK(launch_gemm_nt(g, EPI_PATCH, s));
+        g.M = R; g.N = DP; g.K = h->PD; g.ldc = DP;
+        g.bias = (const float*)(sh + h->s_pb);
+        if (pm == 3) {  // projection output -> LayerNorm(D) -> + pos / class token -> dropout (vit.py:92-100, 122-128)
+            float* py = (float*)(ws + w.py);
+            g.C = py;
+            CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));  // no residual, no dropout: y = acc + bias
+            PatchLn2Args f{};
+            f.y = py; f.x0 = xcur; f.mean = (float*)(ws + w.pmean2); f.rstd = (float*)(ws + w.prstd2);
+            f.gamma = arena + h->o_pln2_w; f.beta = arena + h->o_pln2_b; f.pos = arena + h->o_pos; f.cls = arena + h->o_cls;
+            f.rows = R; f.T = h->T; f.D = D; f.DP = DP; f.eps = 1e-5f; f.drop = pa.drop;
+            CHECK(launch_patch_ln2_finish(f, s));
+        } else {
+            g.C = xcur;
+            g.pos = arena + h->o_pos; g.cls = arena + h->o_cls; g.T = h->T; g.n_valid = D;
+            g.drop = pa.drop;
+            CHECK(launch_gemm_nt(g, EPI_PATCH, s));
+        }
     } else {
         CHECK(launch_patch_embed_fwd(pa, s));
     }
@@ -714,7 +767,34 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
     pa.D = D; pa.DP = DP; pa.x = (float*)gin;
     pa.drop = make_drop(train, h->c.p_dropout, seed, 0xFFFFu);
     pa.dW = grads + h->o_pw; pa.dbias = grads + h->o_pb; pa.dcls = grads + h->o_cls; pa.dpos = grads + h->o_pos;
-    if (h->s_pw >= 0) {  // dpos / dcls + bf16 gradient, U recomputed from the images, then dW (+ dbias through the ones column)
+    if (h->s_pw >= 0 && h->c.patch_mode >= 2) {
+        // modes 2 / 3: [LayerNorm(D) backward] -> dW (+ dbias) against the normalised patches of the forward -> dU -> LayerNorm(patch) parameter gradients
+        const char* ws = (const char*)workspace;
+        bf16_t* gd = (bf16_t*)(sc + sl.pgd);
+        const bool ln2 = h->c.patch_mode == 3;
+        float* gdf = ln2 ? (float*)(sc + sl.dz) : nullptr;  // fp32 scratch, free at this point
+        CHECK(launch_patch_bwd_pos_cast_nocls(pa, gd, gdf, s));
+        if (ln2) {
+            LnBwdArgs lb{};
+            lb.dz = gdf; lb.x = (const float*)(ws + w.py); lb.mean = (const float*)(ws + w.pmean2); lb.rstd = (const float*)(ws + w.prstd2);
+            lb.gamma = arena + h->o_pln2_w; lb.gin = nullptr; lb.gout = (float*)(sc + sl.G);
+            lb.dgamma = grads + h->o_pln2_w; lb.dbeta = grads + h->o_pln2_b; lb.dy_next = gd;
+            lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
+            CHECK(launch_ln_bwd(lb, s));
+        }
+        GemmTNArgs t{};
+        t.Y = gd; t.ldy = DP; t.X = (const bf16_t*)(ws + w.u_hi); t.ldx = h->PDX; t.M = R; t.NY = DP; t.NX = h->PDX; t.dW = grads + h->o_pw; t.ldw = h->PD;
+        t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->PDX; t.xseg_valid = h->PD; t.alpha = 1.f;
+        t.dbias = grads + h->o_pb; t.ones_col = h->PD;
+        t.m_chunk = tp.mc_patch; t.slab = slab;
+        CHECK(launch_gemm_tn(t, s));
+        float* du = (float*)(sc + sl.pdu);
+        GemmNTArgs g{};
+        g.A = gd; g.lda = DP; g.B = (const bf16_t*)(sh + h->s_pw_t); g.ldb = DP; g.M = R; g.N = h->PD; g.K = DP; g.C = du; g.ldc = h->PD;
+        CHECK(launch_gemm_nt(g, EPI_F32, s));
+        CHECK(launch_ln_param_grad(du, h->PD, (const float*)(ws + w.u32), h->PDX, (const float*)(ws + w.pmean1), (const float*)(ws + w.prstd1), R, h->PD,
+                                   grads + h->o_pln_w, grads + h->o_pln_b, s));
+    } else if (h->s_pw >= 0) {  // dpos / dcls + bf16 gradient, U recomputed from the images, then dW (+ dbias through the ones column)
         bf16_t* gd = (bf16_t*)(sc + sl.pgd);
         bf16_t* u = (bf16_t*)(sc + sl.pu);
         CHECK(launch_patch_bwd_pos_cast(pa, gd, s));

@@ -40,6 +40,23 @@ int launch_patch_embed_bwd(const PatchArgs& a, hipStream_t s);
 int launch_patch_unfold(const PatchArgs& a, bf16_t* u_hi, bf16_t* u_lo, int ldu, hipStream_t s);
 // backward prologue: dpos / dcls sums over the batch and gd = bf16(dropout_bwd(g)) [B*T][DP] for the dW GEMM
 int launch_patch_bwd_pos_cast(const PatchArgs& a, bf16_t* gd, hipStream_t s);
+// Patch modes 2 / 3 (vit.py:83-100): the unfolded patches in fp32 (they go through a LayerNorm over the patch before
+// the projection). mode 2 = Shifted Patch Tokenization: channels = image + its 4 diagonal shifts by P/2 with zero
+// padding (PatchShifting vit.py:15-38, single-channel input), patch width (C+4)*P*P. Class-token rows and pad columns 0.
+int launch_patch_unfold_f32(const PatchArgs& a, int spt, float* u, int ldu, hipStream_t s);
+// same backward prologue for modes 2 / 3: gd rows of the class token are ZERO (the projection never sees that row) and
+// the masked gradient is also kept in fp32 (gdf, may be NULL) for the LayerNorm behind the projection (mode 3)
+int launch_patch_bwd_pos_cast_nocls(const PatchArgs& a, bf16_t* gd, float* gdf, hipStream_t s);
+// mode 3 epilogue: x0 = dropout(LN(y) * gamma + beta + pos) for patch rows, dropout(cls + pos[0]) for class-token rows
+struct PatchLn2Args {
+    const float* y; float* x0; float* mean; float* rstd;
+    const float* gamma; const float* beta; const float* pos; const float* cls;
+    int rows, T, D, DP; float eps; DropCfg drop;
+};
+int launch_patch_ln2_finish(const PatchLn2Args& a, hipStream_t s);
+// LayerNorm parameter gradients only: dgamma[c] += sum_r dz[r][c] * xhat[r][c], dbeta[c] += sum_r dz[r][c]
+int launch_ln_param_grad(const float* dz, int lddz, const float* x, int ldx, const float* mean, const float* rstd, int rows, int D,
+                         float* dgamma, float* dbeta, hipStream_t s);
 
 struct LnFwdArgs {
     const float* x;      // [rows][DP]
@@ -60,7 +77,7 @@ struct LnBwdArgs {
     const float* x;      // LN input
     const float* mean; const float* rstd;
     const float* gamma;  // [D]
-    const float* gin;    // [rows][DP] residual-stream grad flowing past the LN
+    const float* gin;    // [rows][DP] residual-stream grad flowing past the LN, or nullptr (= 0)
     float* gout;         // [rows][DP] = gin + dx
     float* dgamma; float* dbeta;  // [D] atomics
     float* dinject;      // [B][DP] atomics or nullptr: sum over the image's tokens of gout

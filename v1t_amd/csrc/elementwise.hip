@@ -156,6 +156,116 @@ __global__ void patch_bwd_pos_cast_kernel(PatchArgs a, bf16_t* gd) {
     }
 }
 
+// fp32 unfold for patch modes 2 / 3; thread = one 16-B chunk (4 columns) of one row
+__global__ __launch_bounds__(256) void patch_unfold_f32_kernel(PatchArgs a, int spt, float* u, int ldu) {
+    const int PP = a.P * a.P, L = a.NH * a.NW, T = L + 1, cpr = ldu / 4;
+    const int CH = spt ? a.C + 4 : a.C, PD = CH * PP, sh = a.P / 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.B * T * cpr) return;
+    const int jc = (int)(idx % cpr);
+    const long long row = idx / cpr;
+    const int t = (int)(row % T), b = (int)(row / T);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t > 0) {
+        const int l = t - 1, y0 = (l / a.NW) * a.stride, x0 = (l % a.NW) * a.stride;
+        const float* img = a.img + (size_t)b * a.C * a.IH * a.IW;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * jc + e;
+            if (j < PD) {
+                const int c = j / PP, kh = (j % PP) / a.P, kw = j % a.P;
+                int yy = y0 + kh, xx = x0 + kw, ch = c;
+                if (spt && c >= a.C) {  // shifted copies of channel 0: left-upper, right-upper, left-bottom, right-bottom
+                    const int q = c - a.C;  // padded[..., yy + (q>>1 ? 2sh : 0), xx + (q&1 ? 2sh : 0)] with pad sh on every side
+                    yy += ((q >> 1) ? sh : -sh);
+                    xx += ((q & 1) ? sh : -sh);
+                    ch = 0;
+                }
+                if (yy >= 0 && yy < a.IH && xx >= 0 && xx < a.IW) v[e] = img[((size_t)ch * a.IH + yy) * a.IW + xx];
+            }
+        }
+    }
+    *(f32x4*)(u + row * ldu + 4 * jc) = v;
+}
+
+__global__ void patch_bwd_pos_cast_nocls_kernel(PatchArgs a, bf16_t* gd, float* gdf) {
+    const int L = a.NH * a.NW, T = L + 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * a.DP) return;
+    const int t = idx / a.DP, d = idx % a.DP;
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        const int row = b * T + t;
+        float g = 0.f;
+        if (d < a.D) {
+            g = a.x[(size_t)row * a.DP + d];
+            if (a.drop.thresh) g = drop_keep(a.drop.key, row, d, a.drop.thresh) ? g * a.drop.inv_keep : 0.f;
+        }
+        s += g;
+        const float gp = t == 0 ? 0.f : g;  // the class-token row bypasses the projection
+        gd[(size_t)row * a.DP + d] = (bf16_t)gp;
+        if (gdf) gdf[(size_t)row * a.DP + d] = gp;
+    }
+    if (d < a.D) {
+        a.dpos[(size_t)t * a.D + d] += s;
+        if (t == 0) a.dcls[d] += s;
+    }
+}
+
+// one wave per row (mode 3 only, not a hot path)
+__global__ __launch_bounds__(256) void patch_ln2_finish_kernel(PatchLn2Args a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int t = row % a.T;
+    float v[4], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (c < a.D) ? a.y[(size_t)row * a.DP + c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / a.D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        const float d = (c < a.D) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / a.D + a.eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= a.DP) continue;
+        float o = 0.f;
+        if (c < a.D) {
+            o = (t == 0) ? a.cls[c] + a.pos[c] : (v[i] - mean) * rstd * a.gamma[c] + a.beta[c] + a.pos[(size_t)t * a.D + c];
+            if (a.drop.thresh) o = drop_keep(a.drop.key, row, c, a.drop.thresh) ? o * a.drop.inv_keep : 0.f;
+        }
+        a.x0[(size_t)row * a.DP + c] = o;
+    }
+    if (lane == 0) {
+        a.mean[row] = mean;
+        a.rstd[row] = rstd;
+    }
+}
+
+// thread = column, workgroup = 64 rows (not a hot path)
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* dz, int lddz, const float* x, int ldx, const float* mean, const float* rstd,
+                                                            int rows, int D, float* dgamma, float* dbeta) {
+    const int r0 = blockIdx.x * 64;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float sg = 0.f, sb = 0.f;
+        for (int r = r0; r < min(r0 + 64, rows); ++r) {
+            const float g = dz[(size_t)r * lddz + c];
+            sg += g * (x[(size_t)r * ldx + c] - mean[r]) * rstd[r];
+            sb += g;
+        }
+        atomicAdd(&dgamma[c], sg);
+        atomicAdd(&dbeta[c], sb);
+    }
+}
+
 // dWp[d][j] += sum_{b,l} gd[b][1+l][d] * U[b][l][j]; dbp[d] += sum gd.  Workgroup = 64 patches of one
 // image, thread = d, 16 j's at a time in registers; results are transposed through LDS so each
 // atomic wave-instruction covers 64-B runs instead of 64 different rows.
@@ -319,7 +429,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
             const size_t o = (size_t)row * a.DP + 4 * (j + 8 * k);
             dz[k] = *(const f32x4*)(a.dz + o);
             xh[k] = *(const f32x4*)(a.x + o);
-            gi[k] = *(const f32x4*)(a.gin + o);
+            gi[k] = a.gin ? *(const f32x4*)(a.gin + o) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -651,18 +761,15 @@ int launch_patch_embed_bwd(const PatchArgs& a, hipStream_t s) {
 }
 
 int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
-    if (a.DP > 256 || a.DP % 32 != 0) return V1T_ERR_UNSUPPORTED;
+    if (a.DP > 384 || a.DP % 32 != 0) return V1T_ERR_UNSUPPORTED;
     const dim3 grid((a.rows + 31) / 32);
+#define LN_FWD_CASE(N) case N: hipLaunchKernelGGL(ln_fwd_kernel<N>, grid, dim3(256), 0, s, a); break;
     switch (a.DP / 32) {
-        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
-        case 5: hipLaunchKernelGGL(ln_fwd_kernel<5>, grid, dim3(256), 0, s, a); break;
-        case 6: hipLaunchKernelGGL(ln_fwd_kernel<6>, grid, dim3(256), 0, s, a); break;
-        case 7: hipLaunchKernelGGL(ln_fwd_kernel<7>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, s, a); break;
+        LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) LN_FWD_CASE(5) LN_FWD_CASE(6)
+        LN_FWD_CASE(7) LN_FWD_CASE(8) LN_FWD_CASE(9) LN_FWD_CASE(10) LN_FWD_CASE(11) LN_FWD_CASE(12)
+        default: return V1T_ERR_UNSUPPORTED;
     }
+#undef LN_FWD_CASE
     return ok();
 }
 
@@ -746,5 +853,25 @@ int launch_resize_bilinear(const float* in, float* out, int planes, int IH, int 
     const long long n = (long long)planes * OH * OW;
     if (n <= 0) return V1T_OK;
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, planes, IH, IW, OH, OW);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_patch_unfold_f32(const PatchArgs& a, int spt, float* u, int ldu, hipStream_t s) {
+    const long long n = (long long)a.B * (a.NH * a.NW + 1) * (ldu / 4);
+    hipLaunchKernelGGL(patch_unfold_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, spt, u, ldu);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_patch_bwd_pos_cast_nocls(const PatchArgs& a, bf16_t* gd, float* gdf, hipStream_t s) {
+    const int T = a.NH * a.NW + 1;
+    hipLaunchKernelGGL(patch_bwd_pos_cast_nocls_kernel, dim3((T * a.DP + 255) / 256), dim3(256), 0, s, a, gd, gdf);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_patch_ln2_finish(const PatchLn2Args& a, hipStream_t s) {
+    if (a.DP > 256) return V1T_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(patch_ln2_finish_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_ln_param_grad(const float* dz, int lddz, const float* x, int ldx, const float* mean, const float* rstd, int rows, int D,
+                         float* dgamma, float* dbeta, hipStream_t s) {
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((rows + 63) / 64), dim3(256), 0, s, dz, lddz, x, ldx, mean, rstd, rows, D, dgamma, dbeta);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + 32 * wave + acc_row(r, lane);
-                resv[nb][r] = (row < g.M) ? g.res[(size_t)row * g.ldres + n0 + 32 * nb + (lane & 31)] : 0.f;
+                resv[nb][r] = (g.res && row < g.M) ? g.res[(size_t)row * g.ldres + n0 + 32 * nb + (lane & 31)] : 0.f;
             }
     }
     u32x4 ra[A_ITERS], rb[B_ITERS];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_split_kernel(GemmNTArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + 32 * wave + acc_row(r, lane);
-                resv[nb][r] = (row < g.M) ? g.res[(size_t)row * g.ldres + n0 + 32 * nb + (lane & 31)] : 0.f;
+                resv[nb][r] = (g.res && row < g.M) ? g.res[(size_t)row * g.ldres + n0 + 32 * nb + (lane & 31)] : 0.f;
             }
     }
     u32x4 ra[2][A_ITERS], rb[2][B_ITERS];
