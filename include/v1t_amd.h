@@ -80,14 +80,18 @@ int v1t_vit_pack(const v1t_vit* h, const float* arena, void* shadow, void* strea
 int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, const float* images,
                     const float* behaviors, int mouse_idx, int batch, void* workspace,
                     long long workspace_bytes, int save_for_backward, int training, uint64_t seed,
-                    float* out, void* stream);
+                    const float* path_scale, float* out, void* stream);
+/* path_scale: stochastic depth (DropPath, models/utils.py:121-141; vit.py:360-361) - NULL (= identity: eval, or
+ * drop_path 0) or device floats [num_blocks][2][batch]: the factor floor(keep + U) / keep of sample b for the
+ * {attention, MLP} branch of each block, drawn by the caller (one U[0,1) per sample and branch, as the reference does).
+ * The backward must be given the same array. */
 
 /* Backward of the above: gout (B,T,DP) fp32 = dL/d out; accumulates (+=) into grads, a flat fp32
  * buffer with the arena's layout (gradient accumulation over mice, train.py:97-111, is free). */
 int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, const float* images,
                      const float* behaviors, int mouse_idx, int batch, const void* workspace,
                      void* scratch, long long scratch_bytes, int training, uint64_t seed,
-                     const float* gout, float* grads, void* stream);
+                     const float* path_scale, const float* gout, float* grads, void* stream);
 
 /* keep-mask of one dropout stream, for replaying the exact mask in a CPU check.
  * stream ids: 8*block + {0: attention P (rows B*H*T, cols T), 1: proj out, 2: fc1 out, 3: fc2 out}

@@ -100,7 +100,7 @@ def ref_args(cfg: O.Config, ds_name="sensorium"):
         core="vit", readout="gaussian2d", behavior_mode=cfg.behavior_mode, shift_mode=cfg.shift_mode,
         center_crop=1.0, resize_image=0, ds_name=ds_name, patch_size=cfg.patch_size, patch_mode=cfg.patch_mode,
         patch_stride=cfg.patch_stride, num_blocks=cfg.num_blocks, num_heads=cfg.num_heads, emb_dim=cfg.emb_dim,
-        mlp_dim=cfg.mlp_dim, p_dropout=cfg.p_dropout, t_dropout=cfg.t_dropout, drop_path=0.0, use_lsa=cfg.use_lsa,
+        mlp_dim=cfg.mlp_dim, p_dropout=cfg.p_dropout, t_dropout=cfg.t_dropout, drop_path=cfg.drop_path, use_lsa=cfg.use_lsa,
         disable_bias=cfg.disable_bias, core_reg_scale=cfg.core_reg_scale,
         disable_grid_predictor=cfg.disable_grid_predictor, grid_predictor_dim=cfg.grid_predictor_dim,
         bias_mode=cfg.bias_mode, readout_reg_scale=cfg.readout_reg_scale, shifter_reg_scale=cfg.shifter_reg_scale,
@@ -387,6 +387,49 @@ def gen_elu_edge(out: dict, log=print):
     log("  elu edge: ok")
 
 
+def gen_drop_path(out: dict, log=print):
+    """G7: stochastic depth (DropPath, models/utils.py:121-141; vit.py:360-361) in train mode, every other dropout 0.
+    The reference draws torch.rand((B,1,1)) per branch (block order, mha then mlp) and then the readout's eps; the same
+    draws are replayed into the oracle as masks."""
+    cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 128},
+                   p_dropout=0.0, t_dropout=0.0, drop_path=0.3)
+    mouse, B, seed, rng_seed, ds_size = "A", 6, 77, 2468, 4500.0
+    sd = W.make_state_dict(cfg, seed)
+    batch = W.make_batch(cfg, mouse, B, seed)
+    model = build_reference_model(cfg, sd, seed)
+    keep = 1.0 - cfg.drop_path
+    torch.manual_seed(rng_seed)
+    dpm = {}
+    for k in range(cfg.num_blocks):
+        for br in ("mha", "mlp"):
+            dpm[(k, br)] = torch.floor(keep + torch.rand((B, 1, 1), dtype=torch.float32)).reshape(B)
+    eps = torch.empty(B, cfg.num_neurons[mouse], 1, 2).normal_().reshape(B, -1, 2)
+    marr = torch.stack([torch.stack([dpm[(k, "mha")], dpm[(k, "mlp")]]) for k in range(cfg.num_blocks)])  # (NB, 2, B)
+    assert 0 < float(marr.sum()) < marr.numel(), "pick a seed that drops some and keeps some"
+    loss, reg, y, grads, _ = ref_forward_backward(model, cfg, batch, mouse, ds_size, train_eps_seed=rng_seed)
+    for dt, rt, at in ((torch.float32, 2e-4, 2e-5), (torch.float64, 2e-5, 2e-6)):
+        sdd = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        b = {k: v.to(dt) for k, v in batch.items()}
+        ol, orr, oy = O.total_loss(cfg, sdd, b, mouse, ds_size, eps=eps.to(dt), masks={"drop_path": dpm})
+        (ol + orr).backward()
+        e1 = check(f"g7.y[{dt}]", y, oy, rt, at)
+        check(f"g7.loss[{dt}]", loss, ol, rt, at)
+        eg = 0.0
+        for k, g in grads.items():
+            og = sdd[k].grad if sdd[k].grad is not None else torch.zeros_like(sdd[k])
+            scale = float(g.abs().max()) + 1e-12
+            eg = max(eg, check(f"g7.grad[{k}][{dt}]", g, og, rt * 5, at * 5 + rt * scale) / scale)
+        log(f"  g7: oracle[{str(dt)[6:]}] vs reference: y err {e1:.2e}, worst grad err/scale {eg:.2e}")
+    out["g7/mask"] = marr.numpy()
+    out["g7/eps"] = eps.numpy()
+    out["g7/y"] = y.numpy()
+    out["g7/loss"] = np.float64(loss.item())
+    out["g7/reg"] = np.float64(reg.item())
+    for k, g in grads.items():
+        out[f"g7/grad/{k}"] = sample(g)
+        out[f"g7/gradnorm/{k}"] = np.float64(g.double().norm().item())
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
@@ -396,6 +439,13 @@ def main():
         path = os.path.join(ROOT, "tests", "golden", fname)
         np.savez_compressed(path, **d)
         print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB, {len(d)} arrays")
+
+    d = {}
+    print("G7 drop_path (train mode, stochastic depth 0.3)")
+    gen_drop_path(d)
+    save("g7_drop_path.npz", d)
+    if "--only-g7" in sys.argv:
+        return
 
     d = {}
     print("G1 (C1: 1 block, D=64, 256 neurons, B=2, eval)")

@@ -249,9 +249,17 @@ def vit_tokens(
     pfx: str = "core.",
 ) -> Tensor:
     """ViTCore.forward vit.py:423-433 + Transformer.forward vit.py:348-362, token-major (B,T,D).
-    DropPath is the identity at drop_path=0 (models/utils.py:134-135) — only that case is restated."""
-    assert cfg.drop_path == 0.0, "oracle restates drop_path == 0 only"
+    DropPath (models/utils.py:121-141) is the identity in eval mode or at drop_path=0; in train mode the branch output
+    is `(y / keep) * floor(keep + U[0,1))` with one draw per sample (:136-140). The draws are not made here: pass
+    masks["drop_path"] = {(block, "mha" | "mlp"): (B,) tensor of 0/1} (absent = identity, i.e. eval)."""
     masks = masks or {}
+    dpm = masks.get("drop_path") or {}
+    keep = 1.0 - cfg.drop_path
+
+    def drop_path(y: Tensor, key) -> Tensor:
+        m = dpm.get(key)
+        return y if m is None else (y / keep) * m.to(y.dtype)[:, None, None]
+
     out = patch_embed(cfg, sd, x, masks.get("patch"), pfx=pfx)
     if taps is not None:
         taps["patch_embed"] = out
@@ -262,10 +270,10 @@ def vit_tokens(
     for k in range(cfg.num_blocks):
         if cfg.behavior_mode in (2, 3, 4):
             out = out + behavior_mlp(cfg, sd, k, v, mouse_id, pfx=pfx)[:, None, :]
-        out = attention(cfg, sd, k, out, masks, record, pfx=pfx) + out
+        out = drop_path(attention(cfg, sd, k, out, masks, record, pfx=pfx), (k, "mha")) + out
         if taps is not None:
             taps[f"mha{k}"] = out
-        out = mlp(cfg, sd, k, out, masks, pfx=pfx) + out
+        out = drop_path(mlp(cfg, sd, k, out, masks, pfx=pfx), (k, "mlp")) + out
         if taps is not None:
             taps[f"mlp{k}"] = out
     return out

@@ -106,15 +106,50 @@ def test_variants_vs_reference_golden(golden, dev, vn):
 
 
 def test_unsupported_variants_fail_loudly(dev):
-    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128)
     import v1t_amd
     from v1t_amd.synthetic import default_args, make_ds
 
-    args = default_args(input_shape=cfg.input_shape, resize_image=0, num_blocks=1, emb_dim=64, mlp_dim=128)
+    args = default_args(input_shape=(1, 36, 64), resize_image=0, num_blocks=1, emb_dim=64, mlp_dim=128)
     args.output_shapes = {"A": (8,)}
-    args.drop_path = 0.1  # stochastic depth has no native kernel: must raise, not fall back
+    args.shift_mode = 1  # learned image shifter (gradient w.r.t. the core input): no native path -> must raise, not fall back
     with pytest.raises(NotImplementedError):
         v1t_amd.Model(args, make_ds({"A": 8}))
+
+
+def test_drop_path_vs_reference_golden(dev):
+    """G7: stochastic depth (DropPath, models/utils.py:121-141) in train mode with the reference's draws replayed:
+    predictions, loss and every gradient against the golden run of the real reference."""
+    import os
+
+    from v1t_amd.losses import elu1_poisson_loss
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_drop_path.npz"))
+    cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 128}, p_dropout=0.0, t_dropout=0.0, drop_path=0.3)
+    sd = W.make_state_dict(cfg, 77)
+    batch = W.make_batch(cfg, "A", 6, 77)
+    model, _ = build_native_model(cfg, sd, dev)
+    model.train(True)
+    keep = 1.0 - cfg.drop_path
+    model.core._path_scale_override = torch.from_numpy(g["g7/mask"]).to(dev) / keep
+    bd = {k: v.to(dev) for k, v in batch.items()}
+    eps = torch.from_numpy(g["g7/eps"]).to(dev)
+    z = model.core(bd["image"], mouse_id="A", behaviors=bd["behavior"], pupil_centers=bd["pupil_center"])
+    shifts = model.core_shifter(bd["pupil_center"], mouse_id="A")
+    u = model.readouts["A"](z, shifts=shifts, eps=eps)
+    loss, y = elu1_poisson_loss(u, bd["response"], 4500.0, 6)
+    (loss + model.regularizer("A")).backward()
+    assert_close("g7.y", y.detach().cpu().numpy(), g["g7/y"], Y_RTOL, Y_ATOL)
+    assert abs(float(loss) - float(g["g7/loss"])) <= 1e-4 * abs(float(g["g7/loss"]))
+    n = 0
+    for k, p in model.named_parameters():
+        gk = f"g7/grad/{k}"
+        if gk not in g.files or p.grad is None:
+            continue
+        ref = g[gk]
+        if float(np.abs(ref).max()) > 0:
+            assert rel_to_max(sample(p.grad), ref) < G_TOL, k
+        n += 1
+    assert n >= 20
 
 
 @pytest.mark.parametrize("pm", [2, 3])

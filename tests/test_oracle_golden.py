@@ -1,6 +1,8 @@
 """CPU: the oracle (oracle/v1t_oracle.py) against the golden vectors generated from the real reference
 (oracle/gen_golden.py, run in the build container). This is what pins the oracle on the GPU box where
 /root/reference does not exist."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -102,6 +104,23 @@ def test_optimizer_step_vs_golden(golden):
     O.adamw_step(params, {k: osd[k].grad for k in keys}, {}, step=1, lr=1.647e-3)
     for k in keys:
         assert_close(f"step.{k}", sample(params[k]), golden[f"step/param/{k}"], 1e-4, 1e-6)
+
+
+def test_drop_path_vs_golden():
+    """G7: stochastic depth in train mode, the reference's torch.rand draws replayed as masks (oracle/gen_golden.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_drop_path.npz"))
+    cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 128}, p_dropout=0.0, t_dropout=0.0, drop_path=0.3)
+    sd = W.make_state_dict(cfg, 77)
+    batch = W.make_batch(cfg, "A", 6, 77)
+    m = torch.from_numpy(g["g7/mask"])
+    dpm = {(k, br): m[k, i] for k in range(2) for i, br in enumerate(("mha", "mlp"))}
+    sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    loss, reg, y = O.total_loss(cfg, sdd, batch, "A", 4500.0, eps=torch.from_numpy(g["g7/eps"]), masks={"drop_path": dpm})
+    (loss + reg).backward()
+    assert_close("g7.y", y.detach().numpy(), g["g7/y"], 2e-4, 2e-5)
+    assert abs(float(loss) - float(g["g7/loss"])) <= 1e-5 * abs(float(g["g7/loss"]))
+    for k in ("core.transformer.blocks.0.mha.to_qkv.weight", "core.transformer.blocks.1.mlp.model.4.weight", "core.patch_embedding.pos_embedding"):
+        assert_close(f"g7.grad.{k}", sample(sdd[k].grad), g[f"g7/grad/{k}"], 1e-3, 1e-5 + 1e-3 * float(np.abs(g[f"g7/grad/{k}"]).max()))
 
 
 def test_resize_vs_golden(golden):

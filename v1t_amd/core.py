@@ -94,17 +94,28 @@ class _VitFn(torch.autograd.Function):
         training = core.training
         seed = core._next_seed() if training else 0
         lib = L.load()
+        # stochastic depth (DropPath, models/utils.py:121-141): one U[0,1) per sample and residual branch, as the reference
+        # draws them; the kernels only apply the factor floor(keep + U) / keep
+        ps = None
+        if training and core.drop_path_rate > 0.0:
+            ps = core._path_scale_override
+            if ps is None:
+                keep = 1.0 - core.drop_path_rate
+                ps = torch.floor(keep + torch.rand((core.num_blocks, 2, B), dtype=torch.float32, device=images.device)) / keep
+            ps = ps.to(device=images.device, dtype=torch.float32).contiguous()
+            assert ps.shape == (core.num_blocks, 2, B)
         ws_bytes = lib.v1t_vit_workspace_bytes(core._plan, B, int(need_bwd))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=images.device)
         out = torch.empty((B, core.num_tokens, core.padded_dim), dtype=torch.float32, device=images.device)
         L.check(
             lib.v1t_vit_forward(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), images.data_ptr(),
                                 L.ptr(behaviors), mouse_idx, B, ws.data_ptr(), ws_bytes, int(need_bwd), int(training), seed,
-                                out.data_ptr(), L.stream()),
+                                L.ptr(ps), out.data_ptr(), L.stream()),
             "vit_forward",
         )
         ctx.core, ctx.ws, ctx.images, ctx.behaviors = core, ws, images, behaviors
         ctx.mouse_idx, ctx.seed, ctx.training, ctx.B = mouse_idx, seed, training, B
+        ctx.path_scale = ps
         core._last_ws = (ws, B, bool(need_bwd))
         return out
 
@@ -119,7 +130,7 @@ class _VitFn(torch.autograd.Function):
         L.check(
             lib.v1t_vit_backward(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), ctx.images.data_ptr(),
                                  L.ptr(ctx.behaviors), ctx.mouse_idx, ctx.B, ctx.ws.data_ptr(), scratch.data_ptr(), sb,
-                                 int(ctx.training), ctx.seed, gout.data_ptr(), core._arena.grad.data_ptr(), L.stream()),
+                                 int(ctx.training), ctx.seed, L.ptr(ctx.path_scale), gout.data_ptr(), core._arena.grad.data_ptr(), L.stream()),
             "vit_backward",
         )
         ctx.ws = None
@@ -173,8 +184,8 @@ class ViTCore(Core):
             raise NotImplementedError(f"--patch_mode {args.patch_mode} not implemented.")
         if args.patch_mode == 2 and input_shape[0] != 1:
             raise NotImplementedError("--patch_mode 2 (Shifted Patch Tokenization) is defined for single-channel input only (vit.py:84).")
-        if float(getattr(args, "drop_path", 0.0)) != 0.0:
-            raise NotImplementedError("drop_path > 0 has no gfx950 kernel yet (reference default is 0).")
+        self.drop_path_rate = float(getattr(args, "drop_path", 0.0))
+        assert 0.0 <= self.drop_path_rate < 1.0
         assert 1 <= args.patch_stride <= args.patch_size
         c, h, w = input_shape
         self.mouse_ids = list(args.output_shapes.keys())
@@ -204,6 +215,8 @@ class ViTCore(Core):
         self._anchor = torch.zeros((), requires_grad=True)
         self._seed_state = int(getattr(args, "seed", 1234)) * 1000003 + 12345
         self._last_ws = None
+        self._path_scale_override = None  # tests: (num_blocks, 2, B) factors to replay instead of drawing them
+        self.num_blocks = int(args.num_blocks)
 
     def __del__(self):
         try:

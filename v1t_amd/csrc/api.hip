@@ -499,7 +499,7 @@ int v1t_vit_pack(const v1t_vit* h, const float* arena, void* shadow, void* strea
 
 int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, const float* images, const float* behaviors,
                     int mouse_idx, int B, void* workspace, long long ws_bytes, int save, int training, uint64_t seed,
-                    float* out, void* stream) {
+                    const float* path_scale, float* out, void* stream) {
     if (!h || !arena || !shadow || !images || !workspace || !out || B <= 0) return V1T_ERR_ARG;
     if (h->inject && !behaviors) return V1T_ERR_ARG;
     const WsLayout w = ws_layout(h, B, save != 0);
@@ -607,6 +607,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         if (g_nosplit & 2) g.A_lo = g.B_lo = nullptr;
         g.bias = b.s_projb >= 0 ? (const float*)(sh + b.s_projb) : nullptr; g.res = xa; g.ldres = DP;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 1);
+        g.row_scale = path_scale ? path_scale + (size_t)(2 * k + 0) * B : nullptr; g.T = h->T;
         CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));
 
         LnFwdArgs l2{};
@@ -630,6 +631,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         if (g_nosplit & 8) g.A_lo = g.B_lo = nullptr;
         g.bias = b.s_fc2b >= 0 ? (const float*)(sh + b.s_fc2b) : nullptr; g.res = xm; g.ldres = DP;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 3);
+        g.row_scale = path_scale ? path_scale + (size_t)(2 * k + 1) * B : nullptr; g.T = h->T;
         CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));
         xcur = xo;
     }
@@ -638,7 +640,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
 
 int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, const float* images, const float* behaviors,
                      int mouse_idx, int B, const void* workspace, void* scratch, long long scratch_bytes, int training,
-                     uint64_t seed, const float* gout, float* grads, void* stream) {
+                     uint64_t seed, const float* path_scale, const float* gout, float* grads, void* stream) {
     if (!h || !arena || !shadow || !images || !workspace || !scratch || !gout || !grads || B <= 0) return V1T_ERR_ARG;
     const WsLayout w = ws_layout(h, B, true);
     const ScratchLayout sl = scratch_layout(h, B);
@@ -671,6 +673,7 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         CastArgs ca{};
         ca.g = gout; ca.dy = dy; ca.dbias = b.fc2b >= 0 ? grads + b.fc2b : nullptr;
         ca.drop = make_drop(train, h->c.t_dropout, seed, 8 * (h->NB - 1) + 3);
+        ca.scale = path_scale ? path_scale + (size_t)(2 * (h->NB - 1) + 1) * B : nullptr; ca.T = h->T;
         ca.rows = R; ca.D = D; ca.DP = DP;
         CHECK(launch_drop_cast(ca, s));
     }
@@ -716,6 +719,7 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         lb.gin = gin; lb.gout = G; lb.dgamma = grads + b.ln2w; lb.dbeta = grads + b.ln2b; lb.dinject = nullptr;
         lb.dy_next = dy; lb.dbias_next = b.projb >= 0 ? grads + b.projb : nullptr;
         lb.drop_next = make_drop(train, h->c.t_dropout, seed, 8 * k + 1);
+        lb.scale_next = path_scale ? path_scale + (size_t)(2 * k + 0) * B : nullptr;
         lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
         CHECK(launch_ln_bwd(lb, s));
         gin = G;
@@ -757,6 +761,7 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
             lb.dy_next = dy;
             lb.dbias_next = h->blk[k - 1].fc2b >= 0 ? grads + h->blk[k - 1].fc2b : nullptr;
             lb.drop_next = make_drop(train, h->c.t_dropout, seed, 8 * (k - 1) + 3);
+            lb.scale_next = path_scale ? path_scale + (size_t)(2 * (k - 1) + 1) * B : nullptr;
         }
         lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
         CHECK(launch_ln_bwd(lb, s));

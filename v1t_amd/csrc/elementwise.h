@@ -84,6 +84,7 @@ struct LnBwdArgs {
     bf16_t* dy_next;     // [rows][DP] bf16 = dropout_bwd(gout) for the next (earlier) branch, or nullptr
     float* dbias_next;   // [D] atomics: column sums of dy_next, or nullptr
     DropCfg drop_next;
+    const float* scale_next;  // [B] or nullptr: stochastic-depth factor of the next branch (multiplies dy_next)
     int B, T, D, DP;
 };
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
@@ -94,6 +95,7 @@ struct CastArgs {
     float* dbias;        // [D] atomics or nullptr
     DropCfg drop;
     int rows, D, DP;
+    const float* scale; int T;  // [rows / T] stochastic-depth factor of the branch, or nullptr
 };
 int launch_drop_cast(const CastArgs& a, hipStream_t s);
 

@@ -406,6 +406,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 7, slot = lane >> 3;
     const int b = blockIdx.y, t0 = blockIdx.x * LNB_ROWS;
+    const float snext = a.scale_next ? a.scale_next[b] : 1.f;
     f32x4 gam[CPL], adg[CPL], adb[CPL], ainj[CPL], abn[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
                 adg[k][e] += dz[k][e] * xh[k][e];
                 adb[k][e] += dz[k][e];
                 ainj[k][e] += go[e];
-                float v = go[e];
+                float v = go[e] * snext;
                 if (a.dy_next && a.drop_next.thresh && cok)
                     v = drop_keep(a.drop_next.key, row, c + e, a.drop_next.thresh) ? v * a.drop_next.inv_keep : 0.f;
                 vb[e] = (bf16_t)v;
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(256) void drop_cast_kernel(CastArgs a) {
                 const int c = lane + 64 * i;
                 if (c < a.DP) {
                     float v = g[u][i];
+                    if (a.scale) v *= a.scale[row / a.T];
                     if (a.drop.thresh && c < a.D) v = drop_keep(a.drop.key, row, c, a.drop.thresh) ? v * a.drop.inv_keep : 0.f;
                     const bf16_t vb = (bf16_t)v;
                     a.dy[(size_t)row * a.DP + c] = vb;

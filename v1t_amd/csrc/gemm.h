@@ -38,6 +38,7 @@ struct GemmNTArgs {
     float* colsum; int n_valid;   // fp32 atomics, natural column index < n_valid
     DropCfg drop;
     const float* pos; const float* cls; int T;  // EPI_PATCH: natural [T][n_valid] position table, [n_valid] class token
+    const float* row_scale;       // EPI_BIAS_RES: per-image factor on the branch (stochastic depth), index row / T, or nullptr
 };
 
 struct GemmTNArgs {

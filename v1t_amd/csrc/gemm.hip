@@ -58,6 +58,7 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
             } else if constexpr (EPI == EPI_BIAS_RES) {
                 v += bias;
                 if (g.drop.thresh) v = drop_keep(g.drop.key, row, col, g.drop.thresh) ? v * g.drop.inv_keep : 0.f;
+                if (g.row_scale && ok) v *= g.row_scale[row / g.T];
                 if (ok) ((float*)g.C)[(size_t)row * g.ldc + col] = resv[nb][r] + v;
             } else if constexpr (EPI == EPI_BIAS_GELU) {
                 v += bias;
