@@ -152,6 +152,30 @@ def test_drop_path_vs_reference_golden(dev):
     assert n >= 20
 
 
+def test_behavior_as_channels_vs_oracle(dev):
+    """behavior_mode 1 (image_cropper.py:136-139): the three behaviour variables become constant image channels in front
+    of the core (4-channel patches), no BehaviorMLP. Native model on the raw 1-channel image vs the oracle on the
+    concatenated input."""
+    import v1t_amd
+    from v1t_amd.synthetic import default_args, make_ds
+
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 64}, behavior_mode=1, input_shape=(4, 36, 64))
+    sd = W.make_state_dict(cfg, 5)
+    batch = W.make_batch(cfg, "A", 2, 5)
+    raw = batch["image"][:, :1].contiguous()  # the cropper appends the behaviours itself
+    core_in = torch.cat([raw, batch["behavior"][:, :, None, None].expand(-1, -1, 36, 64)], dim=1)
+    args = default_args(input_shape=(1, 36, 64), resize_image=0, num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, behavior_mode=1)
+    args.output_shapes = {"A": (64,)}
+    model = v1t_amd.Model(args, make_ds({"A": 64}))
+    r = model.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys, r.unexpected_keys
+    model = model.to(dev).train(False)
+    with torch.no_grad():
+        y = model(inputs=raw.to(dev), mouse_id="A", behaviors=batch["behavior"].to(dev), pupil_centers=batch["pupil_center"].to(dev))[0]
+        ref = O.model_forward(cfg, sd, core_in, "A", batch["behavior"], batch["pupil_center"])
+    assert_close("beh1.y", y.cpu().numpy(), ref.numpy(), Y_RTOL, Y_ATOL)
+
+
 @pytest.mark.parametrize("pm", [2, 3])
 def test_patch_modes_2_3_gradients_vs_oracle(dev, pm):
     """SPT / dual-PatchNorm tokenisers (vit.py:83-100): every parameter gradient of the core against the oracle's
