@@ -147,6 +147,12 @@ int v1t_core_shifter_backward(int B, const float* pupil, const float* W0, const 
                               float* dW0, float* db0, float* dW2, float* db2, float* dW4, float* db4,
                               void* stream);
 
+/* ImageCropper crop (image_cropper.py:101-110,126-133): F.grid_sample(mode="nearest", align_corners=True) of
+ * in[B][C][IH][IW] over grid[OH][OW][2] = (x, y) in [-1, 1] (the module's `grid` buffer), moved per image by
+ * shifts[B][2] (the ImageShifter output, image_cropper.py:41-47; NULL = none). Outside the image -> 0. */
+int v1t_crop_nearest(const float* in, int B, int C, int IH, int IW, const float* grid, const float* shifts, float* out,
+                     int OH, int OW, void* stream);
+
 /* ImageCropper resize (image_cropper.py:96-99,134-135): torchvision Resize(antialias=False) = bilinear, half-pixel
  * centres, on `planes` = B*C images of IH x IW -> OH x OW (144x256 -> 36x64 for Sensorium). */
 int v1t_resize_bilinear(const float* in, int planes, int IH, int IW, float* out, int OH, int OW, void* stream);

@@ -98,14 +98,14 @@ class FakeDS:
 def ref_args(cfg: O.Config, ds_name="sensorium"):
     return SimpleNamespace(
         core="vit", readout="gaussian2d", behavior_mode=cfg.behavior_mode, shift_mode=cfg.shift_mode,
-        center_crop=1.0, resize_image=0, ds_name=ds_name, patch_size=cfg.patch_size, patch_mode=cfg.patch_mode,
+        center_crop=cfg.center_crop, resize_image=0, ds_name=ds_name, patch_size=cfg.patch_size, patch_mode=cfg.patch_mode,
         patch_stride=cfg.patch_stride, num_blocks=cfg.num_blocks, num_heads=cfg.num_heads, emb_dim=cfg.emb_dim,
         mlp_dim=cfg.mlp_dim, p_dropout=cfg.p_dropout, t_dropout=cfg.t_dropout, drop_path=cfg.drop_path, use_lsa=cfg.use_lsa,
         disable_bias=cfg.disable_bias, core_reg_scale=cfg.core_reg_scale,
         disable_grid_predictor=cfg.disable_grid_predictor, grid_predictor_dim=cfg.grid_predictor_dim,
         bias_mode=cfg.bias_mode, readout_reg_scale=cfg.readout_reg_scale, shifter_reg_scale=cfg.shifter_reg_scale,
-        cropper_reg_scale=0.0, device=torch.device("cpu"), verbose=0, grad_checkpointing=0,
-        input_shape=cfg.input_shape, output_shapes={m: (cfg.num_neurons[m],) for m in cfg.mouse_ids}, ds_scale=1,
+        cropper_reg_scale=cfg.cropper_reg_scale, device=torch.device("cpu"), verbose=0, grad_checkpointing=0,
+        input_shape=cfg.raw_input_shape or cfg.input_shape, output_shapes={m: (cfg.num_neurons[m],) for m in cfg.mouse_ids}, ds_scale=1,
     )
 
 
@@ -137,7 +137,7 @@ def oracle_grads(cfg, sd, batch, mouse_id, ds_size, eps=None, dtype=torch.float3
     b = {k: v.to(dtype) for k, v in batch.items()}
     loss, reg, y = O.total_loss(cfg, sdd, b, mouse_id, ds_size, eps=None if eps is None else eps.to(dtype))
     (loss + reg).backward()
-    keys = O.core_param_keys(sd) + O.readout_param_keys(sd, mouse_id) + O.shifter_param_keys(sd, mouse_id)
+    keys = O.core_param_keys(sd) + O.readout_param_keys(sd, mouse_id) + O.shifter_param_keys(sd, mouse_id) + O.image_shifter_param_keys(sd, mouse_id)
     # a parameter the restatement never touches (sigma in eval mode) has an all-zero gradient in the reference
     return loss.detach(), reg.detach(), y.detach(), {k: (sdd[k].grad if sdd[k].grad is not None else torch.zeros_like(sdd[k])) for k in keys}
 
@@ -430,6 +430,67 @@ def gen_drop_path(out: dict, log=print):
         out[f"g7/gradnorm/{k}"] = np.float64(g.double().norm().item())
 
 
+def gen_image_shift(out: dict, log=print):
+    """G8: center crop < 1 with the learned image shifter (shift_mode 1 / 3 / 4; image_cropper.py:10-47,120-133) from the
+    RAW image. Outputs for the three modes, the cropped core input, and every gradient for mode 4 (with shifter /
+    cropper L1 so that the image-shifter gradient is the sign term, nearest sampling passing none)."""
+    ds_size, B, seed = 4500.0, 3, 91
+    for sm in (1, 3, 4):
+        cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 96, "B": 50},
+                       shift_mode=sm, center_crop=0.8, raw_input_shape=(1, 36, 64), input_shape=(1, int(36 * 0.8), int(64 * 0.8)),
+                       shifter_reg_scale=0.01, cropper_reg_scale=0.02)
+        name = f"g8/sm{sm}"
+        sd = W.make_state_dict(cfg, seed)
+        model = build_reference_model(cfg, sd, seed)
+        mouse = "B" if sm == 3 else "A"
+        batch = W.make_batch(cfg, mouse, B, seed)
+        assert tuple(batch["image"].shape[1:]) == (1, 36, 64)
+        loss, reg, y, grads, _ = ref_forward_backward(model, cfg, batch, mouse, ds_size)
+        model.train(False)
+        with torch.no_grad():
+            _, img, grid = model(inputs=batch["image"], mouse_id=mouse, behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
+            oshift = O.image_shifter(cfg, sd, mouse, batch["behavior"], batch["pupil_center"])
+            oimg = O.crop_nearest(batch["image"], cfg.center_crop, oshift)
+        check(f"{name}.shift", grid[:, 0, 0, :] - model.image_cropper.grid[:, 0, 0, :], oshift, 1e-5, 1e-7)
+        assert float(oshift.abs().max()) > 0.02, "shifts too small to move the window"
+        check(f"{name}.crop", img, oimg, 0.0, 1e-30)  # a gather: bit-exact
+        for dt, rt, at in ((torch.float32, 2e-4, 2e-5), (torch.float64, 2e-5, 2e-6)):
+            ol, orr, oy, og = oracle_grads(cfg, sd, batch, mouse, ds_size, dtype=dt)
+            e1 = check(f"{name}.y[{dt}]", y, oy, rt, at)
+            check(f"{name}.loss[{dt}]", loss, ol, rt, at)
+            check(f"{name}.reg[{dt}]", reg, orr, rt, at)
+            assert set(grads) == set(og), set(grads) ^ set(og)
+            eg = 0.0
+            for k, g in grads.items():
+                scale = float(g.abs().max()) + 1e-12
+                eg = max(eg, check(f"{name}.grad[{k}][{dt}]", g, og[k], rt * 5, at * 5 + rt * scale) / scale)
+            log(f"  {name}: oracle[{str(dt)[6:]}] vs reference: y err {e1:.2e}, worst grad err/scale {eg:.2e}")
+        out[f"{name}/y"] = y.numpy()
+        out[f"{name}/shift"] = oshift.numpy()
+        out[f"{name}/crop"] = img.numpy()
+        out[f"{name}/loss"] = np.float64(loss.item())
+        out[f"{name}/reg"] = np.float64(reg.item())
+        if sm == 4:
+            for k, g in grads.items():
+                out[f"{name}/grad/{k}"] = sample(g)
+                out[f"{name}/gradnorm/{k}"] = np.float64(g.double().norm().item())
+    # center crop alone (shift_mode 2): the fixed window
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 96}, center_crop=0.7,
+                   raw_input_shape=(1, 36, 64), input_shape=(1, int(36 * 0.7), int(64 * 0.7)))
+    sd = W.make_state_dict(cfg, seed)
+    model = build_reference_model(cfg, sd, seed)
+    batch = W.make_batch(cfg, "A", B, seed)
+    model.train(False)
+    with torch.no_grad():
+        y, img, _ = model(inputs=batch["image"], mouse_id="A", behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
+        oy = O.model_forward_raw(cfg, sd, batch["image"], "A", batch["behavior"], batch["pupil_center"])
+    check("g8/crop07.crop", img, O.crop_nearest(batch["image"], 0.7, None), 0.0, 1e-30)
+    check("g8/crop07.y", y, oy, 2e-4, 2e-5)
+    out["g8/crop07/y"] = y.numpy()
+    out["g8/crop07/crop"] = img.numpy()
+    log("  g8/crop07: ok")
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
@@ -439,6 +500,13 @@ def main():
         path = os.path.join(ROOT, "tests", "golden", fname)
         np.savez_compressed(path, **d)
         print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB, {len(d)} arrays")
+
+    d = {}
+    print("G8 center crop + learned image shifter (shift_mode 1/3/4)")
+    gen_image_shift(d)
+    save("g8_image_shift.npz", d)
+    if "--only-g8" in sys.argv:
+        return
 
     d = {}
     print("G7 drop_path (train mode, stochastic depth 0.3)")

@@ -56,6 +56,9 @@ class Config:
     core_reg_scale: float = 0.5379
     readout_reg_scale: float = 0.0076
     shifter_reg_scale: float = 0.0
+    cropper_reg_scale: float = 0.0
+    center_crop: float = 1.0  # < 1: input_shape above is the CROPPED shape (int(h * crop), int(w * crop)), raw_input_shape the image's
+    raw_input_shape: t.Optional[t.Tuple[int, int, int]] = None
     shift_mode: int = 2
     disable_grid_predictor: bool = False
     grid_predictor_dim: int = 2
@@ -433,6 +436,49 @@ def image_cropper(x: Tensor, resize: t.Optional[t.Tuple[int, int]] = (36, 64)) -
     return x if resize is None else resize_bilinear(x, resize)
 
 
+def image_shifter(cfg: Config, sd: SD, mouse_id: str, behaviors: Tensor, pupil_centers: Tensor) -> Tensor:
+    """ImageShifter.forward image_cropper.py:41-47 as ImageCropper builds it (num_layers=3, hidden 10, :82-88):
+    (pupil | behaviour + pupil for shift_mode 4) -> 10 -> 10 -> 2, tanh after every layer, times max_shift = 1 - crop."""
+    p = f"image_cropper.image_shifter.{mouse_id}.mlp."
+    x = torch.cat((behaviors, pupil_centers), dim=-1) if cfg.shift_mode == 4 else pupil_centers
+    h = torch.tanh(linear(x, sd[p + "0.weight"], sd[p + "0.bias"]))
+    h = torch.tanh(linear(h, sd[p + "2.weight"], sd[p + "2.bias"]))
+    h = torch.tanh(linear(h, sd[p + "4.weight"], sd[p + "4.bias"]))
+    return h * (1.0 - cfg.center_crop)
+
+
+def crop_nearest(x: Tensor, crop_scale: float, shifts: t.Optional[Tensor]) -> Tensor:
+    """The crop of ImageCropper.forward (image_cropper.py:101-110, 126-133): identity grid linspace(-s, s, int(size * s))
+    per axis (+ per-image (x, y) shifts), F.grid_sample(mode="nearest", align_corners=True, zeros padding): source pixel
+    = nearbyint((g + 1) / 2 * (size - 1)) (round half to even), outside the image -> 0. No gradient reaches the shifts."""
+    b, c, h, w = x.shape
+    ch, cw = (h, w) if crop_scale >= 1 else (int(h * crop_scale), int(w * crop_scale))
+    # the sampling coordinates are fp32 in the reference whatever precision the rest of the oracle runs in
+    gy = torch.linspace(-crop_scale, crop_scale, ch, dtype=torch.float32)[None, :].expand(b, -1)
+    gx = torch.linspace(-crop_scale, crop_scale, cw, dtype=torch.float32)[None, :].expand(b, -1)
+    if shifts is not None:
+        sh = shifts.detach().to(torch.float32)
+        gx = gx + sh[:, 0:1]
+        gy = gy + sh[:, 1:2]
+    iy = torch.round((gy + 1) / 2 * (h - 1)).long()
+    ix = torch.round((gx + 1) / 2 * (w - 1)).long()
+    oky = (iy >= 0) & (iy < h)
+    okx = (ix >= 0) & (ix < w)
+    out = x[torch.arange(b)[:, None, None], :, iy.clamp(0, h - 1)[:, :, None], ix.clamp(0, w - 1)[:, None, :]]  # (b, ch, cw, c)
+    out = out * (oky[:, :, None, None] & okx[:, None, :, None]).to(x.dtype)
+    return out.permute(0, 3, 1, 2)
+
+
+def model_forward_raw(cfg: Config, sd: SD, raw: Tensor, mouse_id: str, behaviors: Tensor, pupil_centers: Tensor, **kw) -> Tensor:
+    """Model.forward model.py:151-177 from the RAW image: crop (+ learned image shift for shift_mode 1/3/4), no resize,
+    behaviour-as-channels for behavior_mode 1, then the core-input path of model_forward."""
+    shifts = image_shifter(cfg, sd, mouse_id, behaviors, pupil_centers) if cfg.shift_mode in (1, 3, 4) else None
+    x = crop_nearest(raw, cfg.center_crop, shifts)
+    if cfg.behavior_mode == 1:
+        x = torch.cat([x, behaviors[:, :, None, None].expand(-1, -1, x.shape[2], x.shape[3]).to(x.dtype)], dim=1)
+    return model_forward(cfg, sd, x, mouse_id, behaviors, pupil_centers, **kw)
+
+
 # --------------------------------------------------------------------------------------
 # Model.forward / train step (model.py:151-177, train.py:42-111)
 # --------------------------------------------------------------------------------------
@@ -484,12 +530,19 @@ def shifter_param_keys(sd: SD, mouse_id: str) -> t.List[str]:
     return [k for k in sd if k.startswith(p) and not k.endswith("reg_scale")]
 
 
+def image_shifter_param_keys(sd: SD, mouse_id: str) -> t.List[str]:
+    p = f"image_cropper.image_shifter.{mouse_id}.mlp."
+    return [k for k in sd if k.startswith(p)]
+
+
 def regularizer(cfg: Config, sd: SD, mouse_id: str) -> Tensor:
     """Model.regularizer model.py:141-149: core L1 + readout feature L1 (+ shifter L1 * scale)."""
     reg = core_regularizer(cfg, sd, core_param_keys(sd))
     reg = reg + cfg.readout_reg_scale * sd[f"readouts.{mouse_id}.features"].abs().sum()
     if cfg.shift_mode in (2, 3, 4) and cfg.shifter_reg_scale != 0.0:
         reg = reg + cfg.shifter_reg_scale * sum(sd[k].abs().sum() for k in shifter_param_keys(sd, mouse_id))
+    if cfg.shift_mode in (1, 3, 4) and cfg.cropper_reg_scale != 0.0:  # ImageShifter.regularizer image_cropper.py:38-39
+        reg = reg + cfg.cropper_reg_scale * sum(sd[k].abs().sum() for k in image_shifter_param_keys(sd, mouse_id))
     return reg
 
 
@@ -506,7 +559,8 @@ def total_loss(
     """One micro-batch of train_step train.py:56-72 -> (loss, reg_loss, y_pred)."""
     b = batch["image"].shape[0]
     full = b if batch_size is None else batch_size
-    y = model_forward(cfg, sd, batch["image"], mouse_id, batch["behavior"], batch["pupil_center"], eps=eps, masks=masks)
+    fwd = model_forward_raw if cfg.raw_input_shape is not None else model_forward  # raw: batch["image"] is pre-cropper
+    y = fwd(cfg, sd, batch["image"], mouse_id, batch["behavior"], batch["pupil_center"], eps=eps, masks=masks)
     loss = poisson_loss(batch["response"], y, ds_size, full)
     reg = (b / full) * regularizer(cfg, sd, mouse_id)
     return loss, reg, y

@@ -140,13 +140,24 @@ def make_state_dict(cfg: Config, seed: int = 1234) -> t.Dict[str, torch.Tensor]:
             put(s + "4.weight", _uniform(seed, s + "4w", (2, 5), -0.45, 0.45) * 0.3)
             put(s + "4.bias", _uniform(seed, s + "4b", (2,), -0.45, 0.45) * 0.3)
             put(f"core_shifter.{mid}.reg_scale", np.float32(cfg.shifter_reg_scale))
+        if cfg.shift_mode in (1, 3, 4):  # ImageShifter (image_cropper.py:10-47), num_layers=3, hidden 10
+            s = f"image_cropper.image_shifter.{mid}."
+            nin = 5 if cfg.shift_mode == 4 else 2
+            put(s + "mlp.0.weight", _uniform(seed, s + "0w", (10, nin), -0.7, 0.7))
+            put(s + "mlp.0.bias", _uniform(seed, s + "0b", (10,), -0.7, 0.7))
+            put(s + "mlp.2.weight", _uniform(seed, s + "2w", (10, 10), -0.45, 0.45))
+            put(s + "mlp.2.bias", _uniform(seed, s + "2b", (10,), -0.45, 0.45))
+            put(s + "mlp.4.weight", _uniform(seed, s + "4w", (2, 10), -0.45, 0.45))
+            put(s + "mlp.4.bias", _uniform(seed, s + "4b", (2,), -0.45, 0.45))
+            put(s + "max_shift", np.float32(1.0 - cfg.center_crop))
+            put(s + "reg_scale", np.float32(cfg.cropper_reg_scale))
     return {k: torch.from_numpy(np.array(v, copy=True, order="C")) for k, v in sd.items()}
 
 
 def make_batch(cfg: Config, mouse_id: str, batch: int, seed: int = 1234, full_res: bool = False) -> t.Dict[str, torch.Tensor]:
     """Synthetic Sensorium-shaped batch: image ~N(0,1) at the CORE input shape
     (or (C,144,256) pre-cropper when full_res), behavior ~|N(0,1)|, pupil ~N(0,1), response ~Exp(1)."""
-    c, h, w = cfg.input_shape
+    c, h, w = cfg.raw_input_shape or cfg.input_shape
     if full_res:
         h, w = 144, 256
     n = cfg.num_neurons[mouse_id]

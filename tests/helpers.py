@@ -42,7 +42,8 @@ def build_native_model(cfg, sd, device, dropout=None):
     from v1t_amd.synthetic import default_args, make_ds
 
     args = default_args(
-        input_shape=cfg.input_shape, resize_image=0, num_blocks=cfg.num_blocks, emb_dim=cfg.emb_dim, mlp_dim=cfg.mlp_dim,
+        input_shape=cfg.raw_input_shape or cfg.input_shape, center_crop=cfg.center_crop, cropper_reg_scale=cfg.cropper_reg_scale,
+        shifter_reg_scale=cfg.shifter_reg_scale, readout_reg_scale=cfg.readout_reg_scale, core_reg_scale=cfg.core_reg_scale, resize_image=0, num_blocks=cfg.num_blocks, emb_dim=cfg.emb_dim, mlp_dim=cfg.mlp_dim,
         num_heads=cfg.num_heads, behavior_mode=cfg.behavior_mode, use_lsa=cfg.use_lsa, disable_bias=cfg.disable_bias,
         patch_mode=cfg.patch_mode, patch_stride=cfg.patch_stride, shift_mode=cfg.shift_mode,
         disable_grid_predictor=cfg.disable_grid_predictor, grid_predictor_dim=cfg.grid_predictor_dim,

@@ -111,9 +111,14 @@ def test_unsupported_variants_fail_loudly(dev):
 
     args = default_args(input_shape=(1, 36, 64), resize_image=0, num_blocks=1, emb_dim=64, mlp_dim=128)
     args.output_shapes = {"A": (8,)}
-    args.shift_mode = 1  # learned image shifter (gradient w.r.t. the core input): no native path -> must raise, not fall back
+    args.patch_mode = 4  # not a tokeniser of the reference: must raise, not fall back
     with pytest.raises(NotImplementedError):
         v1t_amd.Model(args, make_ds({"A": 8}))
+    args.patch_mode = 0
+    model = v1t_amd.Model(args, make_ds({"A": 8})).to(dev)
+    x = torch.zeros(1, 1, 36, 64, device=dev, requires_grad=True)  # gradient w.r.t. the core input has no kernel
+    with pytest.raises(NotImplementedError):
+        model.core(x, mouse_id="A", behaviors=torch.zeros(1, 3, device=dev), pupil_centers=torch.zeros(1, 2, device=dev))
 
 
 def test_drop_path_vs_reference_golden(dev):
@@ -150,6 +155,95 @@ def test_drop_path_vs_reference_golden(dev):
             assert rel_to_max(sample(p.grad), ref) < G_TOL, k
         n += 1
     assert n >= 20
+
+
+@pytest.mark.parametrize("sm", [1, 3, 4])
+def test_image_shifter_vs_reference_golden(dev, sm):
+    """G8: center crop 0.8 + learned image shifter (shift_mode 1/3/4; image_cropper.py:10-47,120-133) from the RAW image:
+    the crop is a gather (bit-exact), predictions within the y tolerance, and for mode 4 every gradient (the image
+    shifter's is its L1 term alone — nearest sampling passes none) against the real reference's."""
+    import os
+
+    from v1t_amd.losses import elu1_poisson_loss
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_image_shift.npz"))
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 96, "B": 50}, shift_mode=sm,
+                   center_crop=0.8, raw_input_shape=(1, 36, 64), input_shape=(1, 28, 51), shifter_reg_scale=0.01, cropper_reg_scale=0.02)
+    mouse = "B" if sm == 3 else "A"
+    sd = W.make_state_dict(cfg, 91)
+    batch = W.make_batch(cfg, mouse, 3, 91)
+    model, _ = build_native_model(cfg, sd, dev)
+    assert model.image_cropper.output_shape == (1, 28, 51)
+    model.train(False)
+    bd = {k: v.to(dev) for k, v in batch.items()}
+    u, img, grid = model(inputs=bd["image"], mouse_id=mouse, behaviors=bd["behavior"], pupil_centers=bd["pupil_center"], activate=False)
+    assert np.array_equal(img.detach().cpu().numpy(), g[f"g8/sm{sm}/crop"])
+    assert_close("g8.shift", (grid[:, 0, 0, :] - model.image_cropper.grid[:, 0, 0, :]).detach().cpu().numpy(), g[f"g8/sm{sm}/shift"], 1e-5, 1e-6)
+    loss, y = elu1_poisson_loss(u, bd["response"], 4500.0, 3)
+    reg = model.regularizer(mouse)
+    (loss + reg).backward()
+    assert_close("g8.y", y.detach().cpu().numpy(), g[f"g8/sm{sm}/y"], Y_RTOL, Y_ATOL)
+    assert abs(float(reg.detach()) - float(g[f"g8/sm{sm}/reg"])) <= 1e-4 * abs(float(g[f"g8/sm{sm}/reg"]))
+    names = {p_["name"] for p_ in model.get_parameters(core_lr=1e-3)}
+    assert names == {"core", "readouts", "image_cropper"} | ({"core_shifter"} if sm != 1 else set())
+    if sm == 4:
+        n = 0
+        for k, p in model.named_parameters():
+            gk = f"g8/sm4/grad/{k}"
+            if gk not in g.files:
+                continue
+            assert p.grad is not None, k
+            ref = g[gk]
+            if float(np.abs(ref).max()) > 0:
+                assert rel_to_max(sample(p.grad), ref) < G_TOL, k
+            n += 1
+        assert n >= 20 and any("image_shifter" in k for k, _ in model.named_parameters())
+
+
+def test_center_crop_vs_reference_golden(dev):
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_image_shift.npz"))
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 96}, center_crop=0.7,
+                   raw_input_shape=(1, 36, 64), input_shape=(1, 25, 44))
+    sd = W.make_state_dict(cfg, 91)
+    batch = W.make_batch(cfg, "A", 3, 91)
+    model, _ = build_native_model(cfg, sd, dev)
+    model.train(False)
+    bd = {k: v.to(dev) for k, v in batch.items()}
+    with torch.no_grad():
+        y, img, _ = model(inputs=bd["image"], mouse_id="A", behaviors=bd["behavior"], pupil_centers=bd["pupil_center"])
+    assert np.array_equal(img.cpu().numpy(), g["g8/crop07/crop"])
+    assert_close("crop07.y", y.cpu().numpy(), g["g8/crop07/y"], Y_RTOL, Y_ATOL)
+
+
+def test_image_shifter_fused_step_matches_autograd_l1(dev):
+    """The fused trainer's per-run L1 coefficients (Model.mouse_l1_ranges) cover the core / image shifter terms that
+    Model.regularizer adds (core_shifter.py:21-22, image_cropper.py:38-39): one fused step == autograd + AdamW oracle."""
+    from v1t_amd.dist import MouseSharding
+    from v1t_amd.synthetic import make_ds
+    from v1t_amd.trainer import Trainer
+
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 96}, shift_mode=4, center_crop=0.8,
+                   raw_input_shape=(1, 36, 64), input_shape=(1, 28, 51), shifter_reg_scale=0.01, cropper_reg_scale=0.02, p_dropout=0.0, t_dropout=0.0)
+    sd = W.make_state_dict(cfg, 12)
+    batch = W.make_batch(cfg, "A", 4, 12)
+    model, args = build_native_model(cfg, sd, dev)
+    args.batch_size = 4
+    runs = model.mouse_l1_ranges("A")
+    assert [c for _, _, c in runs] == pytest.approx([cfg.readout_reg_scale, 0.0, 0.01, 0.02]) and sum(n for _, n, _ in runs) == model.mouse_arena("A").total
+    tr = Trainer(args, model, make_ds(cfg.num_neurons), MouseSharding(["A"], 0, 1))
+    ref = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    tr.train_step({"A": {k: v.to(dev) for k, v in batch.items()}})
+    new = model.state_dict()
+    lr = args.lr
+    for k in O.image_shifter_param_keys(sd, "A"):
+        # nearest sampling passes no gradient: g = reg_scale * sign(w); first AdamW step moves by lr * g / (|g| + eps)
+        w0 = ref[k].cpu()
+        expect = w0 - lr * torch.sign(w0)
+        assert_close(k, new[k].cpu().numpy(), expect.numpy(), 0, 2e-6)
+    for k in O.shifter_param_keys(sd, "A"):
+        assert float((new[k].cpu() - ref[k].cpu()).abs().max()) > 0
 
 
 def test_behavior_as_channels_vs_oracle(dev):

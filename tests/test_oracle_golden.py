@@ -123,6 +123,45 @@ def test_drop_path_vs_golden():
         assert_close(f"g7.grad.{k}", sample(sdd[k].grad), g[f"g7/grad/{k}"], 1e-3, 1e-5 + 1e-3 * float(np.abs(g[f"g7/grad/{k}"]).max()))
 
 
+def _g8_cfg(sm):
+    return O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 96, "B": 50}, shift_mode=sm,
+                    center_crop=0.8, raw_input_shape=(1, 36, 64), input_shape=(1, 28, 51), shifter_reg_scale=0.01, cropper_reg_scale=0.02)
+
+
+@pytest.mark.parametrize("sm", [1, 3, 4])
+def test_image_shifter_vs_golden(sm):
+    """G8: center crop 0.8 + the learned image shifter (shift_mode 1/3/4) from the raw image, reference outputs."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_image_shift.npz"))
+    cfg = _g8_cfg(sm)
+    mouse = "B" if sm == 3 else "A"
+    sd = W.make_state_dict(cfg, 91)
+    batch = W.make_batch(cfg, mouse, 3, 91)
+    sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    shift = O.image_shifter(cfg, sd, mouse, batch["behavior"], batch["pupil_center"])
+    assert_close("g8.shift", shift.numpy(), g[f"g8/sm{sm}/shift"], 1e-5, 1e-7)
+    assert np.array_equal(O.crop_nearest(batch["image"], 0.8, shift).numpy(), g[f"g8/sm{sm}/crop"])
+    loss, reg, y = O.total_loss(cfg, sdd, batch, mouse, 4500.0)
+    (loss + reg).backward()
+    assert_close("g8.y", y.detach().numpy(), g[f"g8/sm{sm}/y"], 2e-4, 2e-5)
+    assert abs(float(reg) - float(g[f"g8/sm{sm}/reg"])) <= 1e-5 * abs(float(g[f"g8/sm{sm}/reg"]))
+    if sm == 4:
+        for k in O.image_shifter_param_keys(sd, mouse) + ["core.patch_embedding.pos_embedding"]:
+            ref = g[f"g8/sm4/grad/{k}"]
+            assert_close(f"g8.grad.{k}", sample(sdd[k].grad), ref, 1e-3, 1e-5 + 1e-3 * float(np.abs(ref).max()))
+
+
+def test_center_crop_vs_golden():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_image_shift.npz"))
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 96}, center_crop=0.7,
+                   raw_input_shape=(1, 36, 64), input_shape=(1, 25, 44))
+    sd = W.make_state_dict(cfg, 91)
+    batch = W.make_batch(cfg, "A", 3, 91)
+    assert np.array_equal(O.crop_nearest(batch["image"], 0.7, None).numpy(), g["g8/crop07/crop"])
+    with torch.no_grad():
+        y = O.model_forward_raw(cfg, sd, batch["image"], "A", batch["behavior"], batch["pupil_center"])
+    assert_close("crop07.y", y.numpy(), g["g8/crop07/y"], 2e-4, 2e-5)
+
+
 def test_resize_vs_golden(golden):
     x = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 1, 144, 256)).astype(np.float32))
     assert_close("resize", sample(O.resize_bilinear(x, (36, 64))), golden["resize/out_sample"], 1e-5, 1e-6)

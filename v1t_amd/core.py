@@ -345,7 +345,7 @@ class ViTCore(Core):
         keep_workspace: keep every block's activations (qkv, lse2, ...) even under no_grad (attention rollout)."""
         L.require_cuda(inputs, "ViTCore.forward")
         if inputs.requires_grad:
-            raise NotImplementedError("gradient w.r.t. the core input (image shifter, shift_mode 1/3/4) has no gfx950 kernel yet")
+            raise NotImplementedError("gradient w.r.t. the core input has no gfx950 kernel (no reference configuration needs it: the cropper samples nearest)")
         self.prepare()
         inputs = inputs.to(torch.float32).contiguous()
         if tuple(inputs.shape[1:]) != tuple(self.input_shape):

@@ -872,6 +872,11 @@ int v1t_gaussian2d_backward(const float* z, long long zsb, long long zsc, int B,
 }
 long long v1t_gaussian2d_backward_ws_bytes(int B, int H, int W, int N) { return (long long)readout_bwd_ws_bytes(B, H, W, N); }
 
+int v1t_crop_nearest(const float* in, int B, int C, int IH, int IW, const float* grid, const float* shifts, float* out, int OH, int OW,
+                     void* stream) {
+    if (!in || !grid || !out || B < 0 || C <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return V1T_ERR_ARG;
+    return launch_crop_nearest(in, B, C, IH, IW, grid, shifts, out, OH, OW, (hipStream_t)stream);
+}
 int v1t_resize_bilinear(const float* in, int planes, int IH, int IW, float* out, int OH, int OW, void* stream) {
     if (!in || !out || planes < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return V1T_ERR_ARG;
     return launch_resize_bilinear(in, out, planes, IH, IW, OH, OW, (hipStream_t)stream);

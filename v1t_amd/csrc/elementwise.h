@@ -143,4 +143,6 @@ int launch_elu1_poisson(const LossArgs& a, hipStream_t s);
 
 int launch_dropout_mask(uint8_t* out, long long rows, long long cols, DropCfg d, hipStream_t s);
 int launch_attn_dropout_mask(uint8_t* out, long long rows, long long T, AttnDrop d, hipStream_t s);
+int launch_crop_nearest(const float* in, int B, int C, int IH, int IW, const float* grid, const float* shifts, float* out, int OH, int OW,
+                        hipStream_t s);
 int launch_resize_bilinear(const float* in, float* out, int planes, int IH, int IW, int OH, int OW, hipStream_t s);

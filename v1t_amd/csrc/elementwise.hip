@@ -719,6 +719,29 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* in, f
     out[i] = top * (1.f - fy) + bot * fy;
 }
 
+// ImageCropper's crop (image_cropper.py:101-110,126-133): F.grid_sample(mode="nearest", align_corners=True, zeros
+// padding) over grid[oy][ox] = (x, y) in [-crop, crop] plus an optional per-image (x, y) shift. Source pixel =
+// rint(((g + 1) / 2) * (size - 1)) in fp32 (round half to even, as ATen's nearbyint), outside the image -> 0.
+// One thread per output pixel; reads are a strided gather of the (L2-resident) image, writes coalesced.
+__global__ __launch_bounds__(256) void crop_nearest_kernel(const float* in, int B, int C, int IH, int IW, const float* grid, const float* shifts,
+                                                           float* out, int OH, int OW) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * C * OH * OW) return;
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+    const long long pl = i / ((long long)OW * OH);
+    const int b = (int)(pl / C);
+    float gx = grid[((size_t)oy * OW + ox) * 2], gy = grid[((size_t)oy * OW + ox) * 2 + 1];
+    if (shifts) {
+        gx = __fadd_rn(gx, shifts[b * 2]);
+        gy = __fadd_rn(gy, shifts[b * 2 + 1]);
+    }
+    const float fx = rintf(__fmul_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f), (float)(IW - 1)));
+    const float fy = rintf(__fmul_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f), (float)(IH - 1)));
+    float v = 0.f;
+    if (fx >= 0.f && fx <= (float)(IW - 1) && fy >= 0.f && fy <= (float)(IH - 1)) v = in[pl * IH * IW + (size_t)fy * IW + (size_t)fx];
+    out[i] = v;
+}
+
 inline int ok() { return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH; }
 inline int nblocks(long long n, int cap = 2048) { return (int)std::min<long long>((n + 255) / 256, cap); }
 
@@ -855,6 +878,13 @@ int launch_resize_bilinear(const float* in, float* out, int planes, int IH, int 
     const long long n = (long long)planes * OH * OW;
     if (n <= 0) return V1T_OK;
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, planes, IH, IW, OH, OW);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_crop_nearest(const float* in, int B, int C, int IH, int IW, const float* grid, const float* shifts, float* out, int OH, int OW,
+                        hipStream_t s) {
+    const long long n = (long long)B * C * OH * OW;
+    if (n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(crop_nearest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, B, C, IH, IW, grid, shifts, out, OH, OW);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 int launch_patch_unfold_f32(const PatchArgs& a, int spt, float* u, int ldu, hipStream_t s) {

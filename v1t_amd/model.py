@@ -12,7 +12,6 @@ import typing as t
 
 import torch
 from torch import nn
-from torch.nn import functional as F
 
 from . import lib as L
 from .core import get_core
@@ -110,19 +109,55 @@ class CoreShifters(nn.ModuleDict):
         return self[mouse_id](pupil_centers)
 
 
+class ImageShifter(nn.Module):
+    """reference image_cropper.py:10-47: (pupil | behaviour + pupil) -> hidden -> ... -> 2 tanh MLP whose output, scaled
+    by max_shift, moves the crop window. O(B) work on 10-wide layers: torch ops."""
+
+    def __init__(self, args, max_shift: float, in_features: int, hidden_features: int, num_layers: int, name: str = "ImageShifter"):
+        super().__init__()
+        self.name = name
+        self.register_buffer("max_shift", torch.tensor(max_shift))
+        self.register_buffer("reg_scale", torch.tensor(float(args.cropper_reg_scale)))
+        out_features = in_features
+        layers = []
+        for _ in range(num_layers - 1):
+            layers.extend([nn.Linear(out_features, hidden_features), nn.Tanh()])
+            out_features = hidden_features
+        layers.extend([nn.Linear(out_features, 2), nn.Tanh()])
+        self.mlp = nn.Sequential(*layers)
+
+    def regularizer(self):
+        return self.reg_scale * sum(p.abs().sum() for p in self.parameters())
+
+    def forward(self, behaviors: torch.Tensor, pupil_centers: torch.Tensor):
+        return self.mlp(torch.concat((behaviors, pupil_centers), dim=-1)) * self.max_shift
+
+
+def _crop_nearest(inputs: torch.Tensor, grid: torch.Tensor, shifts: t.Optional[torch.Tensor]) -> torch.Tensor:
+    """Nearest-neighbour crop (F.grid_sample(mode="nearest", align_corners=True), image_cropper.py:126-133) as one
+    gather kernel. Nearest sampling has no gradient w.r.t. the grid (the reference's shifter receives exact zeros
+    through it), so the result is a constant of the graph: the ImageShifter learns from its L1 term only."""
+    L.require_cuda(inputs, "ImageCropper")
+    src = inputs.detach().to(torch.float32).contiguous()
+    b, c, ih, iw = src.shape
+    oh, ow = grid.shape[1], grid.shape[2]
+    out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=src.device)
+    sh = None if shifts is None else shifts.detach().to(torch.float32).contiguous()
+    L.check(L.load().v1t_crop_nearest(src.data_ptr(), b, c, ih, iw, grid.data_ptr(), None if sh is None else sh.data_ptr(), out.data_ptr(), oh, ow,
+                                      L.stream()), "crop_nearest")
+    return out
+
+
 class ImageCropper(nn.Module):
-    """reference image_cropper.py:50-140 for shift_mode in (0, 2) (no learned image shifter): identity
-    crop (nearest grid_sample over the identity grid) at center_crop == 1, then bilinear 144x256 -> 36x64
-    (torchvision Resize(antialias=False) == F.interpolate(bilinear, align_corners=False)), optional
-    behaviour-as-channels (behavior_mode 1)."""
+    """reference image_cropper.py:50-140: center crop (nearest grid_sample over a [-crop, crop] grid, moved per image
+    by the learned ImageShifter for shift_mode 1/3/4), bilinear 144x256 -> 36x64 (torchvision Resize(antialias=False)
+    == F.interpolate(bilinear, align_corners=False)), optional behaviour-as-channels (behavior_mode 1)."""
 
     def __init__(self, args, ds: t.Dict[str, t.Any]):
         super().__init__()
         self.shift_mode = args.shift_mode
         self.input_shape = args.input_shape
         self.behavior_mode = args.behavior_mode
-        if self.shift_mode in (1, 3, 4):
-            raise NotImplementedError("shift_mode 1/3/4 (learned image shifter) is outside the native hot path for now")
         c, in_h, in_w = args.input_shape
         out_h, out_w = in_h, in_w
         if self.behavior_mode == 1:
@@ -137,6 +172,14 @@ class ImageCropper(nn.Module):
         mesh_y, mesh_x = torch.meshgrid(h_pixels, w_pixels, indexing="ij")
         self.register_buffer("grid", torch.stack((mesh_x, mesh_y), dim=2).unsqueeze(0))
         self.image_shifter = None
+        if self.shift_mode in (1, 3, 4):
+            max_shift = 1 - self.crop_scale
+            in_features = 5 if self.shift_mode == 4 else 2  # image_cropper.py:76-79
+            self.image_shifter = nn.ModuleDict({
+                mouse_id: ImageShifter(args, max_shift=max_shift, in_features=in_features, hidden_features=10, num_layers=3,
+                                       name=f"Mouse{mouse_id}ImageShifter")
+                for mouse_id in ds.keys()
+            })
         self.resize = None
         if args.resize_image == 1 and args.ds_name != "franke2022":
             out_h, out_w = 36, 64
@@ -144,22 +187,25 @@ class ImageCropper(nn.Module):
         self.output_shape = (c, out_h, out_w)
 
     def regularizer(self, mouse_id: str):
-        return 0
+        return 0 if self.image_shifter is None else self.image_shifter[mouse_id].regularizer()
 
     def forward(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor):
         grid = self.grid.expand(inputs.size(0), -1, -1, -1)
         outputs = inputs
-        if self.crop_scale < 1:
-            outputs = F.grid_sample(inputs, grid=grid, mode="nearest", align_corners=True)
+        shifts = None
+        if self.image_shifter is not None:
+            b = behaviors if self.shift_mode == 4 else behaviors[:, :0]
+            shifts = self.image_shifter[mouse_id](b, pupil_centers)
+            grid = grid + shifts[:, None, None, :]
+        if shifts is not None or self.crop_scale < 1:  # at crop 1 without shifts the sampled grid is the identity
+            outputs = _crop_nearest(inputs, self.grid, shifts)
         if self.resize is not None:
-            if outputs.is_cuda and outputs.dtype == torch.float32 and not outputs.requires_grad:
-                src = outputs.contiguous()
-                b, c, ih, iw = src.shape
-                outputs = torch.empty((b, c, *self.resize), dtype=torch.float32, device=src.device)
-                L.check(L.load().v1t_resize_bilinear(src.data_ptr(), b * c, ih, iw, outputs.data_ptr(), self.resize[0], self.resize[1], L.stream()),
-                        "resize_bilinear")
-            else:  # gradient w.r.t. the image (learned image shifter) is not on the native path
-                outputs = F.interpolate(outputs, size=self.resize, mode="bilinear", align_corners=False, antialias=False)
+            src = outputs.to(torch.float32).contiguous()
+            L.require_cuda(src, "ImageCropper")
+            b, c, ih, iw = src.shape
+            outputs = torch.empty((b, c, *self.resize), dtype=torch.float32, device=src.device)
+            L.check(L.load().v1t_resize_bilinear(src.data_ptr(), b * c, ih, iw, outputs.data_ptr(), self.resize[0], self.resize[1], L.stream()),
+                    "resize_bilinear")
         if self.behavior_mode == 1:
             h, w = outputs.size(2), outputs.size(3)
             outputs = torch.concat((outputs, behaviors[:, :, None, None].expand(-1, -1, h, w)), dim=1)
@@ -198,6 +244,8 @@ class Model(nn.Module):
         params.append({"params": self.readouts.parameters(), "name": "readouts"})
         if self.core_shifter is not None:
             params.append({"params": self.core_shifter.parameters(), "name": "core_shifter"})
+        if self.image_cropper.image_shifter is not None:
+            params.append({"params": self.image_cropper.parameters(), "name": "image_cropper"})
         return params
 
     def regularizer(self, mouse_id: str):
@@ -224,7 +272,7 @@ class Model(nn.Module):
 
     # ------------------------------------------------------------------ flat per-mouse arenas (fused optimizer / DDP)
     def mouse_arena(self, mouse_id: str) -> FlatArena:
-        """All per-mouse parameters (readout + core shifter) in one flat arena; `features` first, in
+        """All per-mouse parameters (readout + core shifter + image shifter) in one flat arena; `features` first, in
         neuron-major storage, so the L1 term and the feature kernel see one contiguous [N][FS] block."""
         a = self._mouse_arenas.get(mouse_id)
         if a is None:
@@ -232,6 +280,8 @@ class Model(nn.Module):
             params = [ro.features] + [p for p in ro.parameters() if p is not ro.features]
             if self.core_shifter is not None:
                 params += list(self.core_shifter[mouse_id].parameters())
+            if self.image_cropper.image_shifter is not None:
+                params += list(self.image_cropper.image_shifter[mouse_id].parameters())
             special = {}
             if isinstance(ro, Gaussian2DReadout):
                 special[id(ro.features)] = (ro.feature_storage_numel(), ro._feature_view)
@@ -239,3 +289,25 @@ class Model(nn.Module):
             self._mouse_arenas[mouse_id] = a
         a.ensure()
         return a
+
+    def mouse_l1_ranges(self, mouse_id: str) -> t.List[t.Tuple[int, int, float]]:
+        """(start, n, coefficient) runs over the mouse arena for the fused L1 + AdamW step: the terms Model.regularizer
+        adds for this mouse (readout features gaussian2d.py:233-234, core shifter core_shifter.py:21-22, image shifter
+        image_cropper.py:38-39); everything else coefficient 0."""
+        a = self.mouse_arena(mouse_id)
+        ro = self.readouts[mouse_id]
+        coeff = {id(ro.features): float(ro.reg_scale)}
+        if self.core_shifter is not None:
+            cs = self.core_shifter[mouse_id]
+            coeff.update({id(p): float(cs.reg_scale) for p in cs.parameters()})
+        if self.image_cropper.image_shifter is not None:
+            sh = self.image_cropper.image_shifter[mouse_id]
+            coeff.update({id(p): float(sh.reg_scale) for p in sh.parameters()})
+        runs: t.List[t.List[float]] = []
+        for s in a.slots:
+            c = coeff.get(id(s.tensor), 0.0)
+            if runs and runs[-1][2] == c and runs[-1][0] + runs[-1][1] == s.offset:
+                runs[-1][1] += s.numel
+            else:
+                runs.append([s.offset, s.numel, c])
+        return [(int(o), int(n), float(c)) for o, n, c in runs]

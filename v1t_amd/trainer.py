@@ -82,9 +82,7 @@ class Trainer:
             core.mark_updated()
         for mouse_id in self.sharding.local_mice():
             a = model.mouse_arena(mouse_id)
-            ro = model.readouts[mouse_id]
-            nfeat = ro.feature_storage_numel()
-            self.opt.step_arena(a, self.lr, [(0, nfeat, float(ro.reg_scale)), (nfeat, a.total - nfeat, 0.0)])
+            self.opt.step_arena(a, self.lr, model.mouse_l1_ranges(mouse_id))
         return {"loss": torch.stack(losses).sum() if losses else torch.zeros((), device=core._arena.data.device)}
 
     @torch.no_grad()
