@@ -162,6 +162,26 @@ int v1t_resize_bilinear(const float* in, int planes, int IH, int IW, float* out,
 int v1t_elu1_poisson(const float* u, const float* y, long long n, float loss_scale, float gscale,
                      float* yhat, float* du, float* loss, void* stream);
 
+/* ------------------------------------------------------- validation / evaluation metrics (streaming, fp64 moments) */
+/* compute_metrics (train.py:29-39) without stacking predictions on the host (train.py:24-25,186): fold one micro-batch
+ * pred/target[B][N] into acc[5][N] += (sum p, sum t, sum p^2, sum t^2, sum p*t) per neuron and
+ * scal[0] += msse = sum (t-p)^2 (losses.py:25-29), scal[1] += poisson_loss = sum (p - t*log(p+eps)) (losses.py:32-40).
+ * acc / scal are caller-owned, zeroed before the first call. */
+int v1t_metrics_accumulate(const float* pred, const float* target, int B, int N, float eps, double* acc, double* scal,
+                           void* stream);
+/* losses.correlation(y_pred, y_true, dim=0) (losses.py:43-58, eps 1e-8) from the moments of `count` trials:
+ * corr[N] (may be NULL) and *mean_out += mean over neurons (may be NULL). */
+int v1t_metrics_correlation(const double* acc, long long count, int N, float eps, float* corr, double* mean_out,
+                            void* stream);
+/* Metrics.split_responses (metrics.py:41-58) as streaming sums: group[b] in [0, G) is the image index of trial b;
+ * gacc[3][G][N] += (sum t, sum t^2, sum p) per (image, neuron), sqerr[N] += sum (t-p)^2. */
+int v1t_metrics_group_accumulate(const float* pred, const float* target, const int* group, int B, int N, int G,
+                                 double* gacc, double* sqerr, void* stream);
+/* Metrics.correlation_to_average (metrics.py:77-93) and Metrics._fev (metrics.py:95-127) per neuron from those sums
+ * and gcount[G] trials per image; any of the three outputs may be NULL. */
+int v1t_metrics_group_finalize(const double* gacc, const int* gcount, const double* sqerr, int G, int N, float eps,
+                               float* corr_avg, float* fev, float* feve, void* stream);
+
 /* ------------------------------------------------------------------ optimiser-side HBM kernels */
 /* torch.optim.AdamW step (train.py:216-223) over a flat arena, with the L1 regulariser's gradient
  * l1 * sign(p) folded in (vit.py:419-421, gaussian2d.py:99-100) and optional fused zero_grad. */

@@ -491,6 +491,40 @@ def gen_image_shift(out: dict, log=print):
     log("  g8/crop07: ok")
 
 
+def gen_metrics(out: dict, log=print):
+    """G9: validation / evaluation metrics (train.py:29-39, metrics.py:11-142) of the real reference on a synthetic
+    test-tier recording (oracle/metrics_oracle.make_metric_data)."""
+    import_reference()
+    from oracle import metrics_oracle as MO
+    from v1t import losses
+    from v1t.metrics import Metrics
+
+    d = MO.make_metric_data()
+    yt, yp = torch.from_numpy(d["targets"]), torch.from_numpy(d["predictions"])
+    ref = {"metrics/msse": losses.msse(y_true=yt, y_pred=yp), "metrics/poisson_loss": losses.poisson_loss(y_true=yt, y_pred=yp),
+           "metrics/single_trial_correlation": torch.mean(losses.correlation(y1=yp, y2=yt, dim=0))}
+    mine = MO.compute_metrics(d["targets"], d["predictions"])
+    for k, v in ref.items():
+        check(f"g9.{k}", v, torch.tensor(mine[k]), 2e-5, 1e-7)
+        out[f"g9/{k}"] = np.float64(v.item())
+    ds = SimpleNamespace(dataset=SimpleNamespace(tier="test", hashed=False, neuron_ids=d["neuron_ids"].copy()))
+    m = Metrics(ds, {"targets": yt, "predictions": yp, "image_ids": torch.from_numpy(d["image_ids"]), "trial_ids": torch.from_numpy(d["trial_ids"])})
+    ot, op, oi = MO.order(d["targets"], d["predictions"], d["image_ids"], d["trial_ids"], d["neuron_ids"])
+    stc, cta = m.single_trial_correlation(per_neuron=True), m.correlation_to_average(per_neuron=True)
+    fev, fe = m._fev(*m.split_responses(), return_exp_var=True)
+    check("g9.stc", torch.from_numpy(stc), torch.from_numpy(MO.correlation(op, ot, axis=0)), 1e-5, 1e-6)
+    check("g9.cta", torch.from_numpy(cta), torch.from_numpy(MO.correlation_to_average(ot, op, oi)), 1e-5, 1e-6)
+    ofev, ofe = MO.fev_feve(ot, op, oi)
+    check("g9.fev", torch.from_numpy(fev), torch.from_numpy(ofev), 1e-5, 1e-6)
+    check("g9.feve", torch.from_numpy(fe), torch.from_numpy(ofe), 1e-5, 1e-6)
+    kept = m.feve(per_neuron=True)
+    assert 0.1 < len(kept) / len(fev) < 0.98, "FEV threshold should cut some neurons"
+    assert np.array_equal(kept, MO.feve(ot, op, oi)) or np.allclose(kept, MO.feve(ot, op, oi), rtol=1e-5, atol=1e-6)
+    out["g9/single_trial_correlation"], out["g9/correlation_to_average"] = stc, cta
+    out["g9/fev"], out["g9/feve"], out["g9/feve_kept"] = fev, fe, kept
+    log(f"  g9: ok (mean stc {stc.mean():.4f}, cta {cta.mean():.4f}, feve {kept.mean():.4f} over {len(kept)}/{len(fev)} neurons)")
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
@@ -500,6 +534,13 @@ def main():
         path = os.path.join(ROOT, "tests", "golden", fname)
         np.savez_compressed(path, **d)
         print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB, {len(d)} arrays")
+
+    d = {}
+    print("G9 validation / evaluation metrics")
+    gen_metrics(d)
+    save("g9_metrics.npz", d)
+    if "--only-g9" in sys.argv:
+        return
 
     d = {}
     print("G8 center crop + learned image shifter (shift_mode 1/3/4)")

@@ -185,3 +185,21 @@ def test_elu1_poisson_edge_vs_golden(golden):
     assert_close("yhat", yh.detach().numpy(), golden["elu_edge/yhat"], 1e-6, 1.2e-7)
     assert_close("loss", loss.item(), golden["elu_edge/loss"], 1e-5, 0)
     assert_close("du", u.grad.numpy(), golden["elu_edge/du"], 1e-6, 1e-12)
+
+
+def test_metrics_vs_golden():
+    """G9: msse / poisson_loss / correlations / FEVe of the real reference on the synthetic test-tier recording."""
+    from oracle import metrics_oracle as MO
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_metrics.npz"))
+    d = MO.make_metric_data()
+    cm = MO.compute_metrics(d["targets"], d["predictions"])
+    for k, v in cm.items():
+        assert abs(v - float(g[f"g9/{k}"])) <= 2e-5 * abs(float(g[f"g9/{k}"])), k
+    ot, op, oi = MO.order(d["targets"], d["predictions"], d["image_ids"], d["trial_ids"], d["neuron_ids"])
+    assert_close("stc", MO.correlation(op, ot, axis=0), g["g9/single_trial_correlation"], 1e-5, 1e-6)
+    assert_close("cta", MO.correlation_to_average(ot, op, oi), g["g9/correlation_to_average"], 1e-5, 1e-6)
+    fev, fe = MO.fev_feve(ot, op, oi)
+    assert_close("fev", fev, g["g9/fev"], 1e-5, 1e-6)
+    assert_close("feve", fe, g["g9/feve"], 1e-5, 1e-6)
+    assert_close("feve_kept", MO.feve(ot, op, oi), g["g9/feve_kept"], 1e-5, 1e-6)
