@@ -251,3 +251,46 @@ def test_resize_bilinear(ctx, shape, out):
     y = torch.empty(shape[0], shape[1], *out, device=dev)
     L.check(lib.v1t_resize_bilinear(xd.data_ptr(), shape[0] * shape[1], shape[2], shape[3], y.data_ptr(), out[0], out[1], L.stream()))
     assert float((y.cpu() - ref).abs().max()) < 1e-5  # fp32 tap weights: (dst + 0.5) * scale - 0.5 rounds differently at non-integer scales
+
+
+@pytest.mark.parametrize("B,N,gd,sample", [(16, 8000, 2, True), (5, 333, 3, True), (40, 1000, 2, True), (3, 64, 0, True), (4, 130, 2, False)])
+def test_readout_grid_backward_paths(ctx, B, N, gd, sample):
+    """Grid backward (gaussian2d.py:188-235, 265-268): the two-stage workspace path and the atomics path against torch
+    fp32 autograd of mu = tanh(W2 . ELU(W0 . src + b0) + b2), grid = clamp(sigma . eps + mu, -1, 1) + shift."""
+    lib, L, dev = ctx
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    src, W0, b0, W2, b2 = r(N, max(gd, 1)), r(30, max(gd, 1), sc=0.5), r(30, sc=0.3), r(2, 30, sc=0.3), r(2, sc=0.1)
+    mu_free, sigma, eps, shift, dgrid = r(N, 2, sc=0.6), r(N, 2, 2, sc=0.4), r(B, N, 2), r(B, 2, sc=0.1), r(B, N, 2)
+    leaves = [t_.clone().requires_grad_(True) for t_ in (W0, b0, W2, b2, mu_free, sigma, shift)]
+    lW0, lb0, lW2, lb2, lmu, lsig, lsh = leaves
+    mu = torch.tanh(torch.nn.functional.elu(src[:, :gd] @ lW0[:, :gd].T + lb0) @ lW2.T + lb2) if gd > 0 else lmu
+    grid = (torch.einsum("ncd,bnd->bnc", lsig, eps) + mu[None]) if sample else mu[None].expand(B, -1, -1)
+    grid = grid.clamp(-1, 1) + lsh[:, None, :]
+    grid.backward(dgrid)
+    d = lambda t_: t_.contiguous().to(dev)
+    srcd, W0d, b0d, W2d, b2d = d(src[:, :max(gd, 1)]), d(W0[:, :max(gd, 1)]), d(b0), d(W2), d(b2)
+    mud, sigd, epsd, dgd = d(mu_free), d(sigma), d(eps), d(dgrid)
+    for use_ws in (True, False):
+        o = {k: torch.zeros(*s, device=dev) for k, s in (("dW0", (30, max(gd, 1))), ("db0", (30,)), ("dW2", (2, 30)), ("db2", (2,)), ("dmu", (N, 2)),
+                                                           ("dsig", (N, 2, 2)), ("dsh", (B, 2)))}
+        nbytes = int(lib.v1t_readout_grid_backward_ws_bytes(B, N)) if use_ws else 0
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        for rep in range(2):  # outputs accumulate (+=): the second call doubles the predictor / shift gradients
+            L.check(lib.v1t_readout_grid_backward_ws(B, N, gd, srcd.data_ptr() if gd else None, *[(x.data_ptr() if gd else None) for x in (W0d, b0d, W2d, b2d)],
+                                                     None if gd else mud.data_ptr(), sigd.data_ptr(), epsd.data_ptr() if sample else None, dgd.data_ptr(),
+                                                     *[(o[k].data_ptr() if gd else None) for k in ("dW0", "db0", "dW2", "db2")],
+                                                     None if gd else o["dmu"].data_ptr(), o["dsig"].data_ptr() if sample else None, o["dsh"].data_ptr(),
+                                                     ws.data_ptr() if use_ws else None, nbytes, L.stream()))
+        torch.cuda.synchronize()
+        tag = f"ws={use_ws}"
+        assert rel_to_max(o["dsh"].cpu(), 2 * lsh.grad) < 2e-5, tag
+        if sample:
+            assert rel_to_max(o["dsig"].cpu(), lsig.grad) < 2e-5, tag
+        if gd:
+            assert rel_to_max(o["dW0"].cpu(), 2 * lW0.grad[:, :gd]) < 5e-5, tag
+            assert rel_to_max(o["db0"].cpu(), 2 * lb0.grad) < 5e-5, tag
+            assert rel_to_max(o["dW2"].cpu(), 2 * lW2.grad) < 5e-5, tag
+            assert rel_to_max(o["db2"].cpu(), 2 * lb2.grad) < 5e-5, tag
+        else:
+            assert rel_to_max(o["dmu"].cpu(), lmu.grad) < 2e-5, tag

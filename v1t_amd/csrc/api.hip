@@ -892,11 +892,19 @@ int v1t_readout_grid_forward(int B, int N, int gd, const float* src, const float
 int v1t_readout_grid_backward(int B, int N, int gd, const float* src, const float* W0, const float* b0, const float* W2, const float* b2,
                               const float* mu_free, const float* sigma, const float* eps, const float* dgrid, float* dW0, float* db0,
                               float* dW2, float* db2, float* dmu_free, float* dsigma, float* dshift, void* stream) {
+    return v1t_readout_grid_backward_ws(B, N, gd, src, W0, b0, W2, b2, mu_free, sigma, eps, dgrid, dW0, db0, dW2, db2, dmu_free, dsigma, dshift,
+                                        nullptr, 0, stream);
+}
+long long v1t_readout_grid_backward_ws_bytes(int B, int N) { return (long long)grid_bwd_ws_bytes(B, N); }
+int v1t_readout_grid_backward_ws(int B, int N, int gd, const float* src, const float* W0, const float* b0, const float* W2, const float* b2,
+                                 const float* mu_free, const float* sigma, const float* eps, const float* dgrid, float* dW0, float* db0,
+                                 float* dW2, float* db2, float* dmu_free, float* dsigma, float* dshift, void* ws, long long ws_bytes,
+                                 void* stream) {
     if (!sigma || !dgrid || (gd > 0 && (!src || !W0 || !b0 || !W2 || !b2 || !dW0 || !db0 || !dW2 || !db2)) || (gd == 0 && !mu_free)) return V1T_ERR_ARG;
     GridArgs a{};
     a.B = B; a.N = N; a.gd = gd; a.src = src; a.W0 = W0; a.b0 = b0; a.W2 = W2; a.b2 = b2; a.mu_free = mu_free; a.sigma = sigma;
     a.eps = eps; a.dgrid = dgrid; a.dW0 = dW0; a.db0 = db0; a.dW2 = dW2; a.db2 = db2; a.dmu_free = dmu_free; a.dsigma = dsigma; a.dshift = dshift;
-    return launch_grid_bwd(a, (hipStream_t)stream);
+    return launch_grid_bwd(a, ws, (size_t)(ws_bytes < 0 ? 0 : ws_bytes), (hipStream_t)stream);
 }
 int v1t_core_shifter_forward(int B, const float* pupil, const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                              const float* b4, float* shift, void* stream) {

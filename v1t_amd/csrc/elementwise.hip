@@ -385,7 +385,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
 // Workgroup = 64 rows of one image (two 8-row steps per wave); column partials stay in registers across rows and
 // are summed over the 8 row slots of a wave with lane swaps, over the waves through LDS, one atomic per column per WG.
 constexpr int LNB_ROWS = 64;
-constexpr int LNB_RPI = 4;  // drop_cast_kernel: rows per wave iteration
 DEVFN float rowslot_sum(float v) {  // sum over the 8 row slots (lane bits 3, 4, 5); valid in lanes 0..7
     v = dpp_add<0x128, 0xF>(v);  // row_ror:8 -> lane l += lane l ^ 8
     {
@@ -502,42 +501,51 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     }
 }
 
+// Entry of the backward: dy = bf16(dropout_bwd(g) * branch scale), dbias += column sums of dy. Same 8-rows-per-wave,
+// 16-B-per-lane layout as the LayerNorm kernels.
+template <int CPL>
 __global__ __launch_bounds__(256) void drop_cast_kernel(CastArgs a) {
     __shared__ float sred[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 7, slot = lane >> 3;
     const int r0 = blockIdx.x * LNB_ROWS;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int rr = wave * (LNB_ROWS / 4); rr < (wave + 1) * (LNB_ROWS / 4); rr += LNB_RPI) {
-        float g[LNB_RPI][4];
+    f32x4 acc[CPL];
 #pragma unroll
-        for (int u = 0; u < LNB_RPI; ++u) {
-            const int row = min(r0 + rr + u, a.rows - 1);
+    for (int k = 0; k < CPL; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 g[LNB_ROWS / 32][CPL];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = lane + 64 * i;
-                g[u][i] = (c < a.D) ? a.g[(size_t)row * a.DP + c] : 0.f;
-            }
-        }
+    for (int it = 0; it < LNB_ROWS / 32; ++it) {
+        const int row = min(r0 + 8 * (wave + 4 * it) + slot, a.rows - 1);
 #pragma unroll
-        for (int u = 0; u < LNB_RPI; ++u) {
-            const int row = r0 + rr + u;
-            if (row >= a.rows) break;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = lane + 64 * i;
-                if (c < a.DP) {
-                    float v = g[u][i];
-                    if (a.scale) v *= a.scale[row / a.T];
-                    if (a.drop.thresh && c < a.D) v = drop_keep(a.drop.key, row, c, a.drop.thresh) ? v * a.drop.inv_keep : 0.f;
-                    const bf16_t vb = (bf16_t)v;
-                    a.dy[(size_t)row * a.DP + c] = vb;
-                    acc[i] += (float)vb;
-                }
-            }
-        }
+        for (int k = 0; k < CPL; ++k) g[it][k] = *(const f32x4*)(a.g + (size_t)row * a.DP + 4 * (j + 8 * k));
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sred[wave][lane + 64 * i] = acc[i];
+    for (int it = 0; it < LNB_ROWS / 32; ++it) {
+        const int row = r0 + 8 * (wave + 4 * it) + slot;
+        if (row >= a.rows) continue;
+        const float sc = a.scale ? a.scale[row / a.T] : 1.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int c = 4 * (j + 8 * k);
+            bf16x4_t vb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = (c + e < a.D) ? g[it][k][e] * sc : 0.f;
+                if (a.drop.thresh && c + e < a.D) v = drop_keep(a.drop.key, row, c + e, a.drop.thresh) ? v * a.drop.inv_keep : 0.f;
+                vb[e] = (bf16_t)v;
+                acc[k][e] += (float)vb[e];
+            }
+            *(bf16x4_t*)(a.dy + (size_t)row * a.DP + c) = vb;
+        }
+    }
+    // EXEC is whole again here
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float r = rowslot_sum(acc[k][e]);
+            if (slot == 0) sred[wave][4 * (j + 8 * k) + e] = r;
+        }
     __syncthreads();
     const int c = threadIdx.x;
     if (a.dbias && c < a.D) atomicAdd(&a.dbias[c], sred[0][c] + sred[1][c] + sred[2][c] + sred[3][c]);
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(256) void bmlp_fwd_kernel(BmlpArgs a) {
 // BehaviorMLP backward for all blocks in one launch: grid (BMLP_SPLIT, NB). Every workgroup recomputes the
 // tiny intermediates (dpre2 (B,D), dpre1 (B,J)) in LDS and owns a 1/BMLP_SPLIT slice of each gradient, so
 // every output element has exactly one writer -> plain += into the gradient arena.
-constexpr int BMLP_SPLIT = 16;
+constexpr int BMLP_SPLIT = 64;
 __global__ __launch_bounds__(256) void bmlp_bwd_kernel(BmlpBatch bb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const BmlpArgs& a = bb.blk[blockIdx.y];
@@ -598,25 +606,36 @@ __global__ __launch_bounds__(256) void bmlp_bwd_kernel(BmlpBatch bb) {
             for (int b = 0; b < a.B; ++b) s += s2[b * a.D + d];
             a.db3[d] += s;
         }
-    for (int e = tid; e < a.B * a.J; e += 256) {
-        const int b = e / a.J, j = e % a.J;
+    // d pre1 only for the hidden units this workgroup owns (its slice of dW1 / db1 needs no others): (b, j) elements,
+    // four lanes per element splitting the sum over D, combined by two butterfly steps.
+    const int jn = (a.J + nparts - 1) / nparts, j0 = part * jn, j1 = min(a.J, j0 + jn);
+    const int ne = a.B * max(j1 - j0, 0);
+    for (int q0 = 0; q0 < ne * 4; q0 += 256) {  // uniform trip count: the shuffles need every lane
+        const int q = q0 + tid, e = q >> 2, sub = q & 3;
+        const bool v = e < ne;
+        const int b = v ? e / (j1 - j0) : 0, j = v ? j0 + e % (j1 - j0) : 0;
         float s = 0.f;
-        for (int d = 0; d < a.D; ++d) s += s2[b * a.D + d] * a.W3[(size_t)d * a.J + j];
-        const float h = a.hid[e];
-        s1[e] = s * (1.f - h * h);
+        if (v)
+            for (int d = sub; d < a.D; d += 4) s += s2[b * a.D + d] * a.W3[(size_t)d * a.J + j];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (v && sub == 0) {
+            const float h = a.hid[(size_t)b * a.J + j];
+            s1[b * jn + (j - j0)] = s * (1.f - h * h);
+        }
     }
     __syncthreads();
-    for (int e = part * 256 + tid; e < a.J * a.IN; e += 256 * nparts) {
-        const int j = e / a.IN, i = e % a.IN;
+    for (int e = tid; e < (j1 - j0) * a.IN; e += 256) {
+        const int jl = e / a.IN, i = e % a.IN;
         float s = 0.f;
-        for (int b = 0; b < a.B; ++b) s += s1[b * a.J + j] * a.v[b * a.IN + i];
-        a.dW1[e] += s;
+        for (int b = 0; b < a.B; ++b) s += s1[b * jn + jl] * a.v[b * a.IN + i];
+        a.dW1[(size_t)(j0 + jl) * a.IN + i] += s;
     }
     if (a.db1)
-        for (int j = part * 256 + tid; j < a.J; j += 256 * nparts) {
+        for (int jl = tid; jl < j1 - j0; jl += 256) {
             float s = 0.f;
-            for (int b = 0; b < a.B; ++b) s += s1[b * a.J + j];
-            a.db1[j] += s;
+            for (int b = 0; b < a.B; ++b) s += s1[b * jn + jl];
+            a.db1[j0 + jl] += s;
         }
 }
 
@@ -815,8 +834,14 @@ int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
 }
 
 int launch_drop_cast(const CastArgs& a, hipStream_t s) {
-    if (a.DP > 256) return V1T_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(drop_cast_kernel, dim3((a.rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 0, s, a);
+    if (a.DP > 256 || a.DP % 32) return V1T_ERR_UNSUPPORTED;
+    const dim3 grid((a.rows + LNB_ROWS - 1) / LNB_ROWS);
+    switch (a.DP / 32) {
+#define V1T_DC(C) case C: hipLaunchKernelGGL(drop_cast_kernel<C>, grid, dim3(256), 0, s, a); break;
+        V1T_DC(1) V1T_DC(2) V1T_DC(3) V1T_DC(4) V1T_DC(5) V1T_DC(6) V1T_DC(7) V1T_DC(8)
+#undef V1T_DC
+        default: return V1T_ERR_UNSUPPORTED;
+    }
     return ok();
 }
 

@@ -3,51 +3,48 @@
 
 namespace {
 
-struct MuOut {
-    float mu[2];
-    float pre1[GRID_HID];
-};
-
-DEVFN void predict_mu(const GridArgs& a, int n, const float* sW0, const float* sb0, const float* sW2, const float* sb2, float (&mu)[2], float (&h)[GRID_HID]) {
-    float x[3] = {0.f, 0.f, 0.f};
-    for (int i = 0; i < a.gd; ++i) x[i] = a.src[(size_t)n * a.gd + i];
-    float o0 = sb2[0], o1 = sb2[1];
-#pragma unroll
-    for (int j = 0; j < GRID_HID; ++j) {
-        float p = sb0[j];
-        for (int i = 0; i < a.gd; ++i) p += sW0[j * a.gd + i] * x[i];
-        h[j] = p;  // pre-activation
-        const float e = p > 0.f ? p : expm1f(p);
-        o0 += sW2[j] * e;
-        o1 += sW2[GRID_HID + j] * e;
-    }
-    mu[0] = tanhf(o0);
-    mu[1] = tanhf(o1);
-}
-
+// 64 neurons per workgroup (lane = neuron), four waves: wave w evaluates hidden units j = w, w+4, ... of the predictor,
+// the partial pre-activations of mu meet in LDS, then wave w writes the images b = w, w+4, ... (a latency-bound kernel:
+// the split quarters the per-neuron chain).
 __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
     __shared__ float sW0[GRID_HID * 3], sb0[GRID_HID], sW2[2 * GRID_HID], sb2[2];
-    const int tid = threadIdx.x;
+    __shared__ float so[4][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.gd > 0) {
         for (int i = tid; i < GRID_HID * a.gd; i += 256) sW0[i] = a.W0[i];
         for (int i = tid; i < GRID_HID; i += 256) sb0[i] = a.b0[i];
         for (int i = tid; i < 2 * GRID_HID; i += 256) sW2[i] = a.W2[i];
         if (tid < 2) sb2[tid] = a.b2[tid];
     }
+    const int n = blockIdx.x * 64 + lane;
+    const bool ok = n < a.N;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (ok) for (int i = 0; i < a.gd; ++i) x[i] = a.src[(size_t)n * a.gd + i];
+    float s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+    if (ok) { s00 = a.sigma[4 * n]; s01 = a.sigma[4 * n + 1]; s10 = a.sigma[4 * n + 2]; s11 = a.sigma[4 * n + 3]; }
     __syncthreads();
-    const int n = blockIdx.x * 256 + tid;
-    if (n >= a.N) return;
-    float mu[2];
+    float mu0, mu1;
     if (a.gd > 0) {
-        float h[GRID_HID];
-        predict_mu(a, n, sW0, sb0, sW2, sb2, mu, h);
+        float o0 = 0.f, o1 = 0.f;
+        for (int j = wave; j < GRID_HID; j += 4) {
+            float p = sb0[j];
+            for (int i = 0; i < a.gd; ++i) p += sW0[j * a.gd + i] * x[i];
+            const float e = p > 0.f ? p : expm1f(p);
+            o0 += sW2[j] * e;
+            o1 += sW2[GRID_HID + j] * e;
+        }
+        so[wave][0][lane] = o0;
+        so[wave][1][lane] = o1;
+        __syncthreads();
+        mu0 = tanhf(sb2[0] + ((so[0][0][lane] + so[1][0][lane]) + (so[2][0][lane] + so[3][0][lane])));
+        mu1 = tanhf(sb2[1] + ((so[0][1][lane] + so[1][1][lane]) + (so[2][1][lane] + so[3][1][lane])));
     } else {
-        mu[0] = a.mu_free[2 * n];
-        mu[1] = a.mu_free[2 * n + 1];
+        mu0 = ok ? a.mu_free[2 * n] : 0.f;
+        mu1 = ok ? a.mu_free[2 * n + 1] : 0.f;
     }
-    const float s00 = a.sigma[4 * n], s01 = a.sigma[4 * n + 1], s10 = a.sigma[4 * n + 2], s11 = a.sigma[4 * n + 3];
-    for (int b = 0; b < a.B; ++b) {
-        float g0 = mu[0], g1 = mu[1];
+    if (!ok) return;
+    for (int b = wave; b < a.B; b += 4) {
+        float g0 = mu0, g1 = mu1;
         if (a.eps) {
             const float e0 = a.eps[((size_t)b * a.N + n) * 2], e1 = a.eps[((size_t)b * a.N + n) * 2 + 1];
             g0 += s00 * e0 + s01 * e1;  // einsum "ancd,bnid->bnic": g_c = sum_d sigma[n][c][d] eps[d]
@@ -59,14 +56,21 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
             g0 += a.shift[2 * b];
             g1 += a.shift[2 * b + 1];
         }
-        a.grid[((size_t)b * a.N + n) * 2] = g0;
-        a.grid[((size_t)b * a.N + n) * 2 + 1] = g1;
+        *(float2*)(a.grid + ((size_t)b * a.N + n) * 2) = make_float2(g0, g1);
     }
 }
 
+// Backward of the grid: 64 neurons per workgroup (lane = neuron), the serial work of a neuron split over the four waves
+// so that the kernel's critical path is a quarter of the per-neuron chain (it is a latency-bound kernel: 125 workgroups
+// for 8000 neurons): wave w owns hidden units j = w, w+4, ... of the predictor (forward recompute and backward) and
+// images b = w, w+4, ...; the pieces meet in LDS twice (mu, then d mu / d sigma).
+constexpr int GB_WAVES = 4;
+constexpr int GB_SHIFT0 = 192;  // partial row: [0,2) db2, 2 + 6j + {dW2[0][j], dW2[1][j], db0[j], dW0[j][0..2]}, [192, 192 + 2B) d shift
 __global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
+    float* prow = a.part ? a.part + (size_t)blockIdx.x * a.part_stride : nullptr;
     __shared__ float sW0[GRID_HID * 3], sb0[GRID_HID], sW2[2 * GRID_HID], sb2[2];
-    __shared__ float sred[4];
+    __shared__ float so[GB_WAVES][2][64];  // partial pre-tanh mu per wave
+    __shared__ float sd[GB_WAVES][6][64];  // partial d mu (2), d sigma (4) per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.gd > 0) {
         for (int i = tid; i < GRID_HID * a.gd; i += 256) sW0[i] = a.W0[i];
@@ -74,24 +78,52 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
         for (int i = tid; i < 2 * GRID_HID; i += 256) sW2[i] = a.W2[i];
         if (tid < 2) sb2[tid] = a.b2[tid];
     }
-    __syncthreads();
-    const int n = blockIdx.x * 256 + tid;
+    const int n = blockIdx.x * 64 + lane;
     const bool ok = n < a.N;
-    float mu[2] = {0.f, 0.f}, h[GRID_HID];
-    if (ok) {
-        if (a.gd > 0) predict_mu(a, n, sW0, sb0, sW2, sb2, mu, h);
-        else { mu[0] = a.mu_free[2 * n]; mu[1] = a.mu_free[2 * n + 1]; }
-    }
+    // this wave's images: issue the loads first, they are consumed after the mu exchange
+    constexpr int MAXI = 8;  // images per wave per pass
+    float x[3] = {0.f, 0.f, 0.f};
+    if (ok) for (int i = 0; i < a.gd; ++i) x[i] = a.src[(size_t)n * a.gd + i];
     float s00 = 0, s01 = 0, s10 = 0, s11 = 0;
     if (ok) { s00 = a.sigma[4 * n]; s01 = a.sigma[4 * n + 1]; s10 = a.sigma[4 * n + 2]; s11 = a.sigma[4 * n + 3]; }
-    float dmu0 = 0.f, dmu1 = 0.f, ds00 = 0.f, ds01 = 0.f, ds10 = 0.f, ds11 = 0.f;
-    // images in chunks of 8: all loads of a chunk are issued before the first wave reduction / atomic, which the
-    // compiler may not move loads across (32 workgroups: this kernel runs at the latency of its own chain)
-    for (int b0 = 0; b0 < a.B; b0 += 8) {
-        float dd0[8], dd1[8], ee0[8], ee1[8];
+    __syncthreads();
+    // ---- predictor forward, hidden units j = wave, wave + 4, ...
+    constexpr int JW = (GRID_HID + GB_WAVES - 1) / GB_WAVES;
+    float hp[JW], he[JW];
+    float mu0, mu1;
+    if (a.gd > 0) {
+        float o0 = 0.f, o1 = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int b = b0 + u;
+        for (int k = 0; k < JW; ++k) {
+            const int j = wave + GB_WAVES * k;
+            float p = 0.f, e = 0.f;
+            if (j < GRID_HID) {
+                p = sb0[j];
+                for (int i = 0; i < a.gd; ++i) p += sW0[j * a.gd + i] * x[i];
+                e = p > 0.f ? p : expm1f(p);
+                o0 += sW2[j] * e;
+                o1 += sW2[GRID_HID + j] * e;
+            }
+            hp[k] = p;
+            he[k] = e;
+        }
+        so[wave][0][lane] = o0;
+        so[wave][1][lane] = o1;
+        __syncthreads();
+        // same summation order in every wave -> every wave holds the same mu
+        mu0 = tanhf(sb2[0] + ((so[0][0][lane] + so[1][0][lane]) + (so[2][0][lane] + so[3][0][lane])));
+        mu1 = tanhf(sb2[1] + ((so[0][1][lane] + so[1][1][lane]) + (so[2][1][lane] + so[3][1][lane])));
+    } else {
+        mu0 = ok ? a.mu_free[2 * n] : 0.f;
+        mu1 = ok ? a.mu_free[2 * n + 1] : 0.f;
+    }
+    // ---- images b = wave, wave + 4, ...: d shift, d mu, d sigma partials
+    float dmu0 = 0.f, dmu1 = 0.f, ds00 = 0.f, ds01 = 0.f, ds10 = 0.f, ds11 = 0.f;
+    for (int b0 = wave; b0 < a.B; b0 += GB_WAVES * MAXI) {
+        float dd0[MAXI], dd1[MAXI], ee0[MAXI], ee1[MAXI];
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int b = b0 + GB_WAVES * u;
             const bool v = ok && b < a.B;
             const size_t i2 = ((size_t)(v ? b : 0) * a.N + (v ? n : 0)) * 2;
             dd0[u] = v ? a.dgrid[i2] : 0.f;
@@ -100,19 +132,24 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
             ee1[u] = (v && a.eps) ? a.eps[i2 + 1] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int b = b0 + u;
-            if (b >= a.B) break;
+        for (int u = 0; u < MAXI; ++u) {
+            const int b = b0 + GB_WAVES * u;
+            if (b >= a.B) break;  // wave-uniform
             const float d0 = dd0[u], d1 = dd1[u], e0 = ee0[u], e1 = ee1[u];
             if (a.dshift) {  // d shift[b] = sum_n d grid (the shift is added after the clamp)
                 const float t0 = wave_sum(d0), t1 = wave_sum(d1);
                 if (lane == 0) {
-                    atomicAdd(&a.dshift[2 * b], t0);
-                    atomicAdd(&a.dshift[2 * b + 1], t1);
+                    if (prow) {
+                        prow[GB_SHIFT0 + 2 * b] = t0;
+                        prow[GB_SHIFT0 + 2 * b + 1] = t1;
+                    } else {
+                        atomicAdd(&a.dshift[2 * b], t0);
+                        atomicAdd(&a.dshift[2 * b + 1], t1);
+                    }
                 }
             }
-            const float p0 = mu[0] + s00 * e0 + s01 * e1;
-            const float p1 = mu[1] + s10 * e0 + s11 * e1;
+            const float p0 = mu0 + s00 * e0 + s01 * e1;
+            const float p1 = mu1 + s10 * e0 + s11 * e1;
             // torch.clamp passes the gradient on the closed interval [-1, 1]
             const float g0 = (p0 >= -1.f && p0 <= 1.f) ? d0 : 0.f;
             const float g1 = (p1 >= -1.f && p1 <= 1.f) ? d1 : 0.f;
@@ -120,50 +157,82 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
             ds00 += g0 * e0; ds01 += g0 * e1; ds10 += g1 * e0; ds11 += g1 * e1;
         }
     }
-    if (ok && a.dsigma) {
-        a.dsigma[4 * n] = ds00; a.dsigma[4 * n + 1] = ds01; a.dsigma[4 * n + 2] = ds10; a.dsigma[4 * n + 3] = ds11;
+    sd[wave][0][lane] = dmu0; sd[wave][1][lane] = dmu1;
+    sd[wave][2][lane] = ds00; sd[wave][3][lane] = ds01; sd[wave][4][lane] = ds10; sd[wave][5][lane] = ds11;
+    __syncthreads();
+    auto total = [&](int c) { return (sd[0][c][lane] + sd[1][c][lane]) + (sd[2][c][lane] + sd[3][c][lane]); };
+    dmu0 = total(0);
+    dmu1 = total(1);
+    if (wave == 0 && ok && a.dsigma) {
+        a.dsigma[4 * n] = total(2); a.dsigma[4 * n + 1] = total(3); a.dsigma[4 * n + 2] = total(4); a.dsigma[4 * n + 3] = total(5);
     }
     if (a.gd == 0) {
-        if (ok && a.dmu_free) { a.dmu_free[2 * n] = dmu0; a.dmu_free[2 * n + 1] = dmu1; }
+        if (wave == 0 && ok && a.dmu_free) { a.dmu_free[2 * n] = dmu0; a.dmu_free[2 * n + 1] = dmu1; }
         return;
     }
-    // grid-predictor backward: per-neuron terms reduced over the wave, one atomic per accumulator per wave
-    const float q0 = ok ? dmu0 * (1.f - mu[0] * mu[0]) : 0.f;  // d(pre-tanh)
-    const float q1 = ok ? dmu1 * (1.f - mu[1] * mu[1]) : 0.f;
-    float x[3] = {0.f, 0.f, 0.f};
-    if (ok) for (int i = 0; i < a.gd; ++i) x[i] = a.src[(size_t)n * a.gd + i];
-    // per-wave sums go to LDS; one atomic per accumulator per workgroup after the loop
-    __shared__ float sacc[4][GRID_HID][6];
-    __shared__ float sq[4][2];
-    {
+    // ---- predictor backward for this wave's hidden units: per-neuron terms reduced over the wave, one atomic per
+    // accumulator per wave (125 workgroups x 4 waves -> ~16 adds per address per wave slot)
+    const float q0 = ok ? dmu0 * (1.f - mu0 * mu0) : 0.f;  // d(pre-tanh)
+    const float q1 = ok ? dmu1 * (1.f - mu1 * mu1) : 0.f;
+    if (wave == 0) {
         const float t0 = wave_sum(q0), t1 = wave_sum(q1);
-        if (lane == 0) { sq[wave][0] = t0; sq[wave][1] = t1; }
+        if (lane == 0) {
+            if (prow) { prow[0] = t0; prow[1] = t1; }
+            else { atomicAdd(&a.db2[0], t0); atomicAdd(&a.db2[1], t1); }
+        }
     }
-#pragma unroll 2
-    for (int j = 0; j < GRID_HID; ++j) {
-        const float p = ok ? h[j] : 0.f;
-        const float e = p > 0.f ? p : expm1f(p);
+#pragma unroll
+    for (int k = 0; k < JW; ++k) {
+        const int j = wave + GB_WAVES * k;
+        if (j >= GRID_HID) break;  // wave-uniform
+        const float p = ok ? hp[k] : 0.f, e = ok ? he[k] : 0.f;
         const float de = p > 0.f ? 1.f : e + 1.f;  // ELU'
         const float dh = (q0 * sW2[j] + q1 * sW2[GRID_HID + j]) * de;
         const float w20 = wave_sum(q0 * e), w21 = wave_sum(q1 * e), bb = wave_sum(dh);
         float wx[3] = {0.f, 0.f, 0.f};
         for (int i = 0; i < a.gd; ++i) wx[i] = wave_sum(dh * x[i]);
         if (lane == 0) {
-            sacc[wave][j][0] = w20; sacc[wave][j][1] = w21; sacc[wave][j][2] = bb;
-            sacc[wave][j][3] = wx[0]; sacc[wave][j][4] = wx[1]; sacc[wave][j][5] = wx[2];
+            if (prow) {
+                float* q = prow + 2 + 6 * j;
+                q[0] = w20; q[1] = w21; q[2] = bb; q[3] = wx[0]; q[4] = wx[1]; q[5] = wx[2];
+            } else {
+                atomicAdd(&a.dW2[j], w20);
+                atomicAdd(&a.dW2[GRID_HID + j], w21);
+                atomicAdd(&a.db0[j], bb);
+                for (int i = 0; i < a.gd; ++i) atomicAdd(&a.dW0[j * a.gd + i], wx[i]);
+            }
         }
     }
-    __syncthreads();
-    if (tid < 2) atomicAdd(&a.db2[tid], sq[0][tid] + sq[1][tid] + sq[2][tid] + sq[3][tid]);
-    if (tid < GRID_HID * 6) {
-        const int j = tid / 6, c = tid % 6;
-        const float v = sacc[0][j][c] + sacc[1][j][c] + sacc[2][j][c] + sacc[3][j][c];
-        if (c == 0) atomicAdd(&a.dW2[j], v);
-        else if (c == 1) atomicAdd(&a.dW2[GRID_HID + j], v);
-        else if (c == 2) atomicAdd(&a.db0[j], v);
-        else if (c - 3 < a.gd) atomicAdd(&a.dW0[j * a.gd + c - 3], v);
+}
+
+// Second stage: column sums of the per-workgroup partial rows, added into the gradients (one writer per element).
+__global__ __launch_bounds__(256) void grid_bwd_reduce_kernel(GridArgs a, int nrows) {
+    __shared__ float sp[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int ncols = GB_SHIFT0 + (a.dshift ? 2 * a.B : 0);
+    const bool live = c < ncols && !(c >= 2 + 6 * GRID_HID && c < GB_SHIFT0);
+    float s0 = 0.f, s1 = 0.f;
+    if (live) {
+        int r = rg;
+        for (; r + 4 < nrows; r += 8) {
+            s0 += a.part[(size_t)r * a.part_stride + c];
+            s1 += a.part[(size_t)(r + 4) * a.part_stride + c];
+        }
+        if (r < nrows) s0 += a.part[(size_t)r * a.part_stride + c];
     }
-    (void)sred;
+    sp[rg][lane] = s0 + s1;
+    __syncthreads();
+    if (rg != 0 || !live) return;
+    const float v = (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
+    if (c >= GB_SHIFT0) { a.dshift[c - GB_SHIFT0] += v; return; }
+    if (a.gd == 0) return;
+    if (c < 2) { a.db2[c] += v; return; }
+    const int j = (c - 2) / 6, k = (c - 2) % 6;
+    if (k == 0) a.dW2[j] += v;
+    else if (k == 1) a.dW2[GRID_HID + j] += v;
+    else if (k == 2) a.db0[j] += v;
+    else if (k - 3 < a.gd) a.dW0[j * a.gd + k - 3] += v;
 }
 
 // shifter: one workgroup; thread b handles sample b (B <= 1024 -> loop)
@@ -190,10 +259,15 @@ __global__ __launch_bounds__(256) void shifter_fwd_kernel(ShifterArgs a) {
     }
 }
 
+// Per-thread partial sums of the 57 parameter gradients (dW0 10, db0 5, dW2 25, db2 5, dW4 10, db4 2) over the thread's
+// samples, one DPP wave reduction per gradient, one LDS add per wave: no same-address atomic chains (the previous version
+// issued 57 LDS atomics per sample, all lanes on the same words, and took 33 us for 16 samples).
 __global__ __launch_bounds__(256) void shifter_bwd_kernel(ShifterArgs a) {
-    __shared__ float acc[64];  // dW0 10, db0 5, dW2 25, db2 5, dW4 10, db4 2 = 57
-    if (threadIdx.x < 64) acc[threadIdx.x] = 0.f;
-    __syncthreads();
+    __shared__ float acc[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[57];
+#pragma unroll
+    for (int k = 0; k < 57; ++k) g[k] = 0.f;
     for (int b = threadIdx.x; b < a.B; b += 256) {
         const float x0 = a.pupil[2 * b], x1 = a.pupil[2 * b + 1];
         float h1[5], h2[5], o[2];
@@ -227,28 +301,40 @@ __global__ __launch_bounds__(256) void shifter_bwd_kernel(ShifterArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            atomicAdd(&acc[2 * j], d1[j] * x0);
-            atomicAdd(&acc[2 * j + 1], d1[j] * x1);
-            atomicAdd(&acc[10 + j], d1[j]);
+            g[2 * j] += d1[j] * x0;
+            g[2 * j + 1] += d1[j] * x1;
+            g[10 + j] += d1[j];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) atomicAdd(&acc[15 + 5 * j + i], d2[j] * h1[i]);
-            atomicAdd(&acc[40 + j], d2[j]);
+            for (int i = 0; i < 5; ++i) g[15 + 5 * j + i] += d2[j] * h1[i];
+            g[40 + j] += d2[j];
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) atomicAdd(&acc[45 + 5 * c + i], d3[c] * h2[i]);
-            atomicAdd(&acc[55 + c], d3[c]);
+            for (int i = 0; i < 5; ++i) g[45 + 5 * c + i] += d3[c] * h2[i];
+            g[55 + c] += d3[c];
         }
+    }
+    const bool active = wave * 64 < a.B;  // wave-uniform: waves without samples skip the reductions
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 57; ++k) {
+            const float v = wave_sum(g[k]);
+            if (lane == 0) acc[wave][k] = v;
+        }
+    } else if (lane < 57) {
+        acc[wave][lane] = 0.f;
     }
     __syncthreads();
     const int t = threadIdx.x;
-    if (t < 10) a.dW0[t] += acc[t];
-    else if (t < 15) a.db0[t - 10] += acc[t];
-    else if (t < 40) a.dW2[t - 15] += acc[t];
-    else if (t < 45) a.db2[t - 40] += acc[t];
-    else if (t < 55) a.dW4[t - 45] += acc[t];
-    else if (t < 57) a.db4[t - 55] += acc[t];
+    if (t >= 57) return;
+    const float v = acc[0][t] + acc[1][t] + acc[2][t] + acc[3][t];
+    if (t < 10) a.dW0[t] += v;
+    else if (t < 15) a.db0[t - 10] += v;
+    else if (t < 40) a.dW2[t - 15] += v;
+    else if (t < 45) a.db2[t - 40] += v;
+    else if (t < 55) a.dW4[t - 45] += v;
+    else a.db4[t - 55] += v;
 }
 
 inline int ok() { return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH; }
@@ -258,13 +344,29 @@ inline int ok() { return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUN
 int launch_grid_fwd(const GridArgs& a, hipStream_t s) {
     if (a.N <= 0) return V1T_OK;
     if (a.gd < 0 || a.gd > 3) return V1T_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(grid_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(grid_fwd_kernel, dim3((a.N + 63) / 64), dim3(256), 0, s, a);
     return ok();
 }
-int launch_grid_bwd(const GridArgs& a, hipStream_t s) {
-    if (a.N <= 0) return V1T_OK;
-    if (a.gd < 0 || a.gd > 3) return V1T_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(grid_bwd_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
+static int gb_stride(int B) { return (GB_SHIFT0 + 2 * B + 31) / 32 * 32; }
+size_t grid_bwd_ws_bytes(int B, int N) { return sizeof(float) * (size_t)((N + 63) / 64) * gb_stride(B); }
+int launch_grid_bwd(const GridArgs& a0, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (a0.N <= 0) return V1T_OK;
+    if (a0.gd < 0 || a0.gd > 3) return V1T_ERR_UNSUPPORTED;
+    GridArgs a = a0;
+    const int nwg = (a.N + 63) / 64;
+    a.part = nullptr;
+    a.part_stride = 0;
+    const bool two_stage = ws && (a.gd > 0 || a.dshift);
+    if (two_stage) {
+        if (ws_bytes < grid_bwd_ws_bytes(a.B, a.N)) return V1T_ERR_ARG;
+        a.part = (float*)ws;
+        a.part_stride = gb_stride(a.B);
+    }
+    hipLaunchKernelGGL(grid_bwd_kernel, dim3(nwg), dim3(256), 0, s, a);
+    if (two_stage) {
+        const int ncols = GB_SHIFT0 + (a.dshift ? 2 * a.B : 0);
+        hipLaunchKernelGGL(grid_bwd_reduce_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, a, nwg);
+    }
     return ok();
 }
 int launch_shifter_fwd(const ShifterArgs& a, hipStream_t s) {

@@ -165,9 +165,12 @@ class _GridFn(torch.autograd.Function):
         dmu = None if mu_free is None else torch.empty_like(mu_free)
         dsigma = torch.empty_like(sigma) if eps is not None else torch.zeros_like(sigma)
         dshift = None if shift is None else torch.zeros_like(shift)
-        L.check(L.load().v1t_readout_grid_backward(B, N, gd, L.ptr(src), L.ptr(W0), L.ptr(b0), L.ptr(W2), L.ptr(b2), L.ptr(mu_free), sigma.data_ptr(),
-                                                   L.ptr(eps), dgrid.data_ptr(), *[L.ptr(x[0]) for x in sinks], L.ptr(dmu),
-                                                   dsigma.data_ptr() if eps is not None else None, L.ptr(dshift), L.stream()), "readout_grid_backward")
+        lib = L.load()
+        ws = torch.empty(int(lib.v1t_readout_grid_backward_ws_bytes(B, N)), dtype=torch.uint8, device=dgrid.device)
+        L.check(lib.v1t_readout_grid_backward_ws(B, N, gd, L.ptr(src), L.ptr(W0), L.ptr(b0), L.ptr(W2), L.ptr(b2), L.ptr(mu_free), sigma.data_ptr(),
+                                                 L.ptr(eps), dgrid.data_ptr(), *[L.ptr(x[0]) for x in sinks], L.ptr(dmu),
+                                                 dsigma.data_ptr() if eps is not None else None, L.ptr(dshift), ws.data_ptr(), ws.numel(), L.stream()),
+                "readout_grid_backward")
         return (None, None, *[x[1] for x in sinks], dmu, dsigma, None, dshift)
 
 
