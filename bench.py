@@ -160,7 +160,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "bf16+fp16",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: default V1T (4 blocks, D=155, 4 heads, MLP 488, T=1654) + Gaussian2d, 7 mice x "
                                    f"{a.neurons} neurons, input 1x144x256 -> 36x64, batch 16 per mouse, dropout+sampling on, AdamW+L1",

@@ -80,7 +80,7 @@ def test_intermediate_taps_vs_reference_golden(golden, dev):
     B, T, DP, D = 2, core.num_tokens, core.padded_dim, cfg.emb_dim
     n = B * T * DP * 4
     x0 = core.workspace_tensor("x0")[:n].view(torch.float32).view(B, T, DP)[:, :, :D]
-    assert_close("patch_embed", sample(x0), golden["g1/tap/patch_embed"], 1e-5, 1e-5)  # fp32 kernel
+    assert_close("patch_embed", sample(x0), golden["g1/tap/patch_embed"], 1e-3, 5e-4)  # fp16 operands (2^-12), fp32 accumulate
     xm = core.workspace_tensor("xm", 0)[:n].view(torch.float32).view(B, T, DP)[:, :, :D]
     assert_close("mha0", sample(xm), golden["g1/tap/mha0"], 1e-3, 1e-3)
 

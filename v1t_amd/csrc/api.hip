@@ -205,6 +205,18 @@ DropCfg make_drop(bool training, float p, uint64_t seed, uint32_t stream) {
 
 // V1T_NOSPLIT=<mask> (dev, numerics ablation): bit 0/1/2/3 runs QKV / proj / FC1 / FC2 of the forward in plain bf16
 static const int g_nosplit = std::getenv("V1T_NOSPLIT") ? atoi(std::getenv("V1T_NOSPLIT")) : 0;
+// Operand format of the forward linear layers (patch projection, QKV, proj, FC1, FC2): fp16 planes + one fp16 MFMA per
+// step (default; 0.28 of the 1e-3 parity bound on the default V1T), or V1T_FWD_BF16X3=1 (dev, numerics ablation): bf16
+// hi + lo planes and three MFMAs (0.07 of the bound, 2.4x the GEMM time). The second plane of every forward activation /
+// weight holds the one or the other; the bf16 "hi" planes are what the backward reads either way.
+static const int g_fwd_f16 = (std::getenv("V1T_FWD_BF16X3") && atoi(std::getenv("V1T_FWD_BF16X3"))) ? 0 : 1;
+static inline void fwd_operands(GemmNTArgs& g) {
+    if (!g_fwd_f16) return;
+    g.f16 = 1;  // the producers wrote fp16 into the second planes (EPI_BIAS_GELU writes C2_lo the same way)
+    if (g.A_lo && g.B_lo) { g.A = g.A_lo; g.B = g.B_lo; }
+    else g.f16 = 0;  // V1T_NOSPLIT ablation: plain bf16
+    g.A_lo = g.B_lo = nullptr;
+}
 // V1T_DEBUG_SYNC=1: print the launch about to be made and synchronise after it (fault localisation).
 static const bool g_debug_sync = std::getenv("V1T_DEBUG_SYNC") != nullptr;
  AttnDrop make_adrop(bool training, float p, uint64_t seed, uint32_t stream) {
@@ -392,7 +404,7 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     auto desc = [&](long long src, int src_ld, long long dst, int drows, int dcols, int rp, int rv, int cp, int cv, int tr, int f32) {
         PackDesc d;
         d.src_off = src; d.dst_off = dst; d.src_ld = src_ld; d.drows = drows; d.dcols = dcols;
-        d.rseg_pad = rp; d.rseg_valid = rv; d.cseg_pad = cp; d.cseg_valid = cv; d.transpose = tr; d.out_f32 = f32 & 1; d.lo_plane = (f32 >> 1) & 1;
+        d.rseg_pad = rp; d.rseg_valid = rv; d.cseg_pad = cp; d.cseg_valid = cv; d.transpose = tr; d.out_f32 = f32 & 1; d.lo_plane = (f32 >> 1) & 1 ? (g_fwd_f16 ? 2 : 1) : 0;
         h->pack.push_back(d);
     };
     for (int k = 0; k < h->NB; ++k) {
@@ -527,15 +539,16 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
             float* u32 = (float*)(ws + w.u32);
             CHECK(launch_patch_unfold_f32(pa, pm == 2, u32, h->PDX, s));
             LnFwdArgs l{};
-            l.x = u32; l.gamma = arena + h->o_pln_w; l.beta = arena + h->o_pln_b; l.z = u_hi; l.z_lo = u_lo;
+            l.x = u32; l.gamma = arena + h->o_pln_w; l.beta = arena + h->o_pln_b; l.z = u_hi; l.z_lo = u_lo; l.lo_f16 = g_fwd_f16;
             l.mean = (float*)(ws + w.pmean1); l.rstd = (float*)(ws + w.prstd1);
             l.rows = R; l.T = h->T; l.D = h->PD; l.DP = h->PDX; l.eps = 1e-5f; l.ones_col = h->PD;
             CHECK(launch_ln_fwd(l, s));
         } else {
-            CHECK(launch_patch_unfold(pa, u_hi, u_lo, h->PDX, s));
+            CHECK(launch_patch_unfold(pa, u_hi, u_lo, g_fwd_f16, h->PDX, s));
         }
         GemmNTArgs g{};
         g.A = u_hi; g.A_lo = u_lo; g.lda = h->PDX; g.B = (const bf16_t*)(sh + h->s_pw); g.B_lo = (const bf16_t*)(sh + h->s_pw_lo); g.ldb = h->PD;
+        fwd_operands(g);
         g.M = R; g.N = DP; g.K = h->PD; g.ldc = DP;
         g.bias = (const float*)(sh + h->s_pb);
         if (pm == 3) {  // projection output -> LayerNorm(D) -> + pos / class token -> dropout (vit.py:92-100, 122-128)
@@ -584,7 +597,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
 
         LnFwdArgs l1{};
         l1.x = xcur; l1.inject = h->inject ? (float*)(ws + w.beta) + (size_t)k * B * DP : nullptr; l1.xout = xa;
-        l1.gamma = arena + b.ln1w; l1.beta = arena + b.ln1b; l1.z = z1; l1.z_lo = (bf16_t*)(wb + w.z1_lo);
+        l1.gamma = arena + b.ln1w; l1.beta = arena + b.ln1b; l1.z = z1; l1.z_lo = (bf16_t*)(wb + w.z1_lo); l1.lo_f16 = g_fwd_f16;
         l1.mean = (float*)(wb + w.mean1); l1.rstd = (float*)(wb + w.rstd1);
         l1.rows = R; l1.T = h->T; l1.D = D; l1.DP = DP; l1.eps = h->c.ln_eps; l1.ones_col = -1;
         CHECK(launch_ln_fwd(l1, s));
@@ -593,10 +606,11 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         g.A = z1; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_qkv); g.ldb = DP; g.M = R; g.N = 3 * HDP; g.K = DP; g.C = qkv; g.ldc = 3 * HDP;
         g.A_lo = (const bf16_t*)(wb + w.z1_lo); g.B_lo = (const bf16_t*)(sh + b.s_qkv_lo);
         if (g_nosplit & 1) g.A_lo = g.B_lo = nullptr;
+        fwd_operands(g);
         CHECK(launch_gemm_nt(g, EPI_BF16, s));
 
         AttnArgs at{};
-        at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = o; at.ldo = HDP; at.o_lo = (bf16_t*)(wb + w.o_lo); at.lse2 = (float*)(wb + w.lse2);
+        at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = o; at.ldo = HDP; at.o_lo = (bf16_t*)(wb + w.o_lo); at.lo_f16 = g_fwd_f16; at.lse2 = (float*)(wb + w.lse2);
         at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
         at.adrop = make_adrop(train, h->c.t_dropout, seed, 8 * k + 0);
         CHECK(launch_attn_fwd(at, DP, s));
@@ -605,13 +619,14 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         g.A = o; g.lda = HDP; g.B = (const bf16_t*)(sh + b.s_proj); g.ldb = HDP; g.M = R; g.N = DP; g.K = HDP; g.C = xm; g.ldc = DP;
         g.A_lo = (const bf16_t*)(wb + w.o_lo); g.B_lo = (const bf16_t*)(sh + b.s_proj_lo);
         if (g_nosplit & 2) g.A_lo = g.B_lo = nullptr;
+        fwd_operands(g);
         g.bias = b.s_projb >= 0 ? (const float*)(sh + b.s_projb) : nullptr; g.res = xa; g.ldres = DP;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 1);
         g.row_scale = path_scale ? path_scale + (size_t)(2 * k + 0) * B : nullptr; g.T = h->T;
         CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));
 
         LnFwdArgs l2{};
-        l2.x = xm; l2.inject = nullptr; l2.xout = nullptr; l2.gamma = arena + b.ln2w; l2.beta = arena + b.ln2b; l2.z = z2; l2.z_lo = (bf16_t*)(wb + w.z2_lo);
+        l2.x = xm; l2.inject = nullptr; l2.xout = nullptr; l2.gamma = arena + b.ln2w; l2.beta = arena + b.ln2b; l2.z = z2; l2.z_lo = (bf16_t*)(wb + w.z2_lo); l2.lo_f16 = g_fwd_f16;
         l2.mean = (float*)(wb + w.mean2); l2.rstd = (float*)(wb + w.rstd2);
         l2.rows = R; l2.T = h->T; l2.D = D; l2.DP = DP; l2.eps = h->c.ln_eps;
         l2.ones_col = (DP > D && h->blk[k].fc1b >= 0) ? DP - 1 : -1;  // d(fc1 bias) comes out of the dW1 GEMM
@@ -621,6 +636,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         g.A = z2; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_fc1); g.ldb = DP; g.M = R; g.N = MP; g.K = DP; g.C = hpre; g.ldc = MP;
         g.A_lo = (const bf16_t*)(wb + w.z2_lo); g.B_lo = (const bf16_t*)(sh + b.s_fc1_lo); g.C2_lo = (bf16_t*)(wb + w.hact_lo);
         if (g_nosplit & 4) g.A_lo = g.B_lo = nullptr;
+        fwd_operands(g);
         g.C2 = hact; g.ldc2 = MP; g.bias = b.s_fc1b >= 0 ? (const float*)(sh + b.s_fc1b) : nullptr;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
         CHECK(launch_gemm_nt(g, EPI_BIAS_GELU, s));
@@ -629,6 +645,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         g.A = hact; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc2); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = xo; g.ldc = DP;
         g.A_lo = (const bf16_t*)(wb + w.hact_lo); g.B_lo = (const bf16_t*)(sh + b.s_fc2_lo);
         if (g_nosplit & 8) g.A_lo = g.B_lo = nullptr;
+        fwd_operands(g);
         g.bias = b.s_fc2b >= 0 ? (const float*)(sh + b.s_fc2b) : nullptr; g.res = xm; g.ldres = DP;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 3);
         g.row_scale = path_scale ? path_scale + (size_t)(2 * k + 1) * B : nullptr; g.T = h->T;
@@ -803,7 +820,7 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         bf16_t* gd = (bf16_t*)(sc + sl.pgd);
         bf16_t* u = (bf16_t*)(sc + sl.pu);
         CHECK(launch_patch_bwd_pos_cast(pa, gd, s));
-        CHECK(launch_patch_unfold(pa, u, nullptr, h->PDX, s));
+        CHECK(launch_patch_unfold(pa, u, nullptr, 0, h->PDX, s));
         GemmTNArgs t{};
         t.Y = gd; t.ldy = DP; t.X = u; t.ldx = h->PDX; t.M = R; t.NY = DP; t.NX = h->PDX; t.dW = grads + h->o_pw; t.ldw = h->PD;
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->PDX; t.xseg_valid = h->PD; t.alpha = 1.f;

@@ -9,7 +9,8 @@
 struct AttnArgs {
     const bf16_t* qkv; int ldqkv;  // [rows][3*H*DP]: q | k | v, each H heads of DP (zero padded) columns
     bf16_t* o; int ldo;            // [rows][H*DP]
-    bf16_t* o_lo;                  // forward only: low plane of o (o - float(bf16(o))) or nullptr
+    bf16_t* o_lo;                  // forward only: second plane of o or nullptr: bf16 residual o - float(bf16(o)), or fp16(o) when lo_f16
+    int lo_f16;
     float* lse2;                   // [B][H][T]  log2-domain: max + log2(sum)
     int B, H, T;
     const float* scale;            // device: 1 value, or H values when scale_per_head

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
                 for (int j = 0; j < 4; ++j) {
                     const float v = o[d][4 * rq + j] * inv;
                     w[j] = (bf16_t)v;
-                    wl[j] = (bf16_t)(v - (float)w[j]);
+                    wl[j] = aux_plane(v, w[j], a.lo_f16);
                 }
                 *(bf16x4*)(orow + 32 * d + 8 * rq + 4 * h2) = w;
                 if (a.o_lo) *(bf16x4*)(a.o_lo + (orow - a.o) + 32 * d + 8 * rq + 4 * h2) = wl;

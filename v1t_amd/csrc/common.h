@@ -29,6 +29,19 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 DEVFN f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// fp16 operands (same rate, 11-bit significand): the forward linear layers, whose operand rounding dominates the error of
+// the predicted responses (DESIGN.md "Numerics"). The planes travel in bf16_t-typed buffers as raw 16-bit patterns.
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+DEVFN f32x16 mfma32h(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// Second plane of a forward activation / weight next to its bf16 plane `hi` (which the backward uses): the fp16 value
+// (saturated) when f16, else the bf16 residual v - hi of the split-bf16 ("bf16x3") scheme.
+DEVFN bf16_t aux_plane(float v, bf16_t hi, int f16) {
+    if (f16) return __builtin_bit_cast(bf16_t, (f16_t)fminf(fmaxf(v, -65504.f), 65504.f));
+    return (bf16_t)(v - (float)hi);
+}
 DEVFN int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // An accumulator tile X (rows in registers, column on the lane) as the B operand of the next

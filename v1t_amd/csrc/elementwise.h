@@ -15,7 +15,7 @@ struct PackDesc {
     int rseg_pad, rseg_valid, cseg_pad, cseg_valid;  // maps in SOURCE orientation (rows, cols of the natural matrix)
     int transpose;      // dst[r][c] = src[c][r]
     int out_f32;
-    int lo_plane;       // bf16 only: write the residual bf16(v - float(bf16(v))) (low plane of the split-bf16 operand)
+    int lo_plane;       // 16-bit outputs: 1 = the residual bf16(v - float(bf16(v))) (split-bf16 low plane), 2 = fp16(v)
 };
 int launch_pack(const float* params, void* shadow, const PackDesc* d_desc, int ndesc, hipStream_t s);
 
@@ -37,7 +37,7 @@ int launch_patch_embed_bwd(const PatchArgs& a, hipStream_t s);
 // MFMA form of the patch embedding (C*P*P % 32 == 0): the unfolded patches as a bf16 matrix U [B*T][ldu]
 // (row b*T is the class token: zeros; columns >= C*P*P: a 1 in column C*P*P of every patch row, then zeros - the
 // ones column hands the bias gradient to the weight-gradient GEMM), hi and optional lo plane.
-int launch_patch_unfold(const PatchArgs& a, bf16_t* u_hi, bf16_t* u_lo, int ldu, hipStream_t s);
+int launch_patch_unfold(const PatchArgs& a, bf16_t* u_hi, bf16_t* u_lo, int lo_f16, int ldu, hipStream_t s);
 // backward prologue: dpos / dcls sums over the batch and gd = bf16(dropout_bwd(g)) [B*T][DP] for the dW GEMM
 int launch_patch_bwd_pos_cast(const PatchArgs& a, bf16_t* gd, hipStream_t s);
 // Patch modes 2 / 3 (vit.py:83-100): the unfolded patches in fp32 (they go through a LayerNorm over the patch before
@@ -64,7 +64,8 @@ struct LnFwdArgs {
     float* xout;         // [rows][DP] (may alias x when inject == nullptr -> not written)
     const float* gamma; const float* beta;  // [D] natural
     bf16_t* z;           // [rows][DP]
-    bf16_t* z_lo;        // [rows][DP] low plane (z - float(bf16(z))) or nullptr
+    bf16_t* z_lo;        // [rows][DP] second plane or nullptr: bf16 residual z - float(bf16(z)), or fp16(z) when lo_f16
+    int lo_f16;
     float* mean; float* rstd;  // [rows]
     int rows, T, D, DP;
     float eps;

@@ -16,7 +16,7 @@ __global__ void pack_kernel(const float* __restrict__ params, char* shadow, cons
         if (rr < d.rseg_valid && cr < d.cseg_valid)
             v = params[d.src_off + (long long)(rs * d.rseg_valid + rr) * d.src_ld + cs * d.cseg_valid + cr];
         if (d.out_f32) ((float*)(shadow + d.dst_off))[i] = v;
-        else if (d.lo_plane) ((bf16_t*)(shadow + d.dst_off))[i] = (bf16_t)(v - (float)(bf16_t)v);
+        else if (d.lo_plane) ((bf16_t*)(shadow + d.dst_off))[i] = aux_plane(v, (bf16_t)v, d.lo_plane == 2);
         else ((bf16_t*)(shadow + d.dst_off))[i] = (bf16_t)v;
     }
 }
@@ -104,7 +104,7 @@ __global__ void patch_bwd_pos_kernel(PatchArgs a) {
 }
 
 // U[b*T + t][j]: thread = one 16-B chunk (8 columns) of one row
-__global__ __launch_bounds__(256) void patch_unfold_kernel(PatchArgs a, bf16_t* u_hi, bf16_t* u_lo, int ldu) {
+__global__ __launch_bounds__(256) void patch_unfold_kernel(PatchArgs a, bf16_t* u_hi, bf16_t* u_lo, int lo_f16, int ldu) {
     const int PD = a.C * a.P * a.P, PP = a.P * a.P, L = a.NH * a.NW, T = L + 1, cpr = ldu / 8;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)a.B * T * cpr) return;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void patch_unfold_kernel(PatchArgs a, bf16_t* 
                 v = 1.f;
             }
             hi[e] = (bf16_t)v;
-            lo[e] = (bf16_t)(v - (float)hi[e]);
+            lo[e] = aux_plane(v, hi[e], lo_f16);
         }
     }
     *(bf16x8*)(u_hi + row * ldu + 8 * jc) = hi;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
             const int cc = c + e;
             const float z = (cc < a.D) ? (v[k][e] - mean) * rstd * a.gamma[cc] + a.beta[cc] : (cc == a.ones_col ? 1.f : 0.f);
             zh[e] = (bf16_t)z;
-            zl[e] = (bf16_t)(z - (float)zh[e]);
+            zl[e] = aux_plane(z, zh[e], a.lo_f16);
         }
         *(bf16x4_t*)(a.z + (size_t)row * a.DP + c) = zh;
         if (a.z_lo) *(bf16x4_t*)(a.z_lo + (size_t)row * a.DP + c) = zl;
@@ -889,9 +889,9 @@ int launch_dropout_mask(uint8_t* out, long long rows, long long cols, DropCfg d,
     return ok();
 }
 
-int launch_patch_unfold(const PatchArgs& a, bf16_t* u_hi, bf16_t* u_lo, int ldu, hipStream_t s) {
+int launch_patch_unfold(const PatchArgs& a, bf16_t* u_hi, bf16_t* u_lo, int lo_f16, int ldu, hipStream_t s) {
     const long long n = (long long)a.B * (a.NH * a.NW + 1) * (ldu / 8);
-    hipLaunchKernelGGL(patch_unfold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, u_hi, u_lo, ldu);
+    hipLaunchKernelGGL(patch_unfold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, u_hi, u_lo, lo_f16, ldu);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 int launch_patch_bwd_pos_cast(const PatchArgs& a, bf16_t* gd, hipStream_t s) {

@@ -28,7 +28,8 @@ struct GemmNTArgs {
     // Used by the four forward linear layers, whose bf16 operand rounding otherwise dominates the error
     // of the predicted responses (DESIGN.md "Numerics").
     const bf16_t* A_lo; const bf16_t* B_lo;
-    bf16_t* C2_lo;                // EPI_BIAS_GELU: low plane of the activation output
+    bf16_t* C2_lo;                // EPI_BIAS_GELU: second plane of the activation output (bf16 residual, or fp16 when f16)
+    int f16;                      // A and B hold fp16 bit patterns: one fp16 MFMA per step (A_lo / B_lo unused)
     int M, N, K;  // M = valid rows (guarded); N % (32*NBLK) == 0; K % 32 == 0
     void* C; int ldc;
     const float* bias;            // [N] fp32 (padded with zeros) or nullptr

@@ -78,7 +78,7 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
                 if (ok) {
                     const bf16_t ah = (bf16_t)a;
                     g.C2[(size_t)row * g.ldc2 + col] = ah;
-                    if (g.C2_lo) g.C2_lo[(size_t)row * g.ldc2 + col] = (bf16_t)(a - (float)ah);
+                    if (g.C2_lo) g.C2_lo[(size_t)row * g.ldc2 + col] = aux_plane(a, ah, g.f16);
                 }
             } else if constexpr (EPI == EPI_DGELU) {
                 float d = 0.f;
@@ -109,7 +109,7 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
 
 // NW waves per workgroup = 32*NW rows (only 4 is launched: 64-row workgroups measured the same time on the
 // single-column-tile GEMMs, which are bound by how they read A, not by workgroups in flight).
-template <int NBLK, int EPI, int NW, int BK>
+template <int NBLK, int EPI, int NW, int BK, bool F16 = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
     constexpr int BM = 32 * NW, NT = 64 * NW;
     constexpr int LS = BK + 8, KC = BK / 8;  // LDS row stride (16-B pad: 80 / 144 B), 16-B chunks per row
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
 #pragma unroll
             for (int nb = 0; nb < NBLK; ++nb) {
                 const bf16x8 b = *(const bf16x8*)(&sB[buf][32 * nb * LS + frag_off + 16 * ks]);
-                acc[nb] = mfma32(a, b, acc[nb]);
+                if constexpr (F16) acc[nb] = mfma32h(a, b, acc[nb]);
+                else acc[nb] = mfma32(a, b, acc[nb]);
             }
         }
         if (kt + 1 < nk) swrite(buf ^ 1);
@@ -302,6 +303,20 @@ int launch_nt_nw(const GemmNTArgs& a, int epi, hipStream_t s) {
     const int grid = ((a.M + BMW - 1) / BMW) * (a.N / BN);
     if (grid <= 0) return V1T_OK;
     const dim3 blk(64 * NW);
+    if (a.f16) {
+        if (a.A_lo || a.B_lo) return V1T_ERR_ARG;
+        switch (epi) {
+            case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BF16, NW, BK, true>), dim3(grid), blk, 0, s, a); break;
+            case EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_F32, NW, BK, true>), dim3(grid), blk, 0, s, a); break;
+            case EPI_BIAS_RES: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_RES, NW, BK, true>), dim3(grid), blk, 0, s, a); break;
+            case EPI_PATCH: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_PATCH, NW, BK, true>), dim3(grid), blk, 0, s, a); break;
+            case EPI_BIAS_GELU:
+                if constexpr (NW == 4) { hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_GELU, 4, BK, true>), dim3(grid), blk, 0, s, a); break; }
+                return V1T_ERR_ARG;
+            default: return V1T_ERR_ARG;
+        }
+        return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    }
     if (a.A_lo) {
         if (!a.B_lo) return V1T_ERR_ARG;
         switch (epi) {

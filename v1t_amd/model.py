@@ -231,6 +231,7 @@ class Model(nn.Module):
         self.add_module("readouts", Readouts(args, model=args.readout, input_shape=self.core.output_shape, output_shapes=self.output_shapes, ds=ds))
         self.elu1 = ELU1()
         self._mouse_arenas: t.Dict[str, FlatArena] = {}
+        self._mouse_l1: t.Dict[str, t.Tuple[int, t.List[t.Tuple[int, int, float]]]] = {}
 
     @property
     def device(self) -> torch.device:
@@ -295,14 +296,19 @@ class Model(nn.Module):
         adds for this mouse (readout features gaussian2d.py:233-234, core shifter core_shifter.py:21-22, image shifter
         image_cropper.py:38-39); everything else coefficient 0."""
         a = self.mouse_arena(mouse_id)
+        cached = self._mouse_l1.get(mouse_id)
+        if cached is not None and cached[0] == a.generation:
+            return cached[1]
         ro = self.readouts[mouse_id]
-        coeff = {id(ro.features): float(ro.reg_scale)}
+        coeff = {id(ro.features): float(ro.reg_scale)}  # reg_scale buffers live on the device: read them once, not per step
         if self.core_shifter is not None:
             cs = self.core_shifter[mouse_id]
-            coeff.update({id(p): float(cs.reg_scale) for p in cs.parameters()})
+            c = float(cs.reg_scale)
+            coeff.update({id(p): c for p in cs.parameters()})
         if self.image_cropper.image_shifter is not None:
             sh = self.image_cropper.image_shifter[mouse_id]
-            coeff.update({id(p): float(sh.reg_scale) for p in sh.parameters()})
+            c = float(sh.reg_scale)
+            coeff.update({id(p): c for p in sh.parameters()})
         runs: t.List[t.List[float]] = []
         for s in a.slots:
             c = coeff.get(id(s.tensor), 0.0)
@@ -310,4 +316,6 @@ class Model(nn.Module):
                 runs[-1][1] += s.numel
             else:
                 runs.append([s.offset, s.numel, c])
-        return [(int(o), int(n), float(c)) for o, n, c in runs]
+        out = [(int(o), int(n), float(c)) for o, n, c in runs]
+        self._mouse_l1[mouse_id] = (a.generation, out)
+        return out

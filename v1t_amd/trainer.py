@@ -53,6 +53,7 @@ class Trainer:
         self.core_lr = args.lr if getattr(args, "core_lr", None) is None else args.core_lr
         self.opt = FusedAdamW(args.lr, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_eps)
         self.batch_size = args.batch_size
+        self._core_l1: t.Optional[float] = None
 
     def train_step(self, batches: t.Dict[str, t.Dict[str, torch.Tensor]]) -> t.Dict[str, torch.Tensor]:
         """batches: mouse_id -> full batch (image, behavior, pupil_center, response) on the device.
@@ -78,7 +79,9 @@ class Trainer:
         # optimizer: core (L1 once per mouse-batch of the global step), then the local mice's arenas
         if not core.frozen:
             ca = core._arena
-            self.opt.step_arena(ca, self.core_lr, [(0, ca.param_floats, float(core.reg_scale) * len(self.mouse_ids))])
+            if self._core_l1 is None:  # the reg_scale buffer lives on the device: one read, not one sync per step
+                self._core_l1 = float(core.reg_scale) * len(self.mouse_ids)
+            self.opt.step_arena(ca, self.core_lr, [(0, ca.param_floats, self._core_l1)])
             core.mark_updated()
         for mouse_id in self.sharding.local_mice():
             a = model.mouse_arena(mouse_id)
