@@ -221,6 +221,14 @@ int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const
                            int H, int T, int DP, const float* scale, int scale_per_head, int mask_diag,
                            float dropout_p, uint64_t seed, uint32_t stream_id, float* delta_ws,
                            void* dqkv, float* dscale, void* stream);
+/* Same with a caller-owned scratch of v1t_attention_backward_ws_bytes(): the dK/dV kernel materialises
+ * dS' = P (dP - delta) ([B*H][T][roundup(T,128)] bf16) and dQ = dS' . K runs as one streaming GEMM over it, instead of
+ * recomputing S and dP a second time (5 MFMA products instead of 7). Not used for mask_diag (LSA). NULL = recompute. */
+long long v1t_attention_backward_ws_bytes(int B, int H, int T);
+int v1t_attention_backward_ws(const void* qkv, const void* o, const void* dO, const float* lse2, int B, int H, int T,
+                              int DP, const float* scale, int scale_per_head, int mask_diag, float dropout_p,
+                              uint64_t seed, uint32_t stream_id, float* delta_ws, void* dqkv, float* dscale,
+                              void* ds_ws, long long ds_bytes, void* stream);
 
 /* ------------------------------------------- attention rollout (utils/attention_rollout.py:92-133) */
 /* Head-max of the softmax probabilities of one block, recomputed from that block's saved qkv

@@ -115,6 +115,21 @@ def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
             assert rel_to_max(d[:, i].cpu(), gq[:, i].cpu()) < 2e-2, nm  # bf16 P / dS / outputs
     if lsa and T > 1:  # the scale is a learnable parameter only with LSA (vit.py:235-239)
         assert rel_to_max(dscale.cpu(), gs.cpu()) < 2e-2
+    if not lsa:
+        # materialised-dS' path (dK/dV kernel writes dS', dQ = dS' . K as a GEMM): dK / dV bit-identical to the recompute path
+        # (same kernel body), dQ sums the same bf16 products in another order
+        nb = int(lib.v1t_attention_backward_ws_bytes(B, H, T))
+        ws = torch.full((nb,), 0xFF, dtype=torch.uint8, device=dev)  # NaN patterns: every element read must have been written
+        d2 = torch.zeros_like(dqkv)
+        for out in (d2, torch.zeros_like(dqkv)):
+            L.check(lib.v1t_attention_backward_ws(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid,
+                                                  delta.data_ptr(), out.data_ptr(), None, ws.data_ptr(), nb, L.stream()))
+        assert torch.equal(d2, out)  # bit-reproducible
+        e = d2.float().view(B * T, 3, H * DP)
+        assert torch.equal(e[:, 1:], d[:, 1:])
+        if float(gq[:, 0].abs().max()) > 0:
+            assert rel_to_max(e[:, 0].cpu(), gq[:, 0].cpu()) < 2e-2
+            assert rel_to_max(e[:, 0].cpu(), d[:, 0].cpu()) < 1e-2
 
 
 @pytest.mark.parametrize("B,C,H,W,N", [(3, 155, 29, 57, 1000), (2, 64, 29, 57, 257), (1, 40, 15, 29, 3), (2, 155, 5, 7, 900)])

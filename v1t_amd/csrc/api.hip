@@ -138,8 +138,12 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
     return w;
 }
 
+// V1T_ATTN_BWD_DS=1 (dev): attention backward with the materialised dS' (attention.h) instead of the fused recompute
+// kernel. Measured at the default shape: dK/dV + store 395 us + dQ GEMM 120 us = 515 us against 501 us fused, so it is
+// off; it needs LDS-staged 16-B stores in the dK/dV body and a deeper pipeline in the GEMM to pay.
+static const int g_attn_ds = (std::getenv("V1T_ATTN_BWD_DS") && atoi(std::getenv("V1T_ATTN_BWD_DS"))) ? 1 : 0;
 struct ScratchLayout {
-    long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, slab, pu, pgd, pdu, total;
+    long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, slab, pu, pgd, pdu, ds, total;
 };
 // contraction rows per workgroup of the weight-gradient GEMMs: aim at >= ~512 workgroups
 int tn_mchunk(long long R, int tiles) {
@@ -184,6 +188,7 @@ ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     s.pu = take(h->s_pw >= 0 ? R * h->PDX * 2 : 0);
     s.pgd = take(h->s_pw >= 0 ? R * h->DP * 2 : 0);
     s.pdu = take(h->c.patch_mode >= 2 ? R * h->PD * 4 : 0);
+    s.ds = take(g_attn_ds && !h->c.use_lsa ? (long long)attn_ds_bytes(B, h->H, h->T) : 0);  // materialised dS' of one block
     s.total = cur;
     return s;
 }
@@ -757,6 +762,7 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         at.adrop = make_adrop(train, h->c.t_dropout, seed, 8 * k + 0);
         at.dO = dO; at.lddo = HDP; at.delta = delta; at.dqkv = dqkv; at.lddqkv = 3 * HDP;
         at.dscale = h->c.use_lsa ? grads + b.scale : nullptr;
+        if (g_attn_ds && !h->c.use_lsa) { at.ds = (bf16_t*)(sc + sl.ds); at.ldds = attn_ds_ld(h->T); }
         CHECK(launch_attn_delta(at, DP, delta, s));
         CHECK(launch_attn_bwd(at, DP, s));
         // dWqkv += dqkv^T z1
@@ -994,7 +1000,17 @@ int v1t_attention_forward(const void* qkv, int B, int H, int T, int DP, const fl
 int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const float* lse2, int B, int H, int T, int DP,
                            const float* scale, int scale_per_head, int mask_diag, float dropout_p, uint64_t seed,
                            uint32_t stream_id, float* delta_ws, void* dqkv, float* dscale, void* stream) {
+    return v1t_attention_backward_ws(qkv, o, dO, lse2, B, H, T, DP, scale, scale_per_head, mask_diag, dropout_p, seed, stream_id, delta_ws, dqkv,
+                                     dscale, nullptr, 0, stream);
+}
+long long v1t_attention_backward_ws_bytes(int B, int H, int T) { return (long long)attn_ds_bytes(B, H, T); }
+int v1t_attention_backward_ws(const void* qkv, const void* o, const void* dO, const float* lse2, int B, int H, int T, int DP,
+                              const float* scale, int scale_per_head, int mask_diag, float dropout_p, uint64_t seed,
+                              uint32_t stream_id, float* delta_ws, void* dqkv, float* dscale, void* ds_ws, long long ds_bytes,
+                              void* stream) {
+    if (ds_ws && ds_bytes < (long long)attn_ds_bytes(B, H, T)) return V1T_ERR_WORKSPACE;
     AttnArgs a{};
+    if (ds_ws) { a.ds = (bf16_t*)ds_ws; a.ldds = attn_ds_ld(T); }
     a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.o = (bf16_t*)o; a.ldo = H * DP; a.lse2 = (float*)lse2; a.B = B; a.H = H; a.T = T;
     a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
     a.adrop = make_adrop(dropout_p > 0.f, dropout_p, seed, stream_id);

@@ -613,7 +613,7 @@ DEVFN void attn_bwd_dq_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& ld
 }
 
 // ------------------------------------------------------------------------------------------
-template <int DP, bool DROP, bool DIAG>
+template <int DP, bool DROP, bool DIAG, bool STORE = false>
 DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& lds) {
     using G = Geo<DP>;
     constexpr int TR = BWD_TR;  // 64-query tiles = two independent 32-query halves (see the dQ kernel)
@@ -737,12 +737,37 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
             dv[d] = mfma32(tdf[2 * d + 1], p1, dv[d]);
         }
     };
-    auto phase3_k = [&](const bf16x8 (&tqf)[2 * G::DB], const f32x16& s) {
+    // STORE: the bf16 dS' that feeds dK also goes to HBM, row-major [query][key], for the dQ GEMM. A lane owns its key
+    // column; element j of k-step sx is query row 16 sx + 8 (j >> 2) + 4 h2 + (j & 3) of the 32-query half, so one store
+    // instruction writes two query rows x 32 consecutive keys (64 B each). Uniform row base in SGPRs, lane offset fixed.
+    const unsigned ds_lane = STORE ? (unsigned)((4 * h2 * a.ldds + key) * 2) : 0u;
+    const char* ds_bh = STORE ? (const char*)(a.ds + (size_t)(b * a.H + h) * a.T * a.ldds) : nullptr;
+    const unsigned kmask = kok ? 0xFFFFFFFFu : 0u;  // keys beyond T: zeros (the GEMM multiplies them with clamped K rows)
+    auto store_ds = [&](auto tail_tag, const bf16x8& v, int qt, int hf, int sx) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        u32x4 w = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] &= kmask;
+        const bf16x8 z = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int qrow = TR * qt + 32 * hf + 16 * sx + 8 * (j >> 2) + (j & 3);  // wave-uniform part of the row
+            if constexpr (TAIL) {
+                if (qrow + 4 * h2 >= a.T) continue;
+            }
+            *(bf16_t*)(const_cast<char*>(ds_bh) + (size_t)qrow * a.ldds * 2 + ds_lane) = z[j];
+        }
+    };
+    auto phase3_k = [&](auto tail_tag, const bf16x8 (&tqf)[2 * G::DB], const f32x16& s, int qt, int hf) {
         const bf16x8 s0 = acc_to_b_pk(s, 0), s1 = acc_to_b_pk(s, 1);
 #pragma unroll
         for (int d = 0; d < G::DB; ++d) {
             dk[d] = mfma32(tqf[2 * d], s0, dk[d]);
             dk[d] = mfma32(tqf[2 * d + 1], s1, dk[d]);
+        }
+        if constexpr (STORE) {
+            store_ds(tail_tag, s0, qt, hf, 0);
+            store_ds(tail_tag, s1, qt, hf, 1);
         }
     };
     // One wave per SIMD issues in order, and an MFMA keeps the issue port only 8 of its 32 cycles: the
@@ -770,7 +795,7 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
         tr_load_d(tdf, 0, buf);
         tr_load_q(tqf, 0, buf);
         phase3_v(tdf, dp0);
-        phase3_k(tqf, s0);
+        phase3_k(tail_tag, tqf, s0, qt, 0);
         softmax_half(tail_tag, s1, dp1, qt, 1, buf);
         __builtin_amdgcn_sched_group_barrier(0x100, 8 * G::DB + 8, 2);
 #pragma unroll
@@ -782,7 +807,7 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
         tr_load_d(tdf, 1, buf);
         tr_load_q(tqf, 1, buf);
         phase3_v(tdf, dp1);
-        phase3_k(tqf, s1);
+        phase3_k(tail_tag, tqf, s1, qt, 1);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -852,9 +877,91 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(AttnArgs a, int 
     }
 }
 
+// dK/dV alone, materialising dS' (AttnArgs::ds) ...
+template <int DP, bool DROP>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_store_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) BwdLds<DP> lds;
+    attn_bwd_dkv_body<DP, DROP, false, true>(a, blockIdx.x, gridDim.x, lds);
+}
+// ... and dQ^T += K^T . dS'^T as a streaming GEMM over it: workgroup = 128 queries of one (image, head), wave = 32 queries,
+// 64-key stages of dS' [128 q][64 k] and K [64 k][DP] by LDS-DMA, double buffered. HBM-bound on reading dS'
+// (2 B per (query, key)): the K tiles come from L2.
+template <int DP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
+    using G = Geo<DP>;
+    constexpr int KT = 64, SSTR = KT + 8;
+    using DmaS = TileDma<KT, SSTR, 128, 4>;
+    using DmaK = TileDma<DP, G::RSTR, KT, 4>;
+    __shared__ __attribute__((aligned(16))) bf16_t sS[2][DmaS::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][DmaK::LDS_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rb, h, b;
+    decode_block(a, blockIdx.x, gridDim.x, rb, h, b);
+    const int q = rb * 128 + 32 * wave + (lane & 31);
+    const int h2 = lane >> 5;
+    DmaS dmaS;
+    DmaK dmaK;
+    dmaS.init(lane, wave, a.ldds);
+    dmaK.init(lane, wave, a.ldqkv);
+    const bf16_t* kbase = a.qkv + (size_t)b * a.T * a.ldqkv + a.H * DP + h * DP;
+    const bf16_t* sbase = a.ds + (size_t)(b * a.H + h) * a.T * a.ldds;
+    f32x16 dq[G::DB];
+#pragma unroll
+    for (int d = 0; d < G::DB; ++d) zero16(dq[d]);
+    const int soff = (32 * wave + (lane & 31)) * SSTR + 4 * h2;
+    const int toff = tr_lane_off(lane, G::RSTR);
+    const int nt = a.ldds / KT;  // every key column up to ldds was written (zeros beyond T)
+    auto stage = [&](int kt, int buf) {
+        dmaS.issue(sbase + KT * kt, 128 * rb, a.T, sS[buf]);
+        dmaK.issue(kbase, KT * kt, a.T, sK[buf]);
+    };
+    stage(0, 0);
+    dma_wait_and_barrier();
+    for (int kt = 0; kt < nt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nt) stage(kt + 1, buf ^ 1);
+        const bf16_t* sp = &sS[buf][soff];
+        const bf16_t* tk = &sK[buf][toff];
+#pragma unroll
+        for (int ks = 0; ks < KT / 16; ++ks) {
+            // B operand = dS'^T, k order of tr_frag / acc_to_b: slot j of lane half h2 is key 16 ks + 8 (j >> 2) + 4 h2 + (j & 3)
+            const bf16x4 lo = *(const bf16x4*)(sp + 16 * ks), hi = *(const bf16x4*)(sp + 16 * ks + 8);
+            bf16x8 bfr;
+            bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
+            bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+#pragma unroll
+            for (int d = 0; d < G::DB; ++d) dq[d] = mfma32(tr_frag<G::RSTR>(tk, 16 * ks, 32 * d), bfr, dq[d]);
+        }
+        dma_wait_and_barrier();
+    }
+    if (q < a.T) {
+        const float f = a.scale[a.scale_per_head ? h : 0] * (a.adrop.thresh8 ? a.adrop.inv_keep : 1.0f);
+        bf16_t* orow = a.dqkv + ((size_t)b * a.T + q) * a.lddqkv + h * DP;
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                bf16x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(dq[d][4 * rq + j] * f);
+                *(bf16x4*)(orow + 32 * d + 8 * rq + 4 * h2) = w;
+            }
+    }
+}
+
 template <int DP, bool DROP, bool DIAG>
 int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
     const int n = ((a.T + 127) / 128) * a.H * a.B;
+    if constexpr (DP >= 128 && !DIAG) {
+        if (a.ds) {
+            if (a.ldds < attn_ds_ld(a.T) || a.ldds % 64) return V1T_ERR_ARG;
+            prof_begin(PROF_ATTN_DKV, s);
+            hipLaunchKernelGGL((attn_bwd_dkv_store_kernel<DP, DROP>), dim3(n), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP>), dim3(n), dim3(256), 0, s, a);
+            prof_end(PROF_ATTN_DKV, s);
+            return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+        }
+    }
     static const bool split = std::getenv("V1T_ATTN_BWD_SPLIT") != nullptr;  // dev switch: time the two bodies separately
     if (DP >= 128 && !split) {
         const int n8 = (n + 7) / 8 * 8;

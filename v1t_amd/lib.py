@@ -77,6 +77,8 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_gemm_tn_slab": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_ll, c_void_p]),
     "v1t_attention_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_u64, c_u32, c_void_p, c_void_p, c_void_p]),
     "v1t_attention_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_u64, c_u32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "v1t_attention_backward_ws_bytes": (c_ll, [c_int, c_int, c_int]),
+    "v1t_attention_backward_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_u64, c_u32, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     "v1t_rollout_headmax": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "v1t_rollout_vecmat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "v1t_profile_enable": (c_int, [c_int, c_int]),
