@@ -171,6 +171,15 @@ int v1t_resize_bilinear(const float* in, int planes, int IH, int IW, float* out,
 int v1t_elu1_poisson(const float* u, const float* y, long long n, float loss_scale, float gscale,
                      float* yhat, float* du, float* loss, void* stream);
 
+/* ------------------------------------------------------------------ input pipeline (packed per-mouse store in HBM) */
+/* MiceDataset.__getitem__ (data.py:419-434) for a whole batch: gather trials index[B] from a packed [trials][E] array
+ * (fp32, or uint8 when src_u8) and apply the dataset transform (data.py:341-403)
+ *   out[b][e] = ((src[index[b]][e] - sub[e % nsub]) / div[e % ndiv]) * mul[e % nmul]      (NULL array = step skipped)
+ * gray_c > 1: out[b] has E / gray_c elements, the mean over the gray_c channel planes (color2gray, data.py:338-339). */
+int v1t_gather_transform(const void* src, int src_u8, const int* index, int B, long long E, const float* sub,
+                         long long nsub, const float* div, long long ndiv, const float* mul, long long nmul,
+                         int gray_c, float* out, void* stream);
+
 /* ------------------------------------------------------- validation / evaluation metrics (streaming, fp64 moments) */
 /* compute_metrics (train.py:29-39) without stacking predictions on the host (train.py:24-25,186): fold one micro-batch
  * pred/target[B][N] into acc[5][N] += (sum p, sum t, sum p^2, sum t^2, sum p*t) per neuron and

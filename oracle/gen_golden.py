@@ -62,6 +62,8 @@ def import_reference():
 
     stub("torchinfo", summary=lambda *a, **k: None)
     stub("wandb")
+    ru = stub("ruamel")  # v1t.utils.yaml (imported by v1t.utils.utils, which v1t.data imports); never called here
+    ru.yaml = stub("ruamel.yaml", YAML=lambda *a, **k: SimpleNamespace())
 
     class Resize:
         def __init__(self, size, antialias=False):
@@ -525,6 +527,34 @@ def gen_metrics(out: dict, log=print):
     log(f"  g9: ok (mean stc {stc.mean():.4f}, cta {cta.mean():.4f}, feve {kept.mean():.4f} over {len(kept)}/{len(fev)} neurons)")
 
 
+def gen_data(out: dict, log=print):
+    """G10: the reference's MiceDataset + DataLoader (data.py:275-491) over a tiny recording written in the on-disk layout by
+    oracle/fake_sensorium.py (same seeds in the tests): collated, standardised batches per tier."""
+    import tempfile
+
+    import_reference()
+    from torch.utils.data import DataLoader
+    from v1t import data as RD
+
+    from oracle import fake_sensorium as FS
+
+    with tempfile.TemporaryDirectory() as root:
+        for ds_name, mouse, shape, gray in (("sensorium", "A", (1, 12, 16), False), ("franke2022", "F", (2, 6, 8), True)):
+            FS.write_fake_mouse(root, ds_name, mouse, seed=3, trials=23, image_shape=shape, neurons=9)
+            args = SimpleNamespace(ds_name=ds_name, behavior_mode=3, seed=1, gray_scale=gray, verbose=0, limit_data=None)
+            for tier in ("train", "validation", "test"):
+                dsx = RD.MiceDataset(args, tier=tier, data_dir=root, mouse_id=mouse)
+                batches = list(DataLoader(dsx, batch_size=4, shuffle=False))
+                tag = f"g10/{ds_name}/{tier}"
+                out[f"{tag}/n"] = np.int64(len(dsx))
+                for k in ("image", "response", "behavior", "pupil_center", "image_id", "trial_id"):
+                    out[f"{tag}/{k}"] = torch.cat([b[k] for b in batches]).numpy()
+                assert out[f"{tag}/image"].dtype == np.float32 and out[f"{tag}/response"].dtype == np.float32
+                out[f"{tag}/precision"] = np.asarray(dsx._response_precision)
+                out[f"{tag}/image_shape"] = np.asarray(dsx.image_shape)
+            log(f"  g10/{ds_name}: ok ({len(dsx)} test trials, image {dsx.image_shape})")
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
@@ -534,6 +564,13 @@ def main():
         path = os.path.join(ROOT, "tests", "golden", fname)
         np.savez_compressed(path, **d)
         print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB, {len(d)} arrays")
+
+    d = {}
+    print("G10 data path (MiceDataset + DataLoader over the on-disk layout)")
+    gen_data(d)
+    save("g10_data.npz", d)
+    if "--only-g10" in sys.argv:
+        return
 
     d = {}
     print("G9 validation / evaluation metrics")

@@ -53,6 +53,7 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_attention_dropout_rate": (c_float, [c_float]),
     "v1t_gaussian2d_forward": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "v1t_gaussian2d_backward": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "v1t_gather_transform": (c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_void_p, c_void_p]),
     "v1t_metrics_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "v1t_metrics_correlation": (c_int, [c_void_p, c_ll, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "v1t_metrics_group_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
