@@ -527,6 +527,54 @@ def gen_metrics(out: dict, log=print):
     log(f"  g9: ok (mean stc {stc.mean():.4f}, cta {cta.mean():.4f}, feve {kept.mean():.4f} over {len(kept)}/{len(fev)} neurons)")
 
 
+def gen_checkpoint(out: dict, log=print):
+    """G11: the checkpoint the reference's Scheduler writes (utils/scheduler.py:84-104) after the G6 step (2 mice, AdamW,
+    dropout 0, eps from G6): model keys, optimizer param-group structure and AdamW moments, scheduler state keys."""
+    import tempfile
+
+    import_reference()
+    from v1t.losses import PoissonLoss
+    from v1t.utils.scheduler import Scheduler
+
+    cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 200, "B": 123},
+                   p_dropout=0.0, t_dropout=0.0)
+    seed, ds_size, lr = 55, 4500.0, 1.647e-3
+    sd = W.make_state_dict(cfg, seed)
+    model = build_reference_model(cfg, sd, seed)
+    crit = PoissonLoss(SimpleNamespace(ds_scale=1), ds={m: SimpleNamespace(dataset=range(int(ds_size))) for m in cfg.mouse_ids})
+    opt = torch.optim.AdamW(model.get_parameters(core_lr=lr), lr=lr, betas=(0.9, 0.9999), eps=1e-8, weight_decay=0)
+    model.train(True)
+    opt.zero_grad()
+    for i, mouse in enumerate(cfg.mouse_ids):
+        batch = W.make_batch(cfg, mouse, 4, seed)
+        torch.manual_seed(1000 + i)  # the same draws as G6 (gen_step)
+        y, _, _ = model(inputs=batch["image"], mouse_id=mouse, behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
+        (crit(y_true=batch["response"], y_pred=y, mouse_id=mouse, batch_size=4) + model.regularizer(mouse)).backward()
+    opt.step()
+    with tempfile.TemporaryDirectory() as d:
+        sch = Scheduler(SimpleNamespace(output_dir=d, device=torch.device("cpu"), verbose=0), model=model, optimizer=opt, mode="max")
+        assert sch.step(0.25, epoch=3) is False  # better than -inf: writes the checkpoint
+        ck = torch.load(os.path.join(d, "ckpt", "model_state.pt"), weights_only=False)
+    assert set(ck) == {"epoch", "value", "model", "optimizer", "scheduler"}
+    out["g11/epoch"], out["g11/value"] = np.int64(ck["epoch"]), np.float64(ck["value"])
+    out["g11/model_keys"] = np.array(list(ck["model"].keys()))
+    out["g11/scheduler_keys"] = np.array(sorted(ck["scheduler"].keys()))
+    names = [k for k, _ in model.named_parameters()]
+    pid = {id(p): k for k, p in model.named_parameters()}
+    order = [pid[id(p)] for g in opt.param_groups for p in g["params"]]  # optimizer index -> parameter name
+    out["g11/opt_param_names"] = np.array(order)
+    out["g11/group_names"] = np.array([g["name"] for g in ck["optimizer"]["param_groups"]])
+    out["g11/group_sizes"] = np.array([len(g["params"]) for g in ck["optimizer"]["param_groups"]])
+    out["g11/group_lr"] = np.array([g["lr"] for g in ck["optimizer"]["param_groups"]])
+    for i, k in enumerate(order):
+        st = ck["optimizer"]["state"][i]
+        out[f"g11/exp_avg/{k}"] = sample(st["exp_avg"])
+        out[f"g11/exp_avg_sq/{k}"] = sample(st["exp_avg_sq"])
+        assert float(st["step"]) == 1.0
+    assert sorted(order) == sorted(names)
+    log(f"  g11: ok ({len(order)} parameters in {len(ck['optimizer']['param_groups'])} groups)")
+
+
 def gen_data(out: dict, log=print):
     """G10: the reference's MiceDataset + DataLoader (data.py:275-491) over a tiny recording written in the on-disk layout by
     oracle/fake_sensorium.py (same seeds in the tests): collated, standardised batches per tier."""
@@ -564,6 +612,13 @@ def main():
         path = os.path.join(ROOT, "tests", "golden", fname)
         np.savez_compressed(path, **d)
         print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB, {len(d)} arrays")
+
+    d = {}
+    print("G11 checkpoint written by the reference's Scheduler")
+    gen_checkpoint(d)
+    save("g11_checkpoint.npz", d)
+    if "--only-g11" in sys.argv:
+        return
 
     d = {}
     print("G10 data path (MiceDataset + DataLoader over the on-disk layout)")

@@ -24,10 +24,72 @@ from .model import Model
 
 
 class FusedAdamW:
-    """AdamW over flat arenas via v1t_adamw_step (one launch per (arena, range))."""
+    """AdamW over flat arenas via v1t_adamw_step (one launch per (arena, range)).
+
+    `param_groups`, `state_dict()` and `load_state_dict()` speak torch.optim.AdamW's format over
+    `model.get_parameters(core_lr)` (train.py:216-223), so checkpoints written by the reference's Scheduler
+    (utils/scheduler.py:84-144) load here and the ones written here load into the reference's optimizer."""
 
     def __init__(self, lr: float, betas=(0.9, 0.9999), eps: float = 1e-8, weight_decay: float = 0.0):
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.model: t.Optional[Model] = None
+        self.param_groups: t.List[t.Dict[str, t.Any]] = []
+
+    def bind(self, model: Model, core_lr: float) -> None:
+        self.model = model
+        self.param_groups = []
+        for g in model.get_parameters(core_lr=core_lr):
+            self.param_groups.append({"name": g["name"], "lr": float(g.get("lr", self.lr)), "betas": tuple(self.betas), "eps": self.eps,
+                                      "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "params": list(g["params"])})
+
+    def group_lr(self, name: str) -> float:
+        for g in self.param_groups:
+            if g["name"] == name:
+                return float(g["lr"])
+        raise KeyError(name)
+
+    def _slots(self) -> t.Dict[int, t.Tuple[t.Any, t.Any]]:
+        """id(parameter) -> (arena, slot) over the core arena and every mouse arena"""
+        m = self.model
+        m.core.prepare()
+        arenas = [m.core._arena] + [m.mouse_arena(k) for k in m.readouts.keys()]
+        return {id(s.tensor): (a, s) for a in arenas for s in a.slots}
+
+    def state_dict(self) -> t.Dict[str, t.Any]:
+        slots = self._slots()
+        state, groups, i = {}, [], 0
+        for g in self.param_groups:
+            idx = []
+            for p in g["params"]:
+                a, s = slots[id(p)]
+                if a.exp_avg is not None and a.step > 0:
+                    view = lambda buf: s.view(buf[s.offset:s.offset + s.numel]).detach().clone().contiguous()
+                    state[i] = {"step": torch.tensor(float(a.step)), "exp_avg": view(a.exp_avg), "exp_avg_sq": view(a.exp_avg_sq)}
+                idx.append(i)
+                i += 1
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": idx})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd: t.Dict[str, t.Any]) -> None:
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        slots = self._slots()
+        i = 0
+        steps: t.Dict[int, int] = {}
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            if len(saved["params"]) != len(g["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            g["lr"] = float(saved["lr"])
+            for p, j in zip(g["params"], saved["params"]):
+                a, s = slots[id(p)]
+                st = sd["state"].get(j, sd["state"].get(str(j)))
+                if st is not None:
+                    m_, v_ = a.moments()
+                    s.view(m_[s.offset:s.offset + s.numel]).copy_(st["exp_avg"].to(m_.device))
+                    s.view(v_[s.offset:s.offset + s.numel]).copy_(st["exp_avg_sq"].to(v_.device))
+                    steps.setdefault(id(a), int(float(st["step"])))
+                    a.step = steps[id(a)]
+                i += 1
 
     def step_arena(self, arena, lr: float, ranges: t.Sequence[t.Tuple[int, int, float]], zero_grad: bool = True) -> None:
         """ranges: (start, n, l1_coeff) in floats; all ranges of one arena share its step counter."""
@@ -52,6 +114,7 @@ class Trainer:
         self.lr = args.lr
         self.core_lr = args.lr if getattr(args, "core_lr", None) is None else args.core_lr
         self.opt = FusedAdamW(args.lr, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_eps)
+        self.opt.bind(model, self.core_lr)
         self.batch_size = args.batch_size
         self._core_l1: t.Optional[float] = None
 
@@ -81,11 +144,12 @@ class Trainer:
             ca = core._arena
             if self._core_l1 is None:  # the reg_scale buffer lives on the device: one read, not one sync per step
                 self._core_l1 = float(core.reg_scale) * len(self.mouse_ids)
-            self.opt.step_arena(ca, self.core_lr, [(0, ca.param_floats, self._core_l1)])
+            self.opt.step_arena(ca, self.opt.group_lr("core"), [(0, ca.param_floats, self._core_l1)])
             core.mark_updated()
         for mouse_id in self.sharding.local_mice():
             a = model.mouse_arena(mouse_id)
-            self.opt.step_arena(a, self.lr, model.mouse_l1_ranges(mouse_id))
+            # readout / shifter groups start at the same lr and are only ever scaled together (scheduler.py:158-168)
+            self.opt.step_arena(a, self.opt.group_lr("readouts"), model.mouse_l1_ranges(mouse_id))
         return {"loss": torch.stack(losses).sum() if losses else torch.zeros((), device=core._arena.data.device)}
 
     @torch.no_grad()
