@@ -75,6 +75,10 @@ def cpu_baseline(seconds_budget: float = 30.0) -> dict:
             "sample": f"oracle fp32 train step (fwd+bwd, no dropout masks), default V1T, 1 mouse x 8000 neurons, B={B}, {n} reps after 1 warm-up, torch {torch.__version__} CPU, {cores} threads"}
 
 
+# (FETCH_SIZE, WRITE_SIZE) in KiB per launch at the default shape, dropout on (profiles/r01_pmc_attention_fetch_write.txt)
+PMC_KIB = {"attn_fwd": (57173.5, 33975.5), "attn_bwd_fused": (166139.7, 104235.2), "attn_bwd_dkv_store": (85146.8, 414981.3), "attn_bwd_dq_gemm": (192139.6, 33252.1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,17 +140,20 @@ def main():
     if rank == 0:
         images = sharding.images_per_step() * a.steps
         fl = algorithmic_flops(args, a.neurons)
-        # dominant kernel: attention backward, the dQ and dK/dV bodies in one launch — the 5 algorithmic products
-        # of flash backward (S, dP, dV, dK, dQ) = 2.5 x forward attention FLOPs; the second evaluation of S and dP
-        # (each body recomputes them: 7 executed products) is NOT counted
-        names = {0: "attn_fwd", 1: "attn_bwd_dq (split launches only)", 2: "attn_bwd_fused (dQ + dK/dV bodies)"}
-        mult = {0: 1.0, 1: 0.5, 2: 2.5}[a.profile_class] if a.profile_class in (0, 1, 2) else 0.0
+        # dominant kernel: attn_bwd_dkv_store (dK/dV of flash backward + the materialised dS'): 4 of the 5 algorithmic
+        # products of the backward (S, dP, dV, dK) = 2.0 x forward attention FLOPs per launch; the fifth (dQ = dS' . K) is
+        # the separate HBM-bound GEMM attn_bwd_dq_gemm (class 1, 0.5 x). With V1T_ATTN_BWD_DS=0 class 2 is the fused
+        # recompute kernel instead (all 5 products, 2.5 x) - the label below follows the switch.
+        fused = os.environ.get("V1T_ATTN_BWD_DS", "1") == "0"
+        names = {0: "attn_fwd", 1: "attn_bwd_dq_gemm (dQ = dS' . K)", 2: "attn_bwd_fused (dQ + dK/dV bodies)" if fused else "attn_bwd_dkv_store (dK/dV + dS')"}
+        mult = {0: 1.0, 1: 0.5, 2: 2.5 if fused else 2.0}[a.profile_class] if a.profile_class in (0, 1, 2) else 0.0
         per_launch = mult * fl["attn_fwd_per_image_block"] * args.batch_size
         # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, KiB, separate --pmc
         # passes: profiles/r01_pmc_attention_fetch_write.txt, tools/pmc_attn.sh); recorded, not collected live, and
         # only valid for the shape it was measured on (16 images x 4 heads x 1654 tokens x 160 padded head dim)
         default_shape = args.batch_size == 16 and a.neurons == 8000
-        traffic = {0: (2 * 57173.5 + 33975.5) * 1024, 2: (2 * 166139.7 + 104235.2) * 1024}.get(a.profile_class) if default_shape else None
+        traffic = {0: PMC_KIB["attn_fwd"], 1: PMC_KIB["attn_bwd_dq_gemm"], 2: PMC_KIB["attn_bwd_fused" if fused else "attn_bwd_dkv_store"]}.get(a.profile_class)
+        traffic = (2 * traffic[0] + traffic[1]) * 1024 if (default_shape and traffic) else None
         avg_ms = total_ms.value / max(launches.value, 1)
         achieved = per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         line = {

@@ -138,10 +138,12 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
     return w;
 }
 
-// V1T_ATTN_BWD_DS=1 (dev): attention backward with the materialised dS' (attention.h) instead of the fused recompute
-// kernel. Measured at the default shape: dK/dV + store 395 us + dQ GEMM 120 us = 515 us against 501 us fused, so it is
-// off; it needs LDS-staged 16-B stores in the dK/dV body and a deeper pipeline in the GEMM to pay.
-static const int g_attn_ds = (std::getenv("V1T_ATTN_BWD_DS") && atoi(std::getenv("V1T_ATTN_BWD_DS"))) ? 1 : 0;
+// Attention backward with the materialised dS' (attention.h): the dK/dV kernel stores dS' tile-major and dQ = dS' . K is a
+// streaming GEMM, instead of the fused kernel whose dQ body recomputes S and dP (7 MFMA products -> 5). Standalone at the
+// default shape it is a draw (dK/dV + store 378 us + GEMM 120 us = 498 us against 497 us fused, dropout on; 470 against 490
+// without dropout); inside the training step it is 1.6 % of the whole step faster (3062 against 3015 images/s, twice),
+// so it is the default. V1T_ATTN_BWD_DS=0 (dev) selects the fused recompute kernel, which LSA (mask_diag) always uses.
+static const int g_attn_ds = (std::getenv("V1T_ATTN_BWD_DS") && !atoi(std::getenv("V1T_ATTN_BWD_DS"))) ? 0 : 1;
 struct ScratchLayout {
     long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, slab, pu, pgd, pdu, ds, total;
 };

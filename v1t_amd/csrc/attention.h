@@ -22,12 +22,13 @@ struct AttnArgs {
     const float* delta;            // [B][H][T] keep_prob * rowsum(dO * O)
     bf16_t* dqkv; int lddqkv;      // [rows][3*H*DP]
     float* dscale;                 // [H] fp32 atomics or nullptr (LSA scale gradient)
-    // optional scratch [B*H][T][ldds] bf16, ldds = attn_ds_ld(T): the dK/dV kernel writes dS' = P (dP - delta) there and
-    // dQ = dS' . K becomes one streaming GEMM instead of a second recomputation of S and dP (5 products instead of 7)
+    // optional scratch of attn_ds_bytes(): the dK/dV kernel writes dS' = P (dP - delta) there, tile-major
+    // [B*H][128-query tile][64-key tile][128][64] bf16 with ldds = attn_ds_ld(T) key columns, and dQ = dS' . K becomes one
+    // streaming GEMM instead of a second recomputation of S and dP (5 products instead of 7)
     bf16_t* ds; int ldds;
 };
 inline int attn_ds_ld(int T) { return (T + 127) / 128 * 128; }
-inline size_t attn_ds_bytes(int B, int H, int T) { return (size_t)B * H * T * attn_ds_ld(T) * 2; }
+inline size_t attn_ds_bytes(int B, int H, int T) { return (size_t)B * H * ((T + 127) / 128 * 128) * attn_ds_ld(T) * 2; }
 
 int launch_attn_fwd(const AttnArgs& a, int DP, hipStream_t s);
 int launch_attn_delta(const AttnArgs& a, int DP, float* delta, hipStream_t s);

@@ -740,23 +740,23 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
     // STORE: the bf16 dS' that feeds dK also goes to HBM, row-major [query][key], for the dQ GEMM. A lane owns its key
     // column; element j of k-step sx is query row 16 sx + 8 (j >> 2) + 4 h2 + (j & 3) of the 32-query half, so one store
     // instruction writes two query rows x 32 consecutive keys (64 B each). Uniform row base in SGPRs, lane offset fixed.
-    const unsigned ds_lane = STORE ? (unsigned)((4 * h2 * a.ldds + key) * 2) : 0u;
-    const char* ds_bh = STORE ? (const char*)(a.ds + (size_t)(b * a.H + h) * a.T * a.ldds) : nullptr;
+    // Layout: [image, head][128-query tile][64-key tile][128 rows][64 keys]: a block is 16 KB contiguous, so both this
+    // kernel's stores and the GEMM's reads are long runs (row-major [T][T] made every access a 64..128 B piece at a
+    // 3.3 KB stride). This wave's 32 keys lie in one key tile; per 32-query half the 16 stores differ by an immediate.
+    const int nkt_ds = STORE ? a.ldds / 64 : 0, nqt_ds = (a.T + 127) / 128;
+    const int ktile = (rb * 128 + 32 * wave) >> 6;
+    const unsigned ds_lane = STORE ? (unsigned)((4 * h2 * 64 + ((32 * wave + (lane & 31)) & 63)) * 2) : 0u;
+    const char* ds_bh = STORE ? (const char*)(a.ds + ((size_t)(b * a.H + h) * nqt_ds * nkt_ds + ktile) * (128 * 64)) : nullptr;
     const unsigned kmask = kok ? 0xFFFFFFFFu : 0u;  // keys beyond T: zeros (the GEMM multiplies them with clamped K rows)
-    auto store_ds = [&](auto tail_tag, const bf16x8& v, int qt, int hf, int sx) {
-        constexpr bool TAIL = decltype(tail_tag)::value;
+    auto store_ds = [&](const bf16x8& v, int qt, int hf, int sx) {
         u32x4 w = __builtin_bit_cast(u32x4, v);
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] &= kmask;
         const bf16x8 z = __builtin_bit_cast(bf16x8, w);
+        // block of query tile qt >> 1 (TR = 64: two steps per 128-query tile); rows beyond T exist in the block (p = 0 there)
+        char* base = const_cast<char*>(ds_bh) + (size_t)(qt >> 1) * nkt_ds * (128 * 64 * 2) + ((qt & 1) * 64 + 32 * hf) * 128;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int qrow = TR * qt + 32 * hf + 16 * sx + 8 * (j >> 2) + (j & 3);  // wave-uniform part of the row
-            if constexpr (TAIL) {
-                if (qrow + 4 * h2 >= a.T) continue;
-            }
-            *(bf16_t*)(const_cast<char*>(ds_bh) + (size_t)qrow * a.ldds * 2 + ds_lane) = z[j];
-        }
+        for (int j = 0; j < 8; ++j) *(bf16_t*)(base + ds_lane + (16 * sx + 8 * (j >> 2) + (j & 3)) * 128) = z[j];
     };
     auto phase3_k = [&](auto tail_tag, const bf16x8 (&tqf)[2 * G::DB], const f32x16& s, int qt, int hf) {
         const bf16x8 s0 = acc_to_b_pk(s, 0), s1 = acc_to_b_pk(s, 1);
@@ -766,8 +766,8 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
             dk[d] = mfma32(tqf[2 * d + 1], s1, dk[d]);
         }
         if constexpr (STORE) {
-            store_ds(tail_tag, s0, qt, hf, 0);
-            store_ds(tail_tag, s1, qt, hf, 1);
+            store_ds(s0, qt, hf, 0);
+            store_ds(s1, qt, hf, 1);
         }
     };
     // One wave per SIMD issues in order, and an MFMA keeps the issue port only 8 of its 32 cycles: the
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_store_kernel(AttnArgs a) 
 }
 // ... and dQ^T += K^T . dS'^T as a streaming GEMM over it: workgroup = 128 queries of one (image, head), wave = 32 queries,
 // 64-key stages of dS' [128 q][64 k] and K [64 k][DP] by LDS-DMA, double buffered. HBM-bound on reading dS'
-// (2 B per (query, key)): the K tiles come from L2.
+// (2 B per (query, key), stored tile-major so that a stage is one contiguous 16 KB block): the K tiles come from L2.
 template <int DP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
     using G = Geo<DP>;
@@ -901,10 +901,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
     const int h2 = lane >> 5;
     DmaS dmaS;
     DmaK dmaK;
-    dmaS.init(lane, wave, a.ldds);
+    dmaS.init(lane, wave, KT);  // tile-major dS': a (128 q, 64 k) block is 16 KB contiguous, rows 64 elements apart
     dmaK.init(lane, wave, a.ldqkv);
     const bf16_t* kbase = a.qkv + (size_t)b * a.T * a.ldqkv + a.H * DP + h * DP;
-    const bf16_t* sbase = a.ds + (size_t)(b * a.H + h) * a.T * a.ldds;
+    const int nkt = a.ldds / KT, nqt = (a.T + 127) / 128;
+    const bf16_t* sbase = a.ds + ((size_t)(b * a.H + h) * nqt + rb) * nkt * (128 * KT);
     f32x16 dq[G::DB];
 #pragma unroll
     for (int d = 0; d < G::DB; ++d) zero16(dq[d]);
@@ -912,7 +913,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
     const int toff = tr_lane_off(lane, G::RSTR);
     const int nt = a.ldds / KT;  // every key column up to ldds was written (zeros beyond T)
     auto stage = [&](int kt, int buf) {
-        dmaS.issue(sbase + KT * kt, 128 * rb, a.T, sS[buf]);
+        dmaS.issue(sbase + (size_t)kt * (128 * KT), 0, 128, sS[buf]);
         dmaK.issue(kbase, KT * kt, a.T, sK[buf]);
     };
     stage(0, 0);
@@ -957,8 +958,10 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
             if (a.ldds < attn_ds_ld(a.T) || a.ldds % 64) return V1T_ERR_ARG;
             prof_begin(PROF_ATTN_DKV, s);
             hipLaunchKernelGGL((attn_bwd_dkv_store_kernel<DP, DROP>), dim3(n), dim3(256), 0, s, a);
-            hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP>), dim3(n), dim3(256), 0, s, a);
             prof_end(PROF_ATTN_DKV, s);
+            prof_begin(PROF_ATTN_DQ, s);
+            hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP>), dim3(n), dim3(256), 0, s, a);
+            prof_end(PROF_ATTN_DQ, s);
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
     }
