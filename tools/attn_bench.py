@@ -40,19 +40,25 @@ for p in (0.0, 0.2544):
             continue
         avg = ms.value / n.value
         print(f"p={p:<6} {name:8s} {avg * 1e3:8.1f} us  executed {mult * flops_fwd / avg / 1e9:7.1f} TFLOP/s ({n.value} launches)", flush=True)
-# materialised-dS' backward (dK/dV + store, then the dQ GEMM): both launches inside one timed interval
+# materialised-dS' backward: dK/dV + store (profile class 2) and the dQ GEMM (class 1), timed in separate passes
 nb = int(lib.v1t_attention_backward_ws_bytes(B, H, T))
 ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+bw = lambda p: lib.v1t_attention_backward_ws(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, 1, 8,
+                                             delta.data_ptr(), dqkv.data_ptr(), None, ws.data_ptr(), nb, L.stream())
 for p in (0.0, 0.2544):
-    for _ in range(3):
-        lib.v1t_attention_backward_ws(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, 1, 8, delta.data_ptr(), dqkv.data_ptr(), None, ws.data_ptr(), nb, L.stream())
-    torch.cuda.synchronize()
-    L.check(lib.v1t_profile_enable(2, reps + 4))
-    for _ in range(reps):
-        lib.v1t_attention_backward_ws(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, 1, 8, delta.data_ptr(), dqkv.data_ptr(), None, ws.data_ptr(), nb, L.stream())
-    torch.cuda.synchronize()
-    n, ms = C.c_int(), C.c_double()
-    L.check(lib.v1t_profile_read(C.byref(n), C.byref(ms)))
-    avg = ms.value / max(n.value, 1)
-    print(f"p={p:<6} bwd_ds   {avg * 1e3:8.1f} us  algorithmic {2.5 * flops_fwd / avg / 1e9:7.1f} TFLOP/s ({n.value} launches)", flush=True)
+    tot = 0.0
+    for cls, name, mult in ((2, "dkv_store", 2.0), (1, "dq_gemm", 0.5)):
+        for _ in range(3):
+            bw(p)
+        torch.cuda.synchronize()
+        L.check(lib.v1t_profile_enable(cls, reps + 4))
+        for _ in range(reps):
+            bw(p)
+        torch.cuda.synchronize()
+        n, ms = C.c_int(), C.c_double()
+        L.check(lib.v1t_profile_read(C.byref(n), C.byref(ms)))
+        avg = ms.value / max(n.value, 1)
+        tot += avg
+        print(f"p={p:<6} {name:9s} {avg * 1e3:8.1f} us  algorithmic {mult * flops_fwd / avg / 1e9:7.1f} TFLOP/s ({n.value} launches)", flush=True)
+    print(f"p={p:<6} bwd (dS')  {tot * 1e3:8.1f} us  algorithmic {2.5 * flops_fwd / tot / 1e9:7.1f} TFLOP/s", flush=True)
 lib.v1t_profile_enable(-1, 0)

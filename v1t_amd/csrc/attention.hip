@@ -883,21 +883,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_store_kernel(AttnArgs a) 
     __shared__ __attribute__((aligned(16))) BwdLds<DP> lds;
     attn_bwd_dkv_body<DP, DROP, false, true>(a, blockIdx.x, gridDim.x, lds);
 }
-// ... and dQ^T += K^T . dS'^T as a streaming GEMM over it: workgroup = 128 queries of one (image, head), wave = 32 queries,
-// 64-key stages of dS' [128 q][64 k] and K [64 k][DP] by LDS-DMA, double buffered. HBM-bound on reading dS'
-// (2 B per (query, key), stored tile-major so that a stage is one contiguous 16 KB block): the K tiles come from L2.
-template <int DP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
+// ... and dQ^T += K^T . dS'^T as a streaming GEMM over it: workgroup = NW waves x 32 queries of one (image, head),
+// 64-key stages of dS' ((128 q, 64 k) blocks) and K [64 k][DP] by LDS-DMA, double buffered. Bound by reading dS' from HBM
+// (2 B per (query, key), stored tile-major so that a stage reads contiguous 16 KB blocks) plus the K tiles from L2, which every
+// workgroup of an (image, head) re-reads: NW = 8 (256 queries share a K tile) halves that L2 traffic.
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
     using G = Geo<DP>;
-    constexpr int KT = 64, SSTR = KT + 8;
-    using DmaS = TileDma<KT, SSTR, 128, 4>;
-    using DmaK = TileDma<DP, G::RSTR, KT, 4>;
-    __shared__ __attribute__((aligned(16))) bf16_t sS[2][DmaS::LDS_ELEMS];
+    constexpr int KT = 64, SSTR = KT + 8, QB = 32 * NW;
+    using DmaS = TileDma<KT, SSTR, 128, NW>;
+    using DmaK = TileDma<DP, G::RSTR, KT, NW>;
+    __shared__ __attribute__((aligned(16))) bf16_t sS[2][NW / 4][DmaS::LDS_ELEMS];
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][DmaK::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, h, b;
-    decode_block(a, blockIdx.x, gridDim.x, rb, h, b);
-    const int q = rb * 128 + 32 * wave + (lane & 31);
+    decode_block(a, blockIdx.x, gridDim.x, rb, h, b, QB);
+    const int q = rb * QB + 32 * wave + (lane & 31);
     const int h2 = lane >> 5;
     DmaS dmaS;
     DmaK dmaK;
@@ -905,15 +906,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
     dmaK.init(lane, wave, a.ldqkv);
     const bf16_t* kbase = a.qkv + (size_t)b * a.T * a.ldqkv + a.H * DP + h * DP;
     const int nkt = a.ldds / KT, nqt = (a.T + 127) / 128;
-    const bf16_t* sbase = a.ds + ((size_t)(b * a.H + h) * nqt + rb) * nkt * (128 * KT);
+    const int qt0 = rb * (NW / 4);  // first 128-query tile of this workgroup
+    const bf16_t* sbase = a.ds + ((size_t)(b * a.H + h) * nqt + qt0) * nkt * (128 * KT);
+    const bool second = NW == 8 && qt0 + 1 < nqt;  // the last workgroup of an odd tile count has one tile only
     f32x16 dq[G::DB];
 #pragma unroll
     for (int d = 0; d < G::DB; ++d) zero16(dq[d]);
-    const int soff = (32 * wave + (lane & 31)) * SSTR + 4 * h2;
+    const int soff = (32 * (wave & 3) + (lane & 31)) * SSTR + 4 * h2;
     const int toff = tr_lane_off(lane, G::RSTR);
     const int nt = a.ldds / KT;  // every key column up to ldds was written (zeros beyond T)
     auto stage = [&](int kt, int buf) {
-        dmaS.issue(sbase + (size_t)kt * (128 * KT), 0, 128, sS[buf]);
+        dmaS.issue(sbase + (size_t)kt * (128 * KT), 0, 128, sS[buf][0]);
+        if constexpr (NW == 8) {
+            if (second) dmaS.issue(sbase + ((size_t)nkt + kt) * (128 * KT), 0, 128, sS[buf][1]);
+        }
         dmaK.issue(kbase, KT * kt, a.T, sK[buf]);
     };
     stage(0, 0);
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
     for (int kt = 0; kt < nt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nt) stage(kt + 1, buf ^ 1);
-        const bf16_t* sp = &sS[buf][soff];
+        const bf16_t* sp = &sS[buf][wave >> 2][soff];
         const bf16_t* tk = &sK[buf][toff];
 #pragma unroll
         for (int ks = 0; ks < KT / 16; ++ks) {
@@ -960,7 +966,9 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((attn_bwd_dkv_store_kernel<DP, DROP>), dim3(n), dim3(256), 0, s, a);
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
-            hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP>), dim3(n), dim3(256), 0, s, a);
+            static const int nw = std::getenv("V1T_DQ_NW") ? atoi(std::getenv("V1T_DQ_NW")) : 8;  // dev switch
+            if (nw == 4) hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP, 4>), dim3(n), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP, 8>), dim3(((a.T + 255) / 256) * a.H * a.B), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DQ, s);
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
