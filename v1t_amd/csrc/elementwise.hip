@@ -382,9 +382,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
 
 // LayerNorm backward + residual add + (optional) token-sum for the injection gradient +
 // (optional) dropout-backward/cast of the result for the next branch and its bias gradient.
-// Workgroup = 64 rows of one image (two 8-row steps per wave); column partials stay in registers across rows and
+// Workgroup = LNB_ROWS rows of one image (LNB_ROWS / 32 8-row steps per wave); column partials stay in registers across rows and
 // are summed over the 8 row slots of a wave with lane swaps, over the waves through LDS, one atomic per column per WG.
-constexpr int LNB_ROWS = 64;
+constexpr int LNB_ROWS = 128;  // 64: 29.0 us, 96: 28.8, 128: 25.5, 256: 31.5 (default shape; fewer column-reduction tails vs. workgroups in flight)
 DEVFN float rowslot_sum(float v) {  // sum over the 8 row slots (lane bits 3, 4, 5); valid in lanes 0..7
     v = dpp_add<0x128, 0xF>(v);  // row_ror:8 -> lane l += lane l ^ 8
     {
