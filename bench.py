@@ -147,13 +147,18 @@ def main():
         fused = os.environ.get("V1T_ATTN_BWD_DS", "1") == "0"
         names = {0: "attn_fwd", 1: "attn_bwd_dq_gemm (dQ = dS' . K)", 2: "attn_bwd_fused (dQ + dK/dV bodies)" if fused else "attn_bwd_dkv_store (dK/dV + dS')"}
         mult = {0: 1.0, 1: 0.5, 2: 2.5 if fused else 2.0}[a.profile_class] if a.profile_class in (0, 1, 2) else 0.0
-        per_launch = mult * fl["attn_fwd_per_image_block"] * args.batch_size
+        # images per launch: the trainer runs the shared core over all local mouse-batches at once (one launch per block)
+        units = sharding.local_units()
+        per_rank = sum(args.batch_size if sl is None else (sl.stop - sl.start) for _, sl in units)
+        imgs_launch = min(per_rank, trainer.core_group * args.batch_size) if (trainer.batch_core and len(units) > 1) else args.batch_size
+        per_launch = mult * fl["attn_fwd_per_image_block"] * imgs_launch
         # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, KiB, separate --pmc
         # passes: profiles/r01_pmc_attention_fetch_write.txt, tools/pmc_attn.sh); recorded, not collected live, and
         # only valid for the shape it was measured on (16 images x 4 heads x 1654 tokens x 160 padded head dim)
         default_shape = args.batch_size == 16 and a.neurons == 8000
         traffic = {0: PMC_KIB["attn_fwd"], 1: PMC_KIB["attn_bwd_dq_gemm"], 2: PMC_KIB["attn_bwd_fused" if fused else "attn_bwd_dkv_store"]}.get(a.profile_class)
-        traffic = (2 * traffic[0] + traffic[1]) * 1024 if (default_shape and traffic) else None
+        # (measured per 16-image launch; the kernels' traffic is proportional to the images of a launch)
+        traffic = (2 * traffic[0] + traffic[1]) * 1024 * imgs_launch / 16 if (default_shape and traffic) else None
         avg_ms = total_ms.value / max(launches.value, 1)
         achieved = per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         line = {

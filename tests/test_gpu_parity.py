@@ -464,3 +464,55 @@ def test_attention_rollout_vs_oracle_default_size(dev):
     for i in range(2):
         ref = O.attention_rollout_row(attn[i])
         assert rel_to_max(rows[i].cpu().numpy(), ref.numpy()) < 3e-3
+
+
+def test_core_batched_over_mice_equals_per_mouse(dev):
+    """Model.forward_mice (one pass of the shared core over the concatenated mouse-batches, ragged sizes) == one
+    Model.forward per mouse: predictions bit-identical rows, gradients equal up to the summation order of the atomics."""
+    from v1t_amd.losses import elu1_poisson_loss
+
+    cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B", "C"), num_neurons={"A": 96, "B": 50, "C": 130})
+    sd = W.make_state_dict(cfg, 9)
+    model, _ = build_native_model(cfg, sd, dev)
+    model.train(False)
+    pairs = [(m, {k: v.to(dev) for k, v in W.make_batch(cfg, m, n, 9).items()}) for m, n in (("A", 3), ("B", 5), ("C", 2))]
+
+    def grads():
+        g = {"core": model.core._arena.grad.clone()}
+        for m in cfg.mouse_ids:
+            g[m] = model.mouse_arena(m).grad.clone()
+        return g
+
+    def zero():
+        model.core.prepare()
+        model.core._arena.attach_grads()
+        model.core._arena.grad.zero_()
+        for m in cfg.mouse_ids:
+            a = model.mouse_arena(m)
+            a.attach_grads()
+            a.grad.zero_()
+
+    zero()
+    ys = []
+    for m, b in pairs:
+        u = model(inputs=b["image"], mouse_id=m, behaviors=b["behavior"], pupil_centers=b["pupil_center"], activate=False)[0]
+        loss, y = elu1_poisson_loss(u, b["response"], 4500.0, b["image"].shape[0])
+        loss.backward()
+        ys.append(y.detach().clone())
+    ref = grads()
+    zero()
+    us = model.forward_mice(pairs, activate=False)
+    losses, ys2 = [], []
+    for (m, b), u in zip(pairs, us):
+        loss, y = elu1_poisson_loss(u, b["response"], 4500.0, b["image"].shape[0])
+        losses.append(loss)
+        ys2.append(y.detach().clone())
+    torch.stack(losses).sum().backward()
+    got = grads()
+    for a, b_ in zip(ys, ys2):
+        assert torch.equal(a, b_)  # eval mode: no dropout, rows independent of the rest of the batch
+    for k in ref:
+        assert rel_to_max(got[k], ref[k]) < 2e-3, k
+    model.core.behavior_mode = 4
+    with pytest.raises(NotImplementedError):
+        model.core.forward_many([b["image"] for _, b in pairs], [m for m, _ in pairs], [b["behavior"] for _, b in pairs], [b["pupil_center"] for _, b in pairs])

@@ -137,6 +137,29 @@ class _VitFn(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
+class _SplitFn(torch.autograd.Function):
+    """Batch slices of the concatenated core output as separate autograd outputs; the backward gathers the slices'
+    gradients into one buffer so that the core runs ONE backward for all of them."""
+
+    @staticmethod
+    def forward(ctx, tokens, *sizes):
+        ctx.sizes, ctx.meta = sizes, (tokens.shape, tokens.dtype, tokens.device)
+        return tuple(tokens.split(list(sizes), dim=0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape, dtype, device = ctx.meta
+        g = torch.empty(shape, dtype=dtype, device=device)
+        o = 0
+        for n, gi in zip(ctx.sizes, grads):
+            if gi is None:
+                g[o:o + n].zero_()
+            else:
+                g[o:o + n].copy_(gi)
+            o += n
+        return (g,) + (None,) * len(ctx.sizes)
+
+
 class _L1Fn(torch.autograd.Function):
     """scale * sum|p| over a flat arena; backward adds scale * sign(p) into the gradient arena."""
 
@@ -360,13 +383,27 @@ class ViTCore(Core):
         need_bwd = (torch.is_grad_enabled() and self._anchor.requires_grad) or keep_workspace
         return _VitFn.apply(self, inputs, beh, midx, self._anchor, need_bwd)
 
-    def forward(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor):
-        tokens = self.forward_tokens(inputs, mouse_id, behaviors, pupil_centers)
+    def tokens_to_output(self, tokens: torch.Tensor) -> torch.Tensor:
         c, h, w = self.output_shape
         # (B, C', h, w) exactly like vit.py:434-435, as a zero-copy strided view of the token-major buffer
         out = tokens[:, 1:, :c].unflatten(1, (h, w)).permute(0, 3, 1, 2)
         out._v1t_tokens = tokens  # lets the native readout skip the view chain (and its backward kernels)
         return out
+
+    def forward(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor):
+        return self.tokens_to_output(self.forward_tokens(inputs, mouse_id, behaviors, pupil_centers))
+
+    def forward_many(self, inputs: t.Sequence[torch.Tensor], mouse_ids: t.Sequence[str], behaviors: t.Sequence[torch.Tensor],
+                     pupil_centers: t.Sequence[torch.Tensor]) -> t.List[torch.Tensor]:
+        """The shared core over several mouse-batches in ONE pass (the core does not depend on the mouse unless
+        behavior_mode == 4): same outputs as one `forward` per batch, but every kernel sees the concatenated batch, which
+        is what fills 256 CUs evenly (one 16-image batch is 3.25 rounds of attention-backward workgroups, i.e. 4)."""
+        if self.behavior_mode == 4 and len(set(mouse_ids)) > 1:
+            raise NotImplementedError("behavior_mode 4 has one BehaviorMLP per mouse: run the mice one by one")
+        sizes = [int(x.shape[0]) for x in inputs]
+        tokens = self.forward_tokens(torch.cat(list(inputs)), mouse_ids[0], torch.cat(list(behaviors)), torch.cat(list(pupil_centers)))
+        parts = _SplitFn.apply(tokens, *sizes) if len(sizes) > 1 else (tokens,)
+        return [self.tokens_to_output(p_) for p_ in parts]
 
     def workspace_tensor(self, name: str, block: int = 0) -> torch.Tensor:
         """Debug / test access to an intermediate of the LAST forward (see v1t_vit_workspace_offset)."""

@@ -851,12 +851,27 @@ int launch_bmlp_fwd(const BmlpArgs& a, hipStream_t s) {
     return ok();
 }
 
-int launch_bmlp_bwd(const BmlpBatch& bb, hipStream_t s) {
-    if (bb.n <= 0) return V1T_OK;
-    const BmlpArgs& a = bb.blk[0];
-    const size_t smem = sizeof(float) * (size_t)a.B * (a.D + a.J);
-    if (smem > 64 * 1024 || bb.n > BMLP_MAX_BLOCKS) return V1T_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bmlp_bwd_kernel, dim3(BMLP_SPLIT, bb.n), dim3(256), smem, s, bb);
+int launch_bmlp_bwd(const BmlpBatch& bb0, hipStream_t s) {
+    if (bb0.n <= 0) return V1T_OK;
+    if (bb0.n > BMLP_MAX_BLOCKS) return V1T_ERR_UNSUPPORTED;
+    // the kernel keeps d(pre-activations) of its samples in LDS: batches larger than fit in 64 KB go in several launches
+    // (the parameter gradients accumulate with +=, one writer per element)
+    const int per = (int)std::max<size_t>(1, (64 * 1024) / (sizeof(float) * (size_t)(bb0.blk[0].D + bb0.blk[0].J)));
+    const int B = bb0.blk[0].B;
+    for (int b0 = 0; b0 < B; b0 += per) {
+        BmlpBatch bb = bb0;
+        const int nb = std::min(per, B - b0);
+        for (int k = 0; k < bb.n; ++k) {
+            BmlpArgs& a = bb.blk[k];
+            a.B = nb;
+            a.v += (size_t)b0 * a.IN;
+            a.hid += (size_t)b0 * a.J;
+            a.out += (size_t)b0 * a.DP;
+            a.dout += (size_t)b0 * a.DP;
+        }
+        const size_t smem = sizeof(float) * (size_t)nb * (bb.blk[0].D + bb.blk[0].J);
+        hipLaunchKernelGGL(bmlp_bwd_kernel, dim3(BMLP_SPLIT, bb.n), dim3(256), smem, s, bb);
+    }
     return ok();
 }
 

@@ -271,6 +271,18 @@ class Model(nn.Module):
             outputs = self.elu1(outputs)
         return outputs, images, image_grids
 
+    def forward_mice(self, batches: t.Sequence[t.Tuple[str, t.Dict[str, torch.Tensor]]], activate: bool = True) -> t.List[torch.Tensor]:
+        """`forward` for several (mouse_id, batch) pairs with ONE pass through the shared core (ViTCore.forward_many);
+        cropper, shifter and readout stay per mouse. Returns the per-pair outputs in order."""
+        images = [self.image_cropper(b["image"], mouse_id=m, behaviors=b["behavior"], pupil_centers=b["pupil_center"])[0] for m, b in batches]
+        zs = self.core.forward_many(images, [m for m, _ in batches], [b["behavior"] for _, b in batches], [b["pupil_center"] for _, b in batches])
+        outs = []
+        for (m, b), z in zip(batches, zs):
+            shifts = self.core_shifter(b["pupil_center"], mouse_id=m) if self.core_shifter is not None else None
+            y = self.readouts(z, mouse_id=m, shifts=shifts)
+            outs.append(self.elu1(y) if activate else y)
+        return outs
+
     # ------------------------------------------------------------------ flat per-mouse arenas (fused optimizer / DDP)
     def mouse_arena(self, mouse_id: str) -> FlatArena:
         """All per-mouse parameters (readout + core shifter + image shifter) in one flat arena; `features` first, in

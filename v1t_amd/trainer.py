@@ -13,6 +13,7 @@ MI355X-first differences (same math):
 """
 from __future__ import annotations
 
+import os
 import typing as t
 
 import torch
@@ -117,6 +118,10 @@ class Trainer:
         self.opt.bind(model, self.core_lr)
         self.batch_size = args.batch_size
         self._core_l1: t.Optional[float] = None
+        # V1T_TRAINER_PER_MOUSE=1 (dev): one core pass per mouse-batch, as the reference's loop does, instead of one pass
+        # over the concatenated local batches
+        self.core_group = int(os.environ.get("V1T_CORE_GROUP", "7"))
+        self.batch_core = self.core_group > 1
 
     def train_step(self, batches: t.Dict[str, t.Dict[str, torch.Tensor]]) -> t.Dict[str, torch.Tensor]:
         """batches: mouse_id -> full batch (image, behavior, pupil_center, response) on the device.
@@ -126,16 +131,29 @@ class Trainer:
         core = model.core
         core.prepare()
         losses = []
+        units = []
         for mouse_id, sl in self.sharding.local_units():
             b = batches[mouse_id]
             full = b["image"].shape[0]
             if sl is not None:
                 b = {k: v[sl] for k, v in b.items()}
             model.mouse_arena(mouse_id).attach_grads()
-            u, _, _ = model(inputs=b["image"], mouse_id=mouse_id, behaviors=b["behavior"], pupil_centers=b["pupil_center"], activate=False)
-            loss, _ = elu1_poisson_loss(u, b["response"], self.ds_sizes[mouse_id], full)
-            loss.backward()
-            losses.append(loss.detach())
+            units.append((mouse_id, b, full))
+        if self.core_group > 1 and len(units) > 1 and core.behavior_mode != 4:
+            # groups of local mouse-batches through the shared core in one pass, one backward per group (gradients sum as
+            # train.py:97-111)
+            for i in range(0, len(units), self.core_group):
+                grp = units[i:i + self.core_group]
+                us = model.forward_mice([(m, b) for m, b, _ in grp], activate=False)
+                ls = [elu1_poisson_loss(u, b["response"], self.ds_sizes[m], full)[0] for (m, b, full), u in zip(grp, us)]
+                (torch.stack(ls).sum() if len(ls) > 1 else ls[0]).backward()
+                losses += [l_.detach() for l_ in ls]
+        else:
+            for mouse_id, b, full in units:
+                u, _, _ = model(inputs=b["image"], mouse_id=mouse_id, behaviors=b["behavior"], pupil_centers=b["pupil_center"], activate=False)
+                loss, _ = elu1_poisson_loss(u, b["response"], self.ds_sizes[mouse_id], full)
+                loss.backward()
+                losses.append(loss.detach())
         self.sharding.reduce_core(core._arena)
         for mouse_id in self.sharding.shared_mice():
             self.sharding.reduce_mouse(mouse_id, model.mouse_arena(mouse_id))
