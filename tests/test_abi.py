@@ -122,6 +122,8 @@ def test_mouse_sharding_assignment():
                 seen[m] += 16 if sl is None else len(range(16)[sl])
         assert all(v == 16 for v in seen.values()), (world, seen)
     s8 = MouseSharding(ids, rank=7, world=8, make_groups=False)
-    assert s8.local_units() == [("G", slice(8, 16))] and s8.shared_mice() == ["G"]  # 8th rank replicates the last mouse
+    assert s8.local_units() == [("G", slice(2, 16))] and s8.shared_mice() == ["G"]  # 14 images per rank: the core is batched over pieces
+    s81 = MouseSharding(ids, rank=1, world=8, make_groups=False)
+    assert s81.local_units() == [("A", slice(14, 16)), ("B", slice(0, 12))] and s81.owners["A"] == [0, 1]
     s2 = MouseSharding(ids, rank=1, world=2, make_groups=False)
     assert s2.local_units() == [("D", slice(8, 16)), ("E", None), ("F", None), ("G", None)]  # 3.5 mice per rank

@@ -70,22 +70,31 @@ def test_two_ranks_seven_mice():
 
 
 def test_three_ranks_one_mouse_cut():
-    # 7 mice on 3 ranks: 40 / 40 / 32 images, mouse C cut 8 + 8 across ranks 0 and 1 (its arena reduced in that 2-rank group)
+    # 7 mice on 3 ranks: 38 / 38 / 36 images, mice C and E cut across neighbouring ranks (their arenas reduced in 2-rank groups)
     loads = []
     for r in range(3):
         sh = MouseSharding(list("ABCDEFG"), rank=r, world=3, batch_size=16, make_groups=False)
         loads.append(sum(16 if sl is None else sl.stop - sl.start for _, sl in sh.local_units()))
-    assert loads == [40, 40, 32]
+    assert loads == [38, 38, 36]
     _run(3, list("ABCDEFG"))
 
 
-def test_four_ranks_whole_mice():
-    # on 4 ranks cutting does not pay (a piece costs ~6.6 images of fixed work: 3 pieces of 28 images lose to 2 whole mice)
-    loads = []
-    for r in range(4):
-        sh = MouseSharding(list("ABCDEFG"), rank=r, world=4, batch_size=16, make_groups=False)
-        loads.append(sum(16 if sl is None else sl.stop - sl.start for _, sl in sh.local_units()))
-    assert loads == [32, 32, 32, 16]
+def test_four_and_eight_ranks_balanced_images():
+    # a rank runs the shared core once over all its pieces, so what counts is its image total: 28 each on 4 ranks
+    # (quarters of a mouse-batch), 14 each on 8 (eighths); every mouse keeps its 16 images
+    for world, want in ((4, 28), (8, 14)):
+        loads, seen = [], {}
+        for r in range(world):
+            sh = MouseSharding(list("ABCDEFG"), rank=r, world=world, batch_size=16, make_groups=False)
+            loads.append(sum(16 if sl is None else sl.stop - sl.start for _, sl in sh.local_units()))
+            for m, sl in sh.local_units():
+                seen.setdefault(m, []).extend(range(16)[sl] if sl is not None else range(16))
+        assert loads == [want] * world
+        assert all(sorted(v) == list(range(16)) for v in seen.values()) and len(seen) == 7
+
+
+def test_four_ranks_three_cut_mice_collectives():
+    _run(4, list("ABCDEFG"))  # B, D and F are shared by neighbouring ranks: three 2-rank groups + the core all-reduce
 
 
 def test_two_ranks_balanced_halves():
@@ -98,3 +107,7 @@ def test_two_ranks_balanced_halves():
 
 def test_replica_rank_shares_a_mouse():
     _run(2, ["A"])  # world > n_mice: both ranks own mouse A and split its batch 8 + 8
+
+
+def test_eight_ranks_every_mouse_cut_collectives():
+    _run(8, list("ABCDEFG"))  # 14 images per rank: all seven mice shared by neighbouring ranks (seven 2-rank groups)

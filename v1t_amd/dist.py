@@ -17,7 +17,7 @@ import torch.distributed as dist
 
 
 class MouseSharding:
-    PIECE_COST = 6.6  # images; see cost() below
+    PIECE_COST = 1.0  # images; see cost() below
 
     def __init__(self, mouse_ids: t.Sequence[str], rank: int = 0, world: int = 1, batch_size: int = 16, make_groups: bool = True):
         self.mouse_ids = list(mouse_ids)
@@ -29,11 +29,11 @@ class MouseSharding:
         self.slices: t.Dict[str, t.Dict[int, t.Optional[slice]]] = {m: {} for m in self.mouse_ids}
         plan = None
         if world <= 2 * n:
-            # balanced dealing: every mouse-batch is cut into g equal parts (g = 1, 2 or 4: the smallest that gives the
+            # balanced dealing: every mouse-batch is cut into g equal parts (g = 1, 2, 4 or 8: the smallest that gives the
             # smallest maximum load), and the n*g parts are dealt to the ranks in order, as evenly as possible
-            # (7 mice: 3.5 + 3.5 on 2 ranks instead of 4 + 3; 28 images each on 4 ranks instead of 32/32/32/16; one
-            # mouse each on 8 ranks with the last one split 8 + 8). A mouse dealt to two ranks is shared: each runs
-            # its part of the batch and the mouse's arena is all-reduced inside that 2-rank group.
+            # (7 mice x 16 images: 56 + 56 on 2 ranks instead of 4 + 3 mice; 28 images each on 4 ranks instead of
+            # 32/32/32/16; 14 images each on 8 ranks). A mouse dealt to several ranks is shared: each runs its part of the
+            # batch and the mouse's arena is all-reduced inside the group of its owners.
             def deal(g):
                 units = n * g
                 quota = [units // world + (1 if r < units % world else 0) for r in range(world)]
@@ -49,9 +49,12 @@ class MouseSharding:
                 return plan_
 
             def cost(plan_, g):
-                # step time of the most loaded rank in image-equivalents: a piece of a mouse-batch costs its images plus
-                # PIECE_COST for what does not shrink with the batch (readout optimizer step, neuron-indexed kernels,
-                # launch-bound small kernels; measured with tools/sim_scaling.py: 16 images 6.0 ms, 8 images 3.9 ms)
+                # step time of the most loaded rank in image-equivalents. A rank runs the shared core ONCE over all its
+                # pieces (Trainer / Model.forward_mice), so its time is ~1.2 ms + 0.245 ms per image whatever the cut
+                # (tools/sim_scaling.py: 16 images 5.1 ms, 32: 9.0, 56: 15.1, 112: 28.7; a rank with two 8-image pieces
+                # of different mice fits the same line); a piece adds its readout launches and, for a cut mouse, one small
+                # all-reduce: ~0.25 ms = PIECE_COST of one image. (Before the core was batched over a rank's pieces
+                # every piece paid ~6.6 images of fixed work and whole mice won on 4 ranks.)
                 per = batch_size // g
                 load = [0.0] * world
                 for m in self.mouse_ids:
@@ -60,7 +63,7 @@ class MouseSharding:
                 return max(load), sum(1 for x in load if x == 0.0)
 
             best = None
-            for g in (1, 2, 4):
+            for g in (1, 2, 4, 8):
                 if batch_size % g:
                     continue
                 plan_ = deal(g)
