@@ -118,8 +118,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
     constexpr int B_CHUNKS = BN * KC;                 // 16-B chunks in a B tile
     constexpr int B_ITERS = (B_CHUNKS + NT - 1) / NT;
     static_assert(NW == 4 || (EPI != EPI_BIAS_GELU && EPI != EPI_DGELU), "fragment-order buffers assume 128-row tiles");
-    __shared__ __attribute__((aligned(16))) bf16_t sA[2][BM * LS];
-    __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LS];
+    // one allocation: the operand tiles (sA, sB) and, after the K loop, the bf16 output staging of EPI_BF16
+    constexpr int CS = BN + 8;  // staging row stride (elements): 16-B aligned rows, odd multiple of 16 B
+    constexpr int SMEM = (2 * BM * LS + 2 * BN * LS) > (BM * CS) ? (2 * BM * LS + 2 * BN * LS) : (BM * CS);
+    __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
+    bf16_t (*sA)[BM * LS] = (bf16_t (*)[BM * LS])smem;
+    bf16_t (*sB)[BN * LS] = (bf16_t (*)[BN * LS])(smem + 2 * BM * LS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntn = g.N / BN;
@@ -196,7 +200,30 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
         __syncthreads();
     }
 
-    gemm_epilogue<NBLK, EPI>(g, acc, resv, m0, n0, wave, lane);
+    if constexpr (EPI == EPI_BF16) {
+        // bf16 output through LDS: a lane holds one column of 16 rows per block, i.e. 2-byte global stores that fill
+        // 64 B of two rows per instruction; staged [32 rows][BN] per wave and written back as 16-B chunks, an instruction
+        // covers 1 KB of consecutive row segments (QKV: 101 MB of output per 16 images, the GEMM was bound by these stores)
+        __syncthreads();  // every wave is done with the operand tiles
+        bf16_t* st = smem + wave * 32 * CS;
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[acc_row(r, lane) * CS + 32 * nb + (lane & 31)] = (bf16_t)acc[nb][r];
+        constexpr int CPR = BN / 8;  // 16-B chunks per row
+        bf16_t* C = (bf16_t*)g.C;
+#pragma unroll
+        for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < 32 * CPR) {
+                const int row = c / CPR, ch = c % CPR;
+                const int grow = m0 + 32 * wave + row;
+                if (grow < g.M) *(u32x4*)(C + (size_t)grow * g.ldc + n0 + 8 * ch) = *(const u32x4*)(st + row * CS + 8 * ch);
+            }
+        }
+    } else {
+        gemm_epilogue<NBLK, EPI>(g, acc, resv, m0, n0, wave, lane);
+    }
 }
 
 
@@ -624,6 +651,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTNArgs g, int gx, in
 
 int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 != 0 || a.N % 32 != 0 || (a.lda % 8) || (a.ldb % 8)) return V1T_ERR_ARG;
+    if (epi == EPI_BF16 && !a.A_lo && (a.ldc % 8)) return V1T_ERR_ARG;  // 16-B output chunks
     if (a.N % 160 == 0) return launch_nt_n<5>(a, epi, s);
     if (a.N % 128 == 0) return launch_nt_n<4>(a, epi, s);
     if (a.N % 64 == 0) return launch_nt_n<2>(a, epi, s);
