@@ -17,7 +17,9 @@ DEVFN size_t frag_index(const GemmNTArgs& g, int m0, int n0, int nb, int wave, i
     return ((((size_t)(m0 / FRAG_BM) * (g.N / 32) + (n0 / 32 + nb)) * 4 + wave) * 64 + lane) * 16;
 }
 
-template <int NBLK, int EPI>
+// STAGED (EPI_BIAS_GELU): the activation is left in `acc` (fp32) for the caller's LDS-staged stores instead of being
+// written with 2-byte stores here.
+template <int NBLK, int EPI, bool STAGED = false>
 DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 (&resv)[NBLK], int m0, int n0, int wave, int lane) {
     // ---- epilogue: col = n0 + 32nb + (lane&31); row = m0 + 32wave + acc_row(r, lane)
     const int rbase = m0 + 32 * wave;
@@ -75,7 +77,9 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
                 float a = v * cdf;
                 if (g.drop.thresh) a = drop_keep(g.drop.key, row, col, g.drop.thresh) ? a * g.drop.inv_keep : 0.f;
                 if (r < 8) gp0[r & 7] = (bf16_t)(ok ? gp : 0.f); else gp1[r & 7] = (bf16_t)(ok ? gp : 0.f);
-                if (ok) {
+                if constexpr (STAGED) {
+                    acc[nb][r] = a;
+                } else if (ok) {
                     const bf16_t ah = (bf16_t)a;
                     g.C2[(size_t)row * g.ldc2 + col] = ah;
                     if (g.C2_lo) g.C2_lo[(size_t)row * g.ldc2 + col] = aux_plane(a, ah, g.f16);
@@ -200,26 +204,37 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
         __syncthreads();
     }
 
-    if constexpr (EPI == EPI_BF16) {
-        // bf16 output through LDS: a lane holds one column of 16 rows per block, i.e. 2-byte global stores that fill
-        // 64 B of two rows per instruction; staged [32 rows][BN] per wave and written back as 16-B chunks, an instruction
-        // covers 1 KB of consecutive row segments (QKV: 101 MB of output per 16 images, the GEMM was bound by these stores)
-        __syncthreads();  // every wave is done with the operand tiles
+    // 16-bit outputs go through LDS: a lane holds one column of 16 rows per block, i.e. 2-byte global stores that fill
+    // 64 B of two rows per instruction; staged [32 rows][BN] per wave (wave-private, no barrier) and written back as 16-B
+    // chunks, an instruction covers 1 KB of consecutive row segments (QKV: 101 MB of output per 16 images; the GEMM was
+    // bound by these stores)
+    auto staged_store = [&](bf16_t* dst, int ld, auto conv) {
         bf16_t* st = smem + wave * 32 * CS;
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[acc_row(r, lane) * CS + 32 * nb + (lane & 31)] = (bf16_t)acc[nb][r];
+            for (int r = 0; r < 16; ++r) st[acc_row(r, lane) * CS + 32 * nb + (lane & 31)] = conv(acc[nb][r]);
         constexpr int CPR = BN / 8;  // 16-B chunks per row
-        bf16_t* C = (bf16_t*)g.C;
 #pragma unroll
         for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
             const int c = c0 + lane;
             if (c < 32 * CPR) {
                 const int row = c / CPR, ch = c % CPR;
                 const int grow = m0 + 32 * wave + row;
-                if (grow < g.M) *(u32x4*)(C + (size_t)grow * g.ldc + n0 + 8 * ch) = *(const u32x4*)(st + row * CS + 8 * ch);
+                if (grow < g.M) *(u32x4*)(dst + (size_t)grow * ld + n0 + 8 * ch) = *(const u32x4*)(st + row * CS + 8 * ch);
             }
+        }
+    };
+    if constexpr (EPI == EPI_BF16) {
+        __syncthreads();  // every wave is done with the operand tiles
+        staged_store((bf16_t*)g.C, g.ldc, [](float v) { return (bf16_t)v; });
+    } else if constexpr (EPI == EPI_BIAS_GELU) {
+        gemm_epilogue<NBLK, EPI, true>(g, acc, resv, m0, n0, wave, lane);  // gelu' (fragment order) written, activation left in acc
+        __syncthreads();
+        staged_store(g.C2, g.ldc2, [](float v) { return (bf16_t)v; });
+        if (g.C2_lo) {
+            const int f16 = g.f16;
+            staged_store(g.C2_lo, g.ldc2, [f16](float v) { return aux_plane(v, (bf16_t)v, f16); });
         }
     } else {
         gemm_epilogue<NBLK, EPI>(g, acc, resv, m0, n0, wave, lane);
@@ -652,6 +667,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTNArgs g, int gx, in
 int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 != 0 || a.N % 32 != 0 || (a.lda % 8) || (a.ldb % 8)) return V1T_ERR_ARG;
     if (epi == EPI_BF16 && !a.A_lo && (a.ldc % 8)) return V1T_ERR_ARG;  // 16-B output chunks
+    if (epi == EPI_BIAS_GELU && !a.A_lo && (a.ldc2 % 8)) return V1T_ERR_ARG;
     if (a.N % 160 == 0) return launch_nt_n<5>(a, epi, s);
     if (a.N % 128 == 0) return launch_nt_n<4>(a, epi, s);
     if (a.N % 64 == 0) return launch_nt_n<2>(a, epi, s);
