@@ -8,6 +8,8 @@ tensor plumbing and run as torch ops; everything between core input and readout 
 """
 from __future__ import annotations
 
+import contextlib
+import os
 import typing as t
 
 import torch
@@ -232,6 +234,11 @@ class Model(nn.Module):
         self.elu1 = ELU1()
         self._mouse_arenas: t.Dict[str, FlatArena] = {}
         self._mouse_l1: t.Dict[str, t.Tuple[int, t.List[t.Tuple[int, int, float]]]] = {}
+        self._streams: t.List[t.Any] = []
+        self.readout_streams = os.environ.get("V1T_READOUT_STREAMS", "1") != "0"
+        if self.readout_streams and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            # parameters used on a mouse's side stream accumulate their gradient there: intended (see forward_mice)
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
     @property
     def device(self) -> torch.device:
@@ -277,11 +284,36 @@ class Model(nn.Module):
         images = [self.image_cropper(b["image"], mouse_id=m, behaviors=b["behavior"], pupil_centers=b["pupil_center"])[0] for m, b in batches]
         zs = self.core.forward_many(images, [m for m, _ in batches], [b["behavior"] for _, b in batches], [b["pupil_center"] for _, b in batches])
         outs = []
-        for (m, b), z in zip(batches, zs):
-            shifts = self.core_shifter(b["pupil_center"], mouse_id=m) if self.core_shifter is not None else None
-            y = self.readouts(z, mouse_id=m, shifts=shifts)
-            outs.append(self.elu1(y) if activate else y)
+        # the per-mouse tails (shifter, grid, readout, later the loss and their backward) are chains of small latency-bound
+        # kernels that do not depend on each other across mice: one side stream per mouse lets them overlap. Autograd
+        # runs each node's backward on the stream its forward ran on and orders streams at the graph edges.
+        streams = self._side_streams(len(batches)) if (self.readout_streams and len(batches) > 1 and zs[0].is_cuda) else None
+        main = torch.cuda.current_stream() if streams else None
+        for i, ((m, b), z) in enumerate(zip(batches, zs)):
+            if streams:
+                streams[i].wait_stream(main)
+                ctx = torch.cuda.stream(streams[i])
+            else:
+                ctx = contextlib.nullcontext()
+            with ctx:
+                shifts = self.core_shifter(b["pupil_center"], mouse_id=m) if self.core_shifter is not None else None
+                y = self.readouts(z, mouse_id=m, shifts=shifts)
+                outs.append(self.elu1(y) if activate else y)
+        self._last_streams = streams
         return outs
+
+    def _side_streams(self, n: int):
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream())
+        return self._streams[:n]
+
+    def join_streams(self) -> None:
+        """Make the current stream wait for the side streams of the last forward_mice (call before using its outputs
+        on the current stream)."""
+        if getattr(self, "_last_streams", None):
+            cur = torch.cuda.current_stream()
+            for s_ in self._last_streams:
+                cur.wait_stream(s_)
 
     # ------------------------------------------------------------------ flat per-mouse arenas (fused optimizer / DDP)
     def mouse_arena(self, mouse_id: str) -> FlatArena:

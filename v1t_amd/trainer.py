@@ -13,6 +13,7 @@ MI355X-first differences (same math):
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import typing as t
 
@@ -145,7 +146,14 @@ class Trainer:
             for i in range(0, len(units), self.core_group):
                 grp = units[i:i + self.core_group]
                 us = model.forward_mice([(m, b) for m, b, _ in grp], activate=False)
-                ls = [elu1_poisson_loss(u, b["response"], self.ds_sizes[m], full)[0] for (m, b, full), u in zip(grp, us)]
+                st = getattr(model, "_last_streams", None)
+                ls = []
+                for i, ((m, b, full), u) in enumerate(zip(grp, us)):
+                    with (torch.cuda.stream(st[i]) if st else contextlib.nullcontext()):  # the loss stays on the mouse's stream
+                        ls.append(elu1_poisson_loss(u, b["response"], self.ds_sizes[m], full)[0])
+                    if st:
+                        ls[-1].record_stream(torch.cuda.current_stream())  # summed on the main stream below
+                model.join_streams()
                 (torch.stack(ls).sum() if len(ls) > 1 else ls[0]).backward()
                 losses += [l_.detach() for l_ in ls]
         else:
