@@ -155,6 +155,7 @@ class Trainer:
                         ls[-1].record_stream(torch.cuda.current_stream())  # summed on the main stream below
                 model.join_streams()
                 (torch.stack(ls).sum() if len(ls) > 1 else ls[0]).backward()
+                model.join_streams()  # the readout backward kernels wrote into the mouse arenas on their side streams
                 losses += [l_.detach() for l_ in ls]
         else:
             for mouse_id, b, full in units:
