@@ -389,9 +389,12 @@ int launch_nt_nw(const GemmNTArgs& a, int epi, hipStream_t s) {
 }
 template <int NBLK>
 int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
-    // K-tile 64 where K allows: 128 B (a whole line) of every A row per tile instead of 64 B and half the barriers
+    // K-tile 64 where K allows: 128 B (a whole line) of every A row per tile instead of 64 B and half the barriers - but
+    // its 83 KB of LDS leave one workgroup per CU. Measured on the whole step: 16-image launches (M = 26 k rows) 41.8 ->
+    // 41.3 ms with the 64-wide tile, 112-image launches (M = 185 k) 3987 -> 4032 images/s with the 32-wide one (three
+    // workgroups per CU hide more latency once there are enough of them): chosen by M.
     static const int force_bk = std::getenv("V1T_GEMM_BK") ? atoi(std::getenv("V1T_GEMM_BK")) : 0;  // dev switch
-    const bool bk64 = a.K % 64 == 0 && force_bk != 32;
+    const bool bk64 = a.K % 64 == 0 && force_bk != 32 && (force_bk == 64 || a.M < 65536);
     return bk64 ? launch_nt_nw<NBLK, 4, 64>(a, epi, s) : launch_nt_nw<NBLK, 4, 32>(a, epi, s);
 }
 
