@@ -34,10 +34,10 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
         float bias = 0.f;
         if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU) bias = g.bias ? g.bias[col] : 0.f;
         bf16x8 gp0 = {}, gp1 = {};  // gelu' of this lane's 16 accumulator slots (fragment order)
-        if constexpr (EPI == EPI_DGELU) {
-            const bf16_t* fp = g.aux + frag_index(g, m0, n0, nb, wave, lane);
-            gp0 = *(const bf16x8*)fp;
-            gp1 = *(const bf16x8*)(fp + 8);
+        if constexpr (EPI == EPI_DGELU) {  // prefetched by the kernel before its last K tile: 8 dwords in resv[nb][0..7]
+            f32x4 lo = {resv[nb][0], resv[nb][1], resv[nb][2], resv[nb][3]}, hi = {resv[nb][4], resv[nb][5], resv[nb][6], resv[nb][7]};
+            gp0 = __builtin_bit_cast(bf16x8, lo);
+            gp1 = __builtin_bit_cast(bf16x8, hi);
         }
         float csum = 0.f;
 #pragma unroll
@@ -137,10 +137,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = g.K / BK;
 
-    // residual operand of the epilogue: its 16*NBLK narrow loads are issued HERE, in the prologue, so their
-    // latency hides under the K loop (issued in the epilogue they cost more than the MFMAs of these skinny GEMMs)
+    // residual operand of the epilogue: its 16*NBLK narrow loads are issued at the start of the LAST K tile (peeled below), so
+    // their latency hides under that tile's MFMAs without the 16*NBLK registers being live through the whole K loop next to
+    // the staging registers (held from the prologue they pushed the proj / FC2 kernels to 284 VGPRs = one workgroup per CU)
     f32x16 resv[NBLK];
-    if constexpr (EPI == EPI_BIAS_RES) {
+    auto load_res = [&]() {
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
                 const int row = m0 + 32 * wave + acc_row(r, lane);
                 resv[nb][r] = (g.res && row < g.M) ? g.res[(size_t)row * g.ldres + n0 + 32 * nb + (lane & 31)] : 0.f;
             }
-    }
+    };
     u32x4 ra[A_ITERS], rb[B_ITERS];
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
@@ -187,9 +188,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
     swrite(0);
     __syncthreads();
     const int frag_off = (lane & 31) * LS + 8 * (lane >> 5);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+    auto ktile = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const bf16x8 a = *(const bf16x8*)(&sA[buf][32 * wave * LS + frag_off + 16 * ks]);
@@ -200,9 +199,29 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmNTArgs g) {
                 else acc[nb] = mfma32(a, b, acc[nb]);
             }
         }
-        if (kt + 1 < nk) swrite(buf ^ 1);
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int buf = kt & 1;
+        gload(kt + 1);
+        ktile(buf);
+        swrite(buf ^ 1);
         __syncthreads();
     }
+    if constexpr (EPI == EPI_BIAS_RES) load_res();
+    if constexpr (EPI == EPI_DGELU) {  // saved gelu' fragments (2 x 16 B per block), same early issue
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) {
+            const bf16_t* fp = g.aux + frag_index(g, m0, n0, nb, wave, lane);
+            const f32x4 lo = *(const f32x4*)fp, hi = *(const f32x4*)(fp + 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                resv[nb][j] = lo[j];
+                resv[nb][4 + j] = hi[j];
+            }
+        }
+    }
+    ktile((nk - 1) & 1);
+    __syncthreads();
 
     // 16-bit outputs go through LDS: a lane holds one column of 16 rows per block, i.e. 2-byte global stores that fill
     // 64 B of two rows per instruction; staged [32 rows][BN] per wave (wave-private, no barrier) and written back as 16-B
