@@ -403,25 +403,37 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     }
 }
 
-// delta[b][h][t] = keep_prob * sum_d dO * O
+// delta[b][h][t] = keep_prob * sum_d dO * O. 16 lanes per (row, head) segment: a load instruction reads 256 contiguous
+// bytes of each of its 4 segments (one thread per segment read 16 B at a 320-B stride per lane: 3.4 TB/s).
 template <int DP>
-__global__ void attn_delta_kernel(AttnArgs a, float* delta) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = a.B * a.T * a.H;
-    if (idx >= total) return;
-    const int h = idx % a.H, row = idx / a.H;
-    const int b = row / a.T, t = row % a.T;
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, float* delta) {
+    constexpr int CH = DP / 8;  // 16-B chunks per segment
+    const int sub = threadIdx.x & 15;
+    const long long seg = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const long long total = (long long)a.B * a.T * a.H;
+    const bool ok = seg < total;
+    const int h = ok ? (int)(seg % a.H) : 0;
+    const long long row = ok ? seg / a.H : 0;
     const bf16_t* po = a.o + (size_t)row * a.ldo + h * DP;
     const bf16_t* pd = a.dO + (size_t)row * a.lddo + h * DP;
     float acc = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < DP / 8; ++c) {
-        const bf16x8 x = *(const bf16x8*)(po + 8 * c);
-        const bf16x8 y = *(const bf16x8*)(pd + 8 * c);
+    if (ok) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
+        for (int c = sub; c < CH; c += 16) {
+            const bf16x8 x = *(const bf16x8*)(po + 8 * c);
+            const bf16x8 y = *(const bf16x8*)(pd + 8 * c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
+        }
     }
-    delta[((size_t)b * a.H + h) * a.T + t] = acc * a.adrop.keep_prob;  // 1/keep is folded into the backward epilogues
+    acc += __shfl_xor(acc, 8);
+    acc += __shfl_xor(acc, 4);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 1);
+    if (ok && sub == 0) {
+        const long long b_ = row / a.T, t = row % a.T;
+        delta[((size_t)b_ * a.H + h) * a.T + t] = acc * a.adrop.keep_prob;  // 1/keep is folded into the backward epilogues
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -992,8 +1004,8 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
 }
 template <int DP>
 int launch_delta_t(const AttnArgs& a, float* delta, hipStream_t s) {
-    const int total = a.B * a.T * a.H;
-    hipLaunchKernelGGL((attn_delta_kernel<DP>), dim3((total + 255) / 256), dim3(256), 0, s, a, delta);
+    const long long total = (long long)a.B * a.T * a.H;
+    hipLaunchKernelGGL((attn_delta_kernel<DP>), dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, s, a, delta);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 
