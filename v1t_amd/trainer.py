@@ -119,8 +119,8 @@ class Trainer:
         self.opt.bind(model, self.core_lr)
         self.batch_size = args.batch_size
         self._core_l1: t.Optional[float] = None
-        # V1T_TRAINER_PER_MOUSE=1 (dev): one core pass per mouse-batch, as the reference's loop does, instead of one pass
-        # over the concatenated local batches
+        # V1T_CORE_GROUP=n (dev): mouse-batches per pass of the shared core; 1 = one core pass per mouse-batch, as the
+        # reference's loop does (default: all local mouse-batches in one pass)
         self.core_group = int(os.environ.get("V1T_CORE_GROUP", "7"))
         self.batch_core = self.core_group > 1
 
