@@ -25,12 +25,12 @@ for _ in range(3):
 torch.cuda.synchronize()
 raw = C.CDLL(L.LIB_PATH)
 NT, NP = 8, 16
-buf = (C.c_ulonglong * (4 * NT * NP))()
+buf = (C.c_ulonglong * (8 * NT * NP))()
 n = raw.v1t_kprof_read(buf, len(buf))
 assert n == len(buf), n
-t = np.array(buf, dtype=np.int64).reshape(4, NT, NP)
+t = np.array(buf, dtype=np.int64).reshape(8, NT, NP)
 names = ["loop", "K+S chain", "max", "resc+dma", "softmax", "PV issue", "dma wait", "barrier"]
-for w in range(4):
+for w in (0, 1, 4, 5):
     print(f"wave {w}")
     for k in range(NT - 1):
         seg = [t[w, k, 0] - t[w, k, 7]] + [t[w, k, i + 1] - t[w, k, i] for i in range(6)] + [t[w, k + 1, 7] - t[w, k, 6]]

@@ -29,7 +29,7 @@
 #define KP_T0 8
 #define KP_NT 8
 #define KP_NP 16
-__device__ unsigned long long g_kprof[4 * KP_NT * KP_NP];
+__device__ unsigned long long g_kprof[8 * KP_NT * KP_NP];  // up to 8 waves (forward kernel)
 #define KP_DECL unsigned long long kp_t[KP_NP] = {}
 #define KP_STAMP(i)                                            \
     do {                                                       \
@@ -1173,7 +1173,7 @@ int launch_rollout_vecmat(const float* A, const float* rowsum, const float* v, f
 
 #ifdef V1T_KPROF
 extern "C" int v1t_kprof_read(unsigned long long* out, int n) {
-    const int total = 4 * KP_NT * KP_NP;
+    const int total = 8 * KP_NT * KP_NP;
     if (n < total) return -1;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kprof), sizeof(unsigned long long) * total) != hipSuccess) return -2;
     return total;
