@@ -101,6 +101,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    local = local % torch.cuda.device_count()  # one rank per GPU under the driver; more ranks than GPUs share (dev runs)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
