@@ -899,10 +899,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_store_kernel(AttnArgs a) 
 // 64-key stages of dS' ((128 q, 64 k) blocks) and K [64 k][DP] by LDS-DMA, double buffered. Bound by reading dS' from HBM
 // (2 B per (query, key), stored tile-major so that a stage reads contiguous 16 KB blocks) plus the K tiles from L2, which every
 // workgroup of an (image, head) re-reads: NW = 8 (256 queries share a K tile) halves that L2 traffic.
-template <int DP, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
+template <int DP, int NW, int KT>
+__global__ __launch_bounds__(64 * NW, (NW == 4 || KT == 32) ? 2 : 1) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
     using G = Geo<DP>;
-    constexpr int KT = 64, SSTR = KT + 8, QB = 32 * NW;
+    constexpr int SSTR = KT + 8, QB = 32 * NW, BK = 64;  // BK: key width of a stored dS' block; KT: keys per stage (32: half a block)
     using DmaS = TileDma<KT, SSTR, 128, NW>;
     using DmaK = TileDma<DP, G::RSTR, KT, NW>;
     __shared__ __attribute__((aligned(16))) bf16_t sS[2][NW / 4][DmaS::LDS_ELEMS];
@@ -914,12 +914,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dq_gemm_ker
     const int h2 = lane >> 5;
     DmaS dmaS;
     DmaK dmaK;
-    dmaS.init(lane, wave, KT);  // tile-major dS': a (128 q, 64 k) block is 16 KB contiguous, rows 64 elements apart
+    dmaS.init(lane, wave, BK);  // tile-major dS': a (128 q, 64 k) block is 16 KB contiguous, rows 64 elements apart
     dmaK.init(lane, wave, a.ldqkv);
     const bf16_t* kbase = a.qkv + (size_t)b * a.T * a.ldqkv + a.H * DP + h * DP;
-    const int nkt = a.ldds / KT, nqt = (a.T + 127) / 128;
+    const int nkt = a.ldds / BK, nqt = (a.T + 127) / 128;
     const int qt0 = rb * (NW / 4);  // first 128-query tile of this workgroup
-    const bf16_t* sbase = a.ds + ((size_t)(b * a.H + h) * nqt + qt0) * nkt * (128 * KT);
+    const bf16_t* sbase = a.ds + ((size_t)(b * a.H + h) * nqt + qt0) * nkt * (128 * BK);
     const bool second = NW == 8 && qt0 + 1 < nqt;  // the last workgroup of an odd tile count has one tile only
     f32x16 dq[G::DB];
 #pragma unroll
@@ -928,9 +928,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dq_gemm_ker
     const int toff = tr_lane_off(lane, G::RSTR);
     const int nt = a.ldds / KT;  // every key column up to ldds was written (zeros beyond T)
     auto stage = [&](int kt, int buf) {
-        dmaS.issue(sbase + (size_t)kt * (128 * KT), 0, 128, sS[buf][0]);
+        const size_t blk = (size_t)(kt * KT / BK) * (128 * BK) + (kt * KT) % BK;  // block of this stage + key offset inside it
+        dmaS.issue(sbase + blk, 0, 128, sS[buf][0]);
         if constexpr (NW == 8) {
-            if (second) dmaS.issue(sbase + ((size_t)nkt + kt) * (128 * KT), 0, 128, sS[buf][1]);
+            if (second) dmaS.issue(sbase + (size_t)nkt * (128 * BK) + blk, 0, 128, sS[buf][1]);
         }
         dmaK.issue(kbase, KT * kt, a.T, sK[buf]);
     };
@@ -979,8 +980,11 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
             static const int nw = std::getenv("V1T_DQ_NW") ? atoi(std::getenv("V1T_DQ_NW")) : 8;  // dev switch
-            if (nw == 4) hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP, 4>), dim3(n), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP, 8>), dim3(((a.T + 255) / 256) * a.H * a.B), dim3(512), 0, s, a);
+            static const int kt = std::getenv("V1T_DQ_KT") ? atoi(std::getenv("V1T_DQ_KT")) : 64;  // dev switch
+            const dim3 g8(((a.T + 255) / 256) * a.H * a.B);
+            if (nw == 4) hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP, 4, 64>), dim3(n), dim3(256), 0, s, a);
+            else if (kt == 32) hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP, 8, 32>), g8, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP, 8, 64>), g8, dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DQ, s);
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
