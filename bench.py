@@ -75,8 +75,11 @@ def cpu_baseline(seconds_budget: float = 30.0) -> dict:
             "sample": f"oracle fp32 train step (fwd+bwd, no dropout masks), default V1T, 1 mouse x 8000 neurons, B={B}, {n} reps after 1 warm-up, torch {torch.__version__} CPU, {cores} threads"}
 
 
-# (FETCH_SIZE, WRITE_SIZE) in KiB per launch at the default shape, dropout on (profiles/r01_pmc_attention_fetch_write.txt)
-PMC_KIB = {"attn_fwd": (57173.5, 33975.5), "attn_bwd_fused": (166139.7, 104235.2), "attn_bwd_dkv_store": (85146.8, 414981.3), "attn_bwd_dq_gemm": (192139.6, 33252.1)}
+# (FETCH_SIZE, WRITE_SIZE) in KiB per 112-image launch (all 7 mouse-batches of the default shape in one core pass), dropout
+# on: profiles/r01_pmc_attention_fetch_write.txt, tools/pmc_bench.sh (separate --pmc passes; FETCH_SIZE x2 on gfx950)
+PMC_IMAGES = 112
+PMC_KIB = {"attn_fwd": (422222.9, 522369.0), "attn_bwd_fused": (166139.7 * 7, 104235.2 * 7), "attn_bwd_dkv_store": (623565.6, 2895070.2),
+           "attn_bwd_dq_gemm": (1368689.1, 234988.2)}
 
 
 def main():
@@ -158,8 +161,8 @@ def main():
         # only valid for the shape it was measured on (16 images x 4 heads x 1654 tokens x 160 padded head dim)
         default_shape = args.batch_size == 16 and a.neurons == 8000
         traffic = {0: PMC_KIB["attn_fwd"], 1: PMC_KIB["attn_bwd_dq_gemm"], 2: PMC_KIB["attn_bwd_fused" if fused else "attn_bwd_dkv_store"]}.get(a.profile_class)
-        # (measured per 16-image launch; the kernels' traffic is proportional to the images of a launch)
-        traffic = (2 * traffic[0] + traffic[1]) * 1024 * imgs_launch / 16 if (default_shape and traffic) else None
+        # (measured on 112-image launches; the kernels' traffic is proportional to the images of a launch)
+        traffic = (2 * traffic[0] + traffic[1]) * 1024 * imgs_launch / PMC_IMAGES if (default_shape and traffic) else None
         avg_ms = total_ms.value / max(launches.value, 1)
         achieved = per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         line = {
