@@ -466,12 +466,16 @@ def test_attention_rollout_vs_oracle_default_size(dev):
         assert rel_to_max(rows[i].cpu().numpy(), ref.numpy()) < 3e-3
 
 
-def test_core_batched_over_mice_equals_per_mouse(dev):
+@pytest.mark.parametrize("variant", [{}, {"use_lsa": True}, {"patch_mode": 3}, {"behavior_mode": 0, "shift_mode": 0}, {"patch_stride": 2, "disable_bias": True},
+                                     {"shift_mode": 4, "center_crop": 0.8, "raw_input_shape": (1, 36, 64), "input_shape": (1, 28, 51)}])
+def test_core_batched_over_mice_equals_per_mouse(dev, variant):
     """Model.forward_mice (one pass of the shared core over the concatenated mouse-batches, ragged sizes) == one
-    Model.forward per mouse: predictions bit-identical rows, gradients equal up to the summation order of the atomics."""
+    Model.forward per mouse: predictions bit-identical rows, gradients equal up to the summation order of the atomics.
+    Variants: LSA (fused attention backward), dual PatchNorm, no behaviour / no shifter, strided patches without biases,
+    cropped input with the learned image shifter."""
     from v1t_amd.losses import elu1_poisson_loss
 
-    cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B", "C"), num_neurons={"A": 96, "B": 50, "C": 130})
+    cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B", "C"), num_neurons={"A": 96, "B": 50, "C": 130}, **variant)
     sd = W.make_state_dict(cfg, 9)
     model, _ = build_native_model(cfg, sd, dev)
     model.train(False)
