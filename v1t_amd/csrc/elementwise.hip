@@ -325,58 +325,72 @@ DEVFN float row8_sum(float v) {
 typedef __attribute__((ext_vector_type(4))) bf16_t bf16x4_t;
 
 // LayerNorm forward fused with the BehaviorMLP injection x += beta[b] (vit.py:356-359).
+constexpr int LNF_RPW = 2;  // 8-row groups per wave: all their loads are issued before the first reduction (bytes in flight)
 template <int CPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 7;
-    const int row = (blockIdx.x * 4 + wave) * 8 + (lane >> 3);
-    const bool rok = row < a.rows;
-    const int rr = rok ? row : a.rows - 1;
-    const int b = rr / a.T;
-    f32x4 v[CPL];
-    float s = 0.f;
+    f32x4 v[LNF_RPW][CPL];
+    int rows[LNF_RPW];
+    bool roks[LNF_RPW];
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        const int c = 4 * (j + 8 * k);
-        v[k] = *(const f32x4*)(a.x + (size_t)rr * a.DP + c);
-        if (a.inject) {
-            v[k] += *(const f32x4*)(a.inject + (size_t)b * a.DP + c);
-            if (rok) *(f32x4*)(a.xout + (size_t)row * a.DP + c) = v[k];
-        }
+    for (int it = 0; it < LNF_RPW; ++it) {
+        const int row = ((blockIdx.x * 4 + wave) * LNF_RPW + it) * 8 + (lane >> 3);
+        const bool rok = row < a.rows;
+        const int rr = rok ? row : a.rows - 1;
+        const int b = rr / a.T;
+        rows[it] = row;
+        roks[it] = rok;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (c + e >= a.D) v[k][e] = 0.f;  // pad columns are zero in x; keep them out of the statistics regardless
-            s += v[k][e];
+        for (int k = 0; k < CPL; ++k) {
+            const int c = 4 * (j + 8 * k);
+            v[it][k] = *(const f32x4*)(a.x + (size_t)rr * a.DP + c);
+            if (a.inject) {
+                v[it][k] += *(const f32x4*)(a.inject + (size_t)b * a.DP + c);
+                if (rok) *(f32x4*)(a.xout + (size_t)row * a.DP + c) = v[it][k];
+            }
         }
     }
-    const float mean = row8_sum(s) / a.D;
-    float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < CPL; ++k)
+    for (int it = 0; it < LNF_RPW; ++it) {
+        const int row = rows[it];
+        float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = (4 * (j + 8 * k) + e < a.D) ? v[k][e] - mean : 0.f;
-            q += d * d;
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (4 * (j + 8 * k) + e >= a.D) v[it][k][e] = 0.f;  // pad columns are zero in x; keep them out of the statistics regardless
+                s += v[it][k][e];
+            }
+        const float mean = row8_sum(s) / a.D;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = (4 * (j + 8 * k) + e < a.D) ? v[it][k][e] - mean : 0.f;
+                q += d * d;
+            }
+        const float rstd = rsqrtf(row8_sum(q) / a.D + a.eps);
+        if (!roks[it]) continue;  // the row reductions above need every lane
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int c = 4 * (j + 8 * k);
+            bf16x4_t zh, zl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int cc = c + e;
+                const float z = (cc < a.D) ? (v[it][k][e] - mean) * rstd * a.gamma[cc] + a.beta[cc] : (cc == a.ones_col ? 1.f : 0.f);
+                zh[e] = (bf16_t)z;
+                zl[e] = aux_plane(z, zh[e], a.lo_f16);
+            }
+            *(bf16x4_t*)(a.z + (size_t)row * a.DP + c) = zh;
+            if (a.z_lo) *(bf16x4_t*)(a.z_lo + (size_t)row * a.DP + c) = zl;
         }
-    const float rstd = rsqrtf(row8_sum(q) / a.D + a.eps);
-    if (!rok) return;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        const int c = 4 * (j + 8 * k);
-        bf16x4_t zh, zl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int cc = c + e;
-            const float z = (cc < a.D) ? (v[k][e] - mean) * rstd * a.gamma[cc] + a.beta[cc] : (cc == a.ones_col ? 1.f : 0.f);
-            zh[e] = (bf16_t)z;
-            zl[e] = aux_plane(z, zh[e], a.lo_f16);
+        if (j == 0) {
+            a.mean[row] = mean;
+            a.rstd[row] = rstd;
         }
-        *(bf16x4_t*)(a.z + (size_t)row * a.DP + c) = zh;
-        if (a.z_lo) *(bf16x4_t*)(a.z_lo + (size_t)row * a.DP + c) = zl;
-    }
-    if (j == 0) {
-        a.mean[row] = mean;
-        a.rstd[row] = rstd;
     }
 }
 
@@ -806,7 +820,7 @@ int launch_patch_embed_bwd(const PatchArgs& a, hipStream_t s) {
 
 int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s) {
     if (a.DP > 384 || a.DP % 32 != 0) return V1T_ERR_UNSUPPORTED;
-    const dim3 grid((a.rows + 31) / 32);
+    const dim3 grid((a.rows + 32 * LNF_RPW - 1) / (32 * LNF_RPW));
 #define LN_FWD_CASE(N) case N: hipLaunchKernelGGL(ln_fwd_kernel<N>, grid, dim3(256), 0, s, a); break;
     switch (a.DP / 32) {
         LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) LN_FWD_CASE(5) LN_FWD_CASE(6)
