@@ -575,6 +575,42 @@ def gen_checkpoint(out: dict, log=print):
     log(f"  g11: ok ({len(order)} parameters in {len(ck['optimizer']['param_groups'])} groups)")
 
 
+def gen_boundary(out: dict, log=print):
+    """G12: what the reference's own `Model` / `Gaussian2DReadout` constructors produce at the drop-in boundary
+    (model.py:74-139, gaussian2d.py:19-81,138-186): optimizer group names and the parameter order inside them for
+    shift_mode 2 and 4 (torch.optim state dicts are positional), and the default initialisation of the readout
+    (sigma ~ U(+-0.1), features = 1/C, bias by bias_mode, mu predictor / free mu) under a fixed torch seed."""
+    import_reference()
+    from v1t.models.model import Model
+    from v1t.models.readout.gaussian2d import Gaussian2DReadout
+
+    for sm, extra in ((2, {}), (4, dict(center_crop=0.8, raw_input_shape=(1, 36, 64), input_shape=(1, 28, 51)))):
+        cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 40, "B": 23}, shift_mode=sm, **extra)
+        ds = {m: FakeDS(W.make_coordinates(3, m, cfg.num_neurons[m]), cfg.num_neurons[m]) for m in cfg.mouse_ids}
+        model = Model(ref_args(cfg), ds=ds)
+        pid = {id(p): k for k, p in model.named_parameters()}
+        groups = model.get_parameters(core_lr=1e-3)
+        out[f"g12/sm{sm}/group_names"] = np.array([g["name"] for g in groups])
+        for g in groups:
+            out[f"g12/sm{sm}/group/{g['name']}"] = np.array([pid[id(p)] for p in g["params"]])
+        out[f"g12/sm{sm}/core_output_shape"] = np.asarray(model.core.output_shape)
+        out[f"g12/sm{sm}/state_keys"] = np.array(list(model.state_dict().keys()))
+    n, c = 57, 24
+    coords = W.make_coordinates(5, "A", n)
+    stats = {"mean": (0.5 + np.arange(n, dtype=np.float32) / n), "std": (1.0 + 0.5 * np.cos(np.arange(n, dtype=np.float32)) ** 2).astype(np.float32)}
+    for tag, kw in (("bias0", dict(bias_mode=0)), ("bias1", dict(bias_mode=1)), ("bias2", dict(bias_mode=2)), ("freemu", dict(bias_mode=0, disable_grid_predictor=True)),
+                    ("grid3", dict(bias_mode=0, grid_predictor_dim=3))):
+        a = SimpleNamespace(readout_reg_scale=0.0076, disable_grid_predictor=False, grid_predictor_dim=2, bias_mode=0)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        ds = SimpleNamespace(dataset=SimpleNamespace(coordinates=coords, response_stats=stats))
+        torch.manual_seed(77)
+        ro = Gaussian2DReadout(a, input_shape=(c, 5, 7), output_shape=(n,), ds=ds, name="x")
+        for k, v in ro.state_dict().items():
+            out[f"g12/init/{tag}/{k}"] = v.detach().numpy().copy()
+    log("  g12: ok")
+
+
 def gen_data(out: dict, log=print):
     """G10: the reference's MiceDataset + DataLoader (data.py:275-491) over a tiny recording written in the on-disk layout by
     oracle/fake_sensorium.py (same seeds in the tests): collated, standardised batches per tier."""
@@ -612,6 +648,13 @@ def main():
         path = os.path.join(ROOT, "tests", "golden", fname)
         np.savez_compressed(path, **d)
         print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB, {len(d)} arrays")
+
+    d = {}
+    print("G12 boundary: optimizer groups / readout initialisation of the reference's constructors")
+    gen_boundary(d)
+    save("g12_boundary.npz", d)
+    if "--only-g12" in sys.argv:
+        return
 
     d = {}
     print("G11 checkpoint written by the reference's Scheduler")

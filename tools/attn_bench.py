@@ -10,7 +10,7 @@ from v1t_amd import lib as L  # noqa: E402
 
 lib = L.load()
 dev = torch.device("cuda:0")
-B, H, T, DP = 16, 4, 1654, 160
+B, H, T, DP = int(os.environ.get("ATTN_B", "16")), 4, 1654, 160
 g = torch.Generator().manual_seed(0)
 qkv = (torch.randn(B * T, 3 * H * DP, generator=g) * 0.7).to(dev).bfloat16()
 dO = (torch.randn(B * T, H * DP, generator=g) * 0.5).to(dev).bfloat16()
