@@ -1,6 +1,6 @@
-"""Checkpoint compatibility (v1t_amd/scheduler.py, FusedAdamW.state_dict): the file the native Scheduler writes has the
-structure of the reference's (golden G11: utils/scheduler.py:84-104 after the G6 step) and its AdamW moments; restoring it
-continues training like the uninterrupted run; plateau / early-stopping logic follows scheduler.py:170-198."""
+"""Checkpoint compatibility (v1t_amd/checkpoint.py, FusedAdamW.state_dict): the file the native side writes has the
+structure of the reference's (golden G11: the file utils/scheduler.py:84-104 wrote after the G6 step) and its AdamW moments;
+restoring it continues training like the uninterrupted run; optimizer groups follow the reference's order (golden G12)."""
 import os
 from types import SimpleNamespace
 
@@ -15,38 +15,95 @@ from tests.helpers import build_native_model, rel_to_max, sample
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def test_scheduler_plateau_logic(tmp_path):
-    """No GPU: lr reduction after lr_patience epochs without improvement, termination after max_reduce reductions."""
-    from v1t_amd.scheduler import Scheduler
+def test_checkpoint_file_roundtrip_cpu(tmp_path):
+    """No GPU: file layout, partial (module-filtered) files, atomic replace, missing-file behaviour."""
+    from v1t_amd import checkpoint as CK
 
     class Opt:
         def __init__(self):
             self.param_groups = [{"name": "core", "lr": 1.0}, {"name": "readouts", "lr": 2.0}]
+            self.loaded = None
 
         def state_dict(self):
             return {"state": {}, "param_groups": [dict(g) for g in self.param_groups]}
 
         def load_state_dict(self, sd):
-            pass
+            self.loaded = sd
 
-    model = torch.nn.Linear(2, 2)
-    sch = Scheduler(SimpleNamespace(output_dir=str(tmp_path), device="cpu", verbose=0), model, Opt(), mode="max", max_reduce=2, lr_patience=1, factor=0.5)
-    assert sch.step(0.3, epoch=1) is False and os.path.exists(tmp_path / "ckpt" / "model_state.pt")
-    w_best = model.weight.detach().clone()
-    with torch.no_grad():
-        model.weight.add_(1.0)
-    assert sch.step(0.2, epoch=2) is False and sch.lr_wait == 1  # waits
-    assert sch.step(0.2, epoch=3) is False and sch.num_reduce == 1  # restores the best weights and reduces
-    assert torch.equal(model.weight, w_best) and [g["lr"] for g in sch.optimizer.param_groups] == [0.5, 1.0]
-    assert sch.step(0.1, epoch=4) is False and sch.step(0.1, epoch=5) is False and sch.num_reduce == 2
-    assert sch.step(0.1, epoch=6) is False and sch.step(0.1, epoch=7) is True  # max_reduce reached
+    model = torch.nn.ModuleDict({"core": torch.nn.Linear(2, 2), "readouts": torch.nn.Linear(2, 3)})
+    opt = Opt()
+    assert CK.read(str(tmp_path), model) is None
     with pytest.raises(FileNotFoundError):
-        Scheduler(SimpleNamespace(output_dir=str(tmp_path / "other"), device="cpu", verbose=0), model, Opt()).restore(force=True)
+        CK.read(str(tmp_path), model, required=True)
+    path = CK.write(str(tmp_path), model, opt, epoch=4, value=0.31)
+    assert path == str(tmp_path / "ckpt" / "model_state.pt") and os.path.exists(path) and not os.path.exists(path + ".tmp")
+    blob = torch.load(path, weights_only=False)
+    assert set(blob) == {"epoch", "value", "model", "optimizer", "scheduler"} and blob["scheduler"]["best_value"] == 0.31
+    best = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(1.0)
+    info = CK.read(str(tmp_path), model, opt)
+    assert info["epoch"] == 4 and info["value"] == 0.31 and opt.loaded["param_groups"][1]["lr"] == 2.0
+    assert all(torch.equal(v, best[k]) for k, v in model.state_dict().items())
+    # partial file: only the readouts travel; reading it leaves the core as it is
+    CK.write(str(tmp_path), model, opt, epoch=5, value=0.4, modules=["readouts"])
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(1.0)
+    core_now = model["core"].weight.detach().clone()
+    CK.read(str(tmp_path), model)
+    assert torch.equal(model["core"].weight, core_now) and torch.equal(model["readouts"].weight, best["readouts.weight"])
+    other = torch.nn.ModuleDict({"core": torch.nn.Linear(2, 2)})
+    with pytest.raises(KeyError):
+        CK.read(str(tmp_path), other)
+
+
+def test_optimizer_groups_follow_reference_order_and_load_by_name():
+    """get_parameters() must emit core, readouts, image_cropper, core_shifter like the reference (golden G12,
+    model.py:112-139) and FusedAdamW.load_state_dict must match groups by name and check shapes (no GPU needed)."""
+    import v1t_amd
+    from v1t_amd.synthetic import default_args, make_ds
+    from v1t_amd.trainer import FusedAdamW
+
+    g = np.load(os.path.join(GOLD, "g12_boundary.npz"))
+    args = default_args(input_shape=(1, 36, 64), center_crop=0.8, resize_image=0, num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, shift_mode=4)
+    neurons = {"A": 40, "B": 23}
+    args.output_shapes = {m: (n,) for m, n in neurons.items()}
+    model = v1t_amd.Model(args, make_ds(neurons))
+    names = {id(p): k for k, p in model.named_parameters()}
+    groups = model.get_parameters(core_lr=1e-3)
+    assert [x["name"] for x in groups] == list(g["g12/sm4/group_names"]) == ["core", "readouts", "image_cropper", "core_shifter"]
+    for x in groups:
+        assert [names[id(p)] for p in x["params"]] == list(g[f"g12/sm4/group/{x['name']}"]), x["name"]
+    assert list(model.state_dict().keys()) == list(g["g12/sm4/state_keys"])
+    assert tuple(model.core.output_shape) == tuple(g["g12/sm4/core_output_shape"])
+    # a reference-ordered optimizer state loads; the same state with two groups swapped (positionally) still loads BY NAME;
+    # unnamed + swapped fails on the shape check instead of exchanging moments
+    opt = FusedAdamW(1e-3)
+    opt.bind(model, 1e-3)
+    ref_opt = torch.optim.AdamW(model.get_parameters(core_lr=1e-3), lr=1e-3, betas=(0.9, 0.9999), eps=1e-8, weight_decay=0)
+    for p in model.parameters():
+        p.grad = torch.full_like(p, 0.5)
+    ref_opt.step()
+    sd = ref_opt.state_dict()
+    opt.load_state_dict(sd)
+    a = model.mouse_arena("A")
+    assert a.step == 1 and float(a.exp_avg.abs().max()) > 0
+    back = opt.state_dict()
+    assert [x["name"] for x in back["param_groups"]] == [x["name"] for x in sd["param_groups"]]
+    for i, st in sd["state"].items():
+        assert torch.allclose(back["state"][i]["exp_avg"], st["exp_avg"]) and back["state"][i]["exp_avg"].shape == st["exp_avg"].shape
+    swapped = {"state": sd["state"], "param_groups": [sd["param_groups"][i] for i in (0, 1, 3, 2)]}
+    opt.load_state_dict(swapped)
+    unnamed = {"state": sd["state"], "param_groups": [{k: v for k, v in x.items() if k != "name"} for x in swapped["param_groups"]]}
+    with pytest.raises(ValueError):
+        opt.load_state_dict(unnamed)
 
 
 @pytest.mark.gpu
 def test_checkpoint_vs_reference_golden_and_resume(tmp_path):
-    from v1t_amd.scheduler import Scheduler
+    from v1t_amd import checkpoint as CK
     from v1t_amd.synthetic import make_ds
     from v1t_amd.trainer import Trainer
 
@@ -68,8 +125,7 @@ def test_checkpoint_vs_reference_golden_and_resume(tmp_path):
 
     model, args, tr = fresh()
     tr.train_step(batches)
-    sch = Scheduler(args, model, tr.opt, mode="max")
-    assert sch.step(0.25, epoch=3) is False
+    CK.write(str(tmp_path), model, tr.opt, epoch=3, value=0.25, device=dev)
     ck = torch.load(os.path.join(str(tmp_path), "ckpt", "model_state.pt"), weights_only=False)
     # ---- same file structure as the reference's
     assert set(ck) == {"epoch", "value", "model", "optimizer", "scheduler"} and ck["epoch"] == int(g["g11/epoch"]) and ck["value"] == float(g["g11/value"])
@@ -99,8 +155,8 @@ def test_checkpoint_vs_reference_golden_and_resume(tmp_path):
     tr.train_step(batches)
     cont = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model2, args2, tr2 = fresh()
-    sch2 = Scheduler(args2, model2, tr2.opt, mode="max")
-    assert sch2.restore(force=True, load_optimizer=True, load_scheduler=True) == 3 and sch2.best_value == 0.25
+    info = CK.read(str(tmp_path), model2, tr2.opt, map_location=dev, required=True)
+    assert info["epoch"] == 3 and info["scheduler"]["best_value"] == 0.25
     tr2.train_step(batches)
     # a few gradients are accumulated with float atomics (LayerNorm gamma / beta, bias column sums), so two runs differ
     # in the last bits of g and Adam's second step by a small fraction of lr where g ~ 0; a run that lost the moments or

@@ -53,7 +53,7 @@ def _step(rank, world, port, q):
         ro.forward = (lambda inputs, sample=None, shifts=None, eps=None, _o=ro.forward, _e=e: _o(inputs, sample=sample, shifts=shifts, eps=_e))
     rec = {}
     names = {id(model.core._arena): "core", **{id(model.mouse_arena(m)): m for m in MICE}}
-    tr.opt.step_arena = lambda arena, lr, ranges, zero_grad=True: rec.__setitem__(names[id(arena)], arena.grad.detach().cpu().numpy().copy())  # numpy: pickled by value through the queue
+    tr.opt.step_arena = lambda arena, ranges, zero_grad=True: rec.__setitem__(names[id(arena)], arena.grad.detach().cpu().numpy().copy())  # numpy: pickled by value through the queue
     out = tr.train_step(batches)
     torch.cuda.synchronize()
     q.put((rank, [(m, None if sl is None else (sl.start, sl.stop)) for m, sl in sh.local_units()], rec, float(out["loss"])))

@@ -71,23 +71,34 @@ class _ShifterFn(torch.autograd.Function):
         return (None, *[x[1] for x in sinks])
 
 
+def _tanh_mlp(widths: t.Sequence[int]) -> nn.Sequential:
+    """Linear -> Tanh chain over `widths` (modules 0, 2, 4, ... are the Linears: the state-dict keys `mlp.0/2/4.*` of
+    SURVEY.md Appendix C for widths (2, 5, 5, 2) / (2|5, 10, 10, 2))."""
+    mods: t.List[nn.Module] = []
+    for fan_in, fan_out in zip(widths[:-1], widths[1:]):
+        mods += [nn.Linear(fan_in, fan_out), nn.Tanh()]
+    return nn.Sequential(*mods)
+
+
+def _l1(module: nn.Module, scale: torch.Tensor):
+    total = 0
+    for p in module.parameters():
+        total = total + p.abs().sum()
+    return scale * total
+
+
 class CoreShifter(nn.Module):
-    """reference core_shifter.py:7-40"""
+    """Pupil centre -> (dx, dy) added to the readout positions (reference core_shifter.py:7-40): tanh MLP
+    in_features -> hidden x (num_layers - 1) -> 2, L1-regularised with `shifter_reg_scale`."""
 
     def __init__(self, args, in_features: int, hidden_features: int, num_layers: int, name: str = "CoreShifter"):
         super().__init__()
         self.name = name
         self.register_buffer("reg_scale", torch.tensor(float(getattr(args, "shifter_reg_scale", 0.0))))
-        out_features = in_features
-        layers = []
-        for _ in range(num_layers - 1):
-            layers.extend([nn.Linear(out_features, hidden_features), nn.Tanh()])
-            out_features = hidden_features
-        layers.extend([nn.Linear(out_features, 2), nn.Tanh()])
-        self.mlp = nn.Sequential(*layers)
+        self.mlp = _tanh_mlp([in_features] + [hidden_features] * (num_layers - 1) + [2])
 
     def regularizer(self):
-        return self.reg_scale * sum(p.abs().sum() for p in self.parameters())
+        return _l1(self, self.reg_scale)
 
     def forward(self, pupil_center: torch.Tensor):
         if pupil_center.is_cuda and len(self.mlp) == 6:
@@ -112,27 +123,21 @@ class CoreShifters(nn.ModuleDict):
 
 
 class ImageShifter(nn.Module):
-    """reference image_cropper.py:10-47: (pupil | behaviour + pupil) -> hidden -> ... -> 2 tanh MLP whose output, scaled
-    by max_shift, moves the crop window. O(B) work on 10-wide layers: torch ops."""
+    """(pupil | behaviour + pupil) -> crop-window offset in [-max_shift, max_shift]^2 (reference image_cropper.py:10-47):
+    the same tanh MLP shape as the core shifter with 10 hidden units, scaled by `max_shift`. O(B) work: torch ops."""
 
     def __init__(self, args, max_shift: float, in_features: int, hidden_features: int, num_layers: int, name: str = "ImageShifter"):
         super().__init__()
         self.name = name
         self.register_buffer("max_shift", torch.tensor(max_shift))
         self.register_buffer("reg_scale", torch.tensor(float(args.cropper_reg_scale)))
-        out_features = in_features
-        layers = []
-        for _ in range(num_layers - 1):
-            layers.extend([nn.Linear(out_features, hidden_features), nn.Tanh()])
-            out_features = hidden_features
-        layers.extend([nn.Linear(out_features, 2), nn.Tanh()])
-        self.mlp = nn.Sequential(*layers)
+        self.mlp = _tanh_mlp([in_features] + [hidden_features] * (num_layers - 1) + [2])
 
     def regularizer(self):
-        return self.reg_scale * sum(p.abs().sum() for p in self.parameters())
+        return _l1(self, self.reg_scale)
 
     def forward(self, behaviors: torch.Tensor, pupil_centers: torch.Tensor):
-        return self.mlp(torch.concat((behaviors, pupil_centers), dim=-1)) * self.max_shift
+        return self.max_shift * self.mlp(torch.cat((behaviors, pupil_centers), dim=-1))
 
 
 def _crop_nearest(inputs: torch.Tensor, grid: torch.Tensor, shifts: t.Optional[torch.Tensor]) -> torch.Tensor:
@@ -155,38 +160,33 @@ class ImageCropper(nn.Module):
     by the learned ImageShifter for shift_mode 1/3/4), bilinear 144x256 -> 36x64 (torchvision Resize(antialias=False)
     == F.interpolate(bilinear, align_corners=False)), optional behaviour-as-channels (behavior_mode 1)."""
 
+    RESIZED = (36, 64)  # what the cropper hands to the core for the Sensorium recordings (image_cropper.py:96-99)
+
     def __init__(self, args, ds: t.Dict[str, t.Any]):
         super().__init__()
-        self.shift_mode = args.shift_mode
+        self.shift_mode, self.behavior_mode = args.shift_mode, args.behavior_mode
         self.input_shape = args.input_shape
-        self.behavior_mode = args.behavior_mode
-        c, in_h, in_w = args.input_shape
-        out_h, out_w = in_h, in_w
-        if self.behavior_mode == 1:
-            c += 3
+        channels, height, width = args.input_shape
+        scale = float(args.center_crop)
         self.crop_scale = args.center_crop
-        self.crop_h, self.crop_w = in_h, in_w
-        if self.crop_scale < 1:
-            out_h = self.crop_h = int(in_h * self.crop_scale)
-            out_w = self.crop_w = int(in_w * self.crop_scale)
-        h_pixels = torch.linspace(-self.crop_scale, self.crop_scale, self.crop_h)
-        w_pixels = torch.linspace(-self.crop_scale, self.crop_scale, self.crop_w)
-        mesh_y, mesh_x = torch.meshgrid(h_pixels, w_pixels, indexing="ij")
-        self.register_buffer("grid", torch.stack((mesh_x, mesh_y), dim=2).unsqueeze(0))
+        # window of the crop: the full frame, or int(scale * size) pixels spanning [-scale, scale] of the normalised frame
+        self.crop_h = height if scale >= 1 else int(height * scale)
+        self.crop_w = width if scale >= 1 else int(width * scale)
+        ys = torch.linspace(-scale, scale, self.crop_h)
+        xs = torch.linspace(-scale, scale, self.crop_w)
+        # grid[0, i, j] = (x_j, y_i): the (1, h, w, 2) sampling grid F.grid_sample expects; state-dict key `image_cropper.grid`
+        self.register_buffer("grid", torch.stack((xs[None, :].expand(self.crop_h, -1), ys[:, None].expand(-1, self.crop_w)), dim=-1)[None].contiguous())
+        # learned per-mouse window shift: shift_mode 1 / 3 see the pupil centre (2), shift_mode 4 behaviours + pupil centre (5)
         self.image_shifter = None
         if self.shift_mode in (1, 3, 4):
-            max_shift = 1 - self.crop_scale
-            in_features = 5 if self.shift_mode == 4 else 2  # image_cropper.py:76-79
-            self.image_shifter = nn.ModuleDict({
-                mouse_id: ImageShifter(args, max_shift=max_shift, in_features=in_features, hidden_features=10, num_layers=3,
-                                       name=f"Mouse{mouse_id}ImageShifter")
-                for mouse_id in ds.keys()
-            })
-        self.resize = None
-        if args.resize_image == 1 and args.ds_name != "franke2022":
-            out_h, out_w = 36, 64
-            self.resize = (out_h, out_w)
-        self.output_shape = (c, out_h, out_w)
+            n_in = 5 if self.shift_mode == 4 else 2
+            self.image_shifter = nn.ModuleDict()
+            for mouse_id in ds.keys():
+                self.image_shifter[mouse_id] = ImageShifter(args, max_shift=1 - scale, in_features=n_in, hidden_features=10, num_layers=3,
+                                                            name=f"Mouse{mouse_id}ImageShifter")
+        self.resize = self.RESIZED if (args.resize_image == 1 and args.ds_name != "franke2022") else None
+        out_h, out_w = self.resize if self.resize is not None else (self.crop_h, self.crop_w)
+        self.output_shape = (channels + (3 if self.behavior_mode == 1 else 0), out_h, out_w)
 
     def regularizer(self, mouse_id: str):
         return 0 if self.image_shifter is None else self.image_shifter[mouse_id].regularizer()
@@ -233,7 +233,7 @@ class Model(nn.Module):
         self.add_module("readouts", Readouts(args, model=args.readout, input_shape=self.core.output_shape, output_shapes=self.output_shapes, ds=ds))
         self.elu1 = ELU1()
         self._mouse_arenas: t.Dict[str, FlatArena] = {}
-        self._mouse_l1: t.Dict[str, t.Tuple[int, t.List[t.Tuple[int, int, float]]]] = {}
+        self._mouse_l1: t.Dict[str, t.Tuple[int, t.List[t.Tuple[int, int, float, str]]]] = {}
         self._streams: t.List[t.Any] = []
         self.readout_streams = os.environ.get("V1T_READOUT_STREAMS", "1") != "0"
         if self.readout_streams and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
@@ -250,10 +250,11 @@ class Model(nn.Module):
         if not self.core.frozen:
             params.append({"params": self.core.parameters(), "lr": core_lr, "name": "core"})
         params.append({"params": self.readouts.parameters(), "name": "readouts"})
-        if self.core_shifter is not None:
-            params.append({"params": self.core_shifter.parameters(), "name": "core_shifter"})
+        # group ORDER matters: torch optimizer state dicts are positional (golden G12 pins it for shift_mode 2 and 4)
         if self.image_cropper.image_shifter is not None:
             params.append({"params": self.image_cropper.parameters(), "name": "image_cropper"})
+        if self.core_shifter is not None:
+            params.append({"params": self.core_shifter.parameters(), "name": "core_shifter"})
         return params
 
     def regularizer(self, mouse_id: str):
@@ -335,31 +336,37 @@ class Model(nn.Module):
         a.ensure()
         return a
 
-    def mouse_l1_ranges(self, mouse_id: str) -> t.List[t.Tuple[int, int, float]]:
-        """(start, n, coefficient) runs over the mouse arena for the fused L1 + AdamW step: the terms Model.regularizer
-        adds for this mouse (readout features gaussian2d.py:233-234, core shifter core_shifter.py:21-22, image shifter
-        image_cropper.py:38-39); everything else coefficient 0."""
+    def mouse_step_ranges(self, mouse_id: str) -> t.List[t.Tuple[int, int, float, str]]:
+        """(start, n, L1 coefficient, optimizer group) runs over the mouse arena for the fused L1 + AdamW step. The
+        coefficients are the terms Model.regularizer adds for this mouse (readout features gaussian2d.py:99-100, core
+        shifter core_shifter.py:21-22, image shifter image_cropper.py:38-39; 0 elsewhere); the group name selects the
+        learning rate (model.py:112-139: readouts / image_cropper / core_shifter are separate optimizer groups)."""
         a = self.mouse_arena(mouse_id)
         cached = self._mouse_l1.get(mouse_id)
         if cached is not None and cached[0] == a.generation:
             return cached[1]
         ro = self.readouts[mouse_id]
-        coeff = {id(ro.features): float(ro.reg_scale)}  # reg_scale buffers live on the device: read them once, not per step
+        tag = {id(p): (0.0, "readouts") for p in ro.parameters()}
+        tag[id(ro.features)] = (float(ro.reg_scale), "readouts")  # reg_scale buffers live on the device: read once, not per step
         if self.core_shifter is not None:
             cs = self.core_shifter[mouse_id]
             c = float(cs.reg_scale)
-            coeff.update({id(p): c for p in cs.parameters()})
+            tag.update({id(p): (c, "core_shifter") for p in cs.parameters()})
         if self.image_cropper.image_shifter is not None:
             sh = self.image_cropper.image_shifter[mouse_id]
             c = float(sh.reg_scale)
-            coeff.update({id(p): c for p in sh.parameters()})
-        runs: t.List[t.List[float]] = []
+            tag.update({id(p): (c, "image_cropper") for p in sh.parameters()})
+        runs: t.List[list] = []
         for s in a.slots:
-            c = coeff.get(id(s.tensor), 0.0)
-            if runs and runs[-1][2] == c and runs[-1][0] + runs[-1][1] == s.offset:
+            c, grp = tag[id(s.tensor)]
+            if runs and runs[-1][2] == c and runs[-1][3] == grp and runs[-1][0] + runs[-1][1] == s.offset:
                 runs[-1][1] += s.numel
             else:
-                runs.append([s.offset, s.numel, c])
-        out = [(int(o), int(n), float(c)) for o, n, c in runs]
+                runs.append([s.offset, s.numel, c, grp])
+        out = [(int(o), int(n), float(c), str(g)) for o, n, c, g in runs]
         self._mouse_l1[mouse_id] = (a.generation, out)
         return out
+
+    def mouse_l1_ranges(self, mouse_id: str) -> t.List[t.Tuple[int, int, float]]:
+        """(start, n, L1 coefficient) runs of `mouse_step_ranges`."""
+        return [(o, n, c) for o, n, c, _ in self.mouse_step_ranges(mouse_id)]

@@ -53,7 +53,7 @@ class FusedAdamW:
     def _slots(self) -> t.Dict[int, t.Tuple[t.Any, t.Any]]:
         """id(parameter) -> (arena, slot) over the core arena and every mouse arena"""
         m = self.model
-        m.core.prepare()
+        m.core._arena.ensure()  # flat storage only: no kernel launch, works on a CPU model too
         arenas = [m.core._arena] + [m.mouse_arena(k) for k in m.readouts.keys()]
         return {id(s.tensor): (a, s) for a in arenas for s in a.slots}
 
@@ -73,32 +73,50 @@ class FusedAdamW:
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd: t.Dict[str, t.Any]) -> None:
-        if len(sd["param_groups"]) != len(self.param_groups):
+        """torch.optim.AdamW-format state. Groups are matched BY NAME when the file names them (the reference does,
+        model.py:112-139), by position otherwise; every moment's shape is checked against its parameter before anything
+        is copied, so a file with another group order or another model fails instead of swapping moments silently."""
+        saved_groups = sd["param_groups"]
+        if len(saved_groups) != len(self.param_groups):
             raise ValueError("loaded state dict has a different number of parameter groups")
+        if all("name" in g for g in saved_groups):
+            by_name = {g["name"]: g for g in saved_groups}
+            if len(by_name) != len(saved_groups) or set(by_name) != {g["name"] for g in self.param_groups}:
+                raise ValueError(f"parameter groups {sorted(by_name)} do not match {[g['name'] for g in self.param_groups]}")
+            pairs = [(g, by_name[g["name"]]) for g in self.param_groups]
+        else:
+            pairs = list(zip(self.param_groups, saved_groups))
         slots = self._slots()
-        i = 0
-        steps: t.Dict[int, int] = {}
-        for g, saved in zip(self.param_groups, sd["param_groups"]):
+        todo = []
+        for g, saved in pairs:
             if len(saved["params"]) != len(g["params"]):
-                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
-            g["lr"] = float(saved["lr"])
+                raise ValueError(f"group {g['name']}: loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
             for p, j in zip(g["params"], saved["params"]):
-                a, s = slots[id(p)]
                 st = sd["state"].get(j, sd["state"].get(str(j)))
-                if st is not None:
-                    m_, v_ = a.moments()
-                    s.view(m_[s.offset:s.offset + s.numel]).copy_(st["exp_avg"].to(m_.device))
-                    s.view(v_[s.offset:s.offset + s.numel]).copy_(st["exp_avg_sq"].to(v_.device))
-                    steps.setdefault(id(a), int(float(st["step"])))
-                    a.step = steps[id(a)]
-                i += 1
+                if st is None:
+                    continue
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if tuple(st[k].shape) != tuple(p.shape):
+                        raise ValueError(f"group {g['name']}: {k} of saved parameter {j} has shape {tuple(st[k].shape)}, the parameter {tuple(p.shape)}")
+                todo.append((slots[id(p)], st))
+        steps: t.Dict[int, int] = {}
+        for (a, s), st in todo:
+            m_, v_ = a.moments()
+            s.view(m_[s.offset:s.offset + s.numel]).copy_(st["exp_avg"].to(m_.device))
+            s.view(v_[s.offset:s.offset + s.numel]).copy_(st["exp_avg_sq"].to(v_.device))
+            n = int(float(st["step"]))
+            if steps.setdefault(id(a), n) != n:
+                raise ValueError("parameters of one arena carry different step counts")
+            a.step = n
+        for g, saved in pairs:
+            g["lr"] = float(saved["lr"])
 
-    def step_arena(self, arena, lr: float, ranges: t.Sequence[t.Tuple[int, int, float]], zero_grad: bool = True) -> None:
-        """ranges: (start, n, l1_coeff) in floats; all ranges of one arena share its step counter."""
+    def step_arena(self, arena, ranges: t.Sequence[t.Tuple[int, int, float, float]], zero_grad: bool = True) -> None:
+        """ranges: (start, n, l1_coeff, lr) in floats; all ranges of one arena share its step counter."""
         arena.step += 1
         m, v = arena.moments()
         lib = L.load()
-        for start, n, l1 in ranges:
+        for start, n, l1, lr in ranges:
             if n <= 0:
                 continue
             o = 4 * start
@@ -171,12 +189,12 @@ class Trainer:
             ca = core._arena
             if self._core_l1 is None:  # the reg_scale buffer lives on the device: one read, not one sync per step
                 self._core_l1 = float(core.reg_scale) * len(self.mouse_ids)
-            self.opt.step_arena(ca, self.opt.group_lr("core"), [(0, ca.param_floats, self._core_l1)])
+            self.opt.step_arena(ca, [(0, ca.param_floats, self._core_l1, self.opt.group_lr("core"))])
             core.mark_updated()
         for mouse_id in self.sharding.local_mice():
             a = model.mouse_arena(mouse_id)
-            # readout / shifter groups start at the same lr and are only ever scaled together (scheduler.py:158-168)
-            self.opt.step_arena(a, self.opt.group_lr("readouts"), model.mouse_l1_ranges(mouse_id))
+            # one launch per (L1 coefficient, optimizer group) run: readouts / image_cropper / core_shifter keep their own lr
+            self.opt.step_arena(a, [(o, n, c, self.opt.group_lr(g)) for o, n, c, g in model.mouse_step_ranges(mouse_id)])
         return {"loss": torch.stack(losses).sum() if losses else torch.zeros((), device=core._arena.data.device)}
 
     @torch.no_grad()
