@@ -116,8 +116,8 @@ def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
     if lsa and T > 1:  # the scale is a learnable parameter only with LSA (vit.py:235-239)
         assert rel_to_max(dscale.cpu(), gs.cpu()) < 2e-2
     if not lsa:
-        # materialised-dS' path (dK/dV kernel writes dS', dQ = dS' . K as a GEMM): dK / dV bit-identical to the recompute path
-        # (same kernel body), dQ sums the same bf16 products in another order
+        # materialised-dS' path (producer / consumer dK/dV kernel writes dS', dQ = dS' . K as a GEMM): same bf16 products as
+        # the recompute path, summed in another order
         nb = int(lib.v1t_attention_backward_ws_bytes(B, H, T))
         ws = torch.full((nb,), 0xFF, dtype=torch.uint8, device=dev)  # NaN patterns: every element read must have been written
         d2 = torch.zeros_like(dqkv)
@@ -126,10 +126,10 @@ def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
                                                   delta.data_ptr(), out.data_ptr(), None, ws.data_ptr(), nb, L.stream()))
         assert torch.equal(d2, out)  # bit-reproducible
         e = d2.float().view(B * T, 3, H * DP)
-        assert torch.equal(e[:, 1:], d[:, 1:])
-        if float(gq[:, 0].abs().max()) > 0:
-            assert rel_to_max(e[:, 0].cpu(), gq[:, 0].cpu()) < 2e-2
-            assert rel_to_max(e[:, 0].cpu(), d[:, 0].cpu()) < 1e-2
+        for i, nm in enumerate("qkv"):
+            if float(gq[:, i].abs().max()) > 0:
+                assert rel_to_max(e[:, i].cpu(), gq[:, i].cpu()) < 2e-2, nm
+                assert rel_to_max(e[:, i].cpu(), d[:, i].cpu()) < 1e-2, nm
 
 
 @pytest.mark.parametrize("B,C,H,W,N", [(3, 155, 29, 57, 1000), (2, 64, 29, 57, 257), (1, 40, 15, 29, 3), (2, 155, 5, 7, 900)])

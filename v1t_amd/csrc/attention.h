@@ -22,13 +22,19 @@ struct AttnArgs {
     const float* delta;            // [B][H][T] keep_prob * rowsum(dO * O)
     bf16_t* dqkv; int lddqkv;      // [rows][3*H*DP]
     float* dscale;                 // [H] fp32 atomics or nullptr (LSA scale gradient)
-    // optional scratch of attn_ds_bytes(): the dK/dV kernel writes dS' = P (dP - delta) there, tile-major
-    // [B*H][128-query tile][64-key tile][128][64] bf16 with ldds = attn_ds_ld(T) key columns, and dQ = dS' . K becomes one
-    // streaming GEMM instead of a second recomputation of S and dP (5 products instead of 7)
+    // optional scratch of attn_ds_bytes(): the dK/dV kernel writes the bf16 dS' = P (dP - delta) there and dQ = dS' . K becomes
+    // one streaming GEMM instead of a second recomputation of S and dP (5 MFMA products instead of 7). Layout (attention.hip,
+    // "producer / consumer backward"): [B*H][32-query block][32-key block][k-step 2][lane 64][8] bf16 - a 32 x 32 block is the
+    // 2 KB the consumer wave holds as its two B-operand fragments (key on the lane), stored with two 16-B-per-lane instructions.
+    // Behind it: the padded per-row constants [B*H][TPq] fp32 each, nlse = -lse2 / (scale log2 e) and ndelta = -keep_prob *
+    // rowsum(dO * O) (pad rows: nlse = -1e30, so P = 0 there), written by the delta kernel.
     bf16_t* ds; int ldds;
 };
-inline int attn_ds_ld(int T) { return (T + 127) / 128 * 128; }
-inline size_t attn_ds_bytes(int B, int H, int T) { return (size_t)B * H * ((T + 127) / 128 * 128) * attn_ds_ld(T) * 2; }
+__host__ __device__ inline int attn_ds_ld(int T) { return (T + 127) / 128 * 128; }             // key columns covered (128-key workgroups)
+__host__ __device__ inline int attn_ds_tpq(int T) { return (T + 31) / 32 * 32; }               // query rows covered (32-query blocks)
+__host__ __device__ inline size_t attn_ds_elems(int B, int H, int T) { return (size_t)B * H * attn_ds_tpq(T) * attn_ds_ld(T); }
+__host__ __device__ inline size_t attn_rc_floats(int B, int H, int T) { return (size_t)B * H * attn_ds_tpq(T); }
+inline size_t attn_ds_bytes(int B, int H, int T) { return attn_ds_elems(B, H, T) * 2 + 2 * attn_rc_floats(B, H, T) * 4; }
 
 int launch_attn_fwd(const AttnArgs& a, int DP, hipStream_t s);
 int launch_attn_delta(const AttnArgs& a, int DP, float* delta, hipStream_t s);

@@ -625,7 +625,7 @@ DEVFN void attn_bwd_dq_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& ld
 }
 
 // ------------------------------------------------------------------------------------------
-template <int DP, bool DROP, bool DIAG, bool STORE = false>
+template <int DP, bool DROP, bool DIAG>
 DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& lds) {
     using G = Geo<DP>;
     constexpr int TR = BWD_TR;  // 64-query tiles = two independent 32-query halves (see the dQ kernel)
@@ -749,37 +749,12 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
             dv[d] = mfma32(tdf[2 * d + 1], p1, dv[d]);
         }
     };
-    // STORE: the bf16 dS' that feeds dK also goes to HBM, row-major [query][key], for the dQ GEMM. A lane owns its key
-    // column; element j of k-step sx is query row 16 sx + 8 (j >> 2) + 4 h2 + (j & 3) of the 32-query half, so one store
-    // instruction writes two query rows x 32 consecutive keys (64 B each). Uniform row base in SGPRs, lane offset fixed.
-    // Layout: [image, head][128-query tile][64-key tile][128 rows][64 keys]: a block is 16 KB contiguous, so both this
-    // kernel's stores and the GEMM's reads are long runs (row-major [T][T] made every access a 64..128 B piece at a
-    // 3.3 KB stride). This wave's 32 keys lie in one key tile; per 32-query half the 16 stores differ by an immediate.
-    const int nkt_ds = STORE ? a.ldds / 64 : 0, nqt_ds = (a.T + 127) / 128;
-    const int ktile = (rb * 128 + 32 * wave) >> 6;
-    const unsigned ds_lane = STORE ? (unsigned)((4 * h2 * 64 + ((32 * wave + (lane & 31)) & 63)) * 2) : 0u;
-    const char* ds_bh = STORE ? (const char*)(a.ds + ((size_t)(b * a.H + h) * nqt_ds * nkt_ds + ktile) * (128 * 64)) : nullptr;
-    const unsigned kmask = kok ? 0xFFFFFFFFu : 0u;  // keys beyond T: zeros (the GEMM multiplies them with clamped K rows)
-    auto store_ds = [&](const bf16x8& v, int qt, int hf, int sx) {
-        u32x4 w = __builtin_bit_cast(u32x4, v);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] &= kmask;
-        const bf16x8 z = __builtin_bit_cast(bf16x8, w);
-        // block of query tile qt >> 1 (TR = 64: two steps per 128-query tile); rows beyond T exist in the block (p = 0 there)
-        char* base = const_cast<char*>(ds_bh) + (size_t)(qt >> 1) * nkt_ds * (128 * 64 * 2) + ((qt & 1) * 64 + 32 * hf) * 128;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *(bf16_t*)(base + ds_lane + (16 * sx + 8 * (j >> 2) + (j & 3)) * 128) = z[j];
-    };
     auto phase3_k = [&](auto tail_tag, const bf16x8 (&tqf)[2 * G::DB], const f32x16& s, int qt, int hf) {
         const bf16x8 s0 = acc_to_b_pk(s, 0), s1 = acc_to_b_pk(s, 1);
 #pragma unroll
         for (int d = 0; d < G::DB; ++d) {
             dk[d] = mfma32(tqf[2 * d], s0, dk[d]);
             dk[d] = mfma32(tqf[2 * d + 1], s1, dk[d]);
-        }
-        if constexpr (STORE) {
-            store_ds(s0, qt, hf, 0);
-            store_ds(s1, qt, hf, 1);
         }
     };
     // One wave per SIMD issues in order, and an MFMA keeps the issue port only 8 of its 32 cycles: the
@@ -889,83 +864,530 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(AttnArgs a, int 
     }
 }
 
-// dK/dV alone, materialising dS' (AttnArgs::ds) ...
-template <int DP, bool DROP>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_store_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) BwdLds<DP> lds;
-    attn_bwd_dkv_body<DP, DROP, false, true>(a, blockIdx.x, gridDim.x, lds);
-}
-// ... and dQ^T += K^T . dS'^T as a streaming GEMM over it: workgroup = NW waves x 32 queries of one (image, head),
-// 64-key stages of dS' ((128 q, 64 k) blocks) and K [64 k][DP] by LDS-DMA, double buffered. Bound by reading dS' from HBM
-// (2 B per (query, key), stored tile-major so that a stage reads contiguous 16 KB blocks) plus the K tiles from L2, which every
-// workgroup of an (image, head) re-reads: NW = 8 (256 queries share a K tile) halves that L2 traffic.
-template <int DP, int NW, int KT>
-__global__ __launch_bounds__(64 * NW, (NW == 4 || KT == 32) ? 2 : 1) void attn_bwd_dq_gemm_kernel(AttnArgs a) {
-    using G = Geo<DP>;
-    constexpr int SSTR = KT + 8, QB = 32 * NW, BK = 64;  // BK: key width of a stored dS' block; KT: keys per stage (32: half a block)
-    using DmaS = TileDma<KT, SSTR, 128, NW>;
-    using DmaK = TileDma<DP, G::RSTR, KT, NW>;
-    __shared__ __attribute__((aligned(16))) bf16_t sS[2][NW / 4][DmaS::LDS_ELEMS];
-    __shared__ __attribute__((aligned(16))) bf16_t sK[2][DmaK::LDS_ELEMS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int rb, h, b;
-    decode_block(a, blockIdx.x, gridDim.x, rb, h, b, QB);
-    const int q = rb * QB + 32 * wave + (lane & 31);
-    const int h2 = lane >> 5;
-    DmaS dmaS;
-    DmaK dmaK;
-    dmaS.init(lane, wave, BK);  // tile-major dS': a (128 q, 64 k) block is 16 KB contiguous, rows 64 elements apart
-    dmaK.init(lane, wave, a.ldqkv);
-    const bf16_t* kbase = a.qkv + (size_t)b * a.T * a.ldqkv + a.H * DP + h * DP;
-    const int nkt = a.ldds / BK, nqt = (a.T + 127) / 128;
-    const int qt0 = rb * (NW / 4);  // first 128-query tile of this workgroup
-    const bf16_t* sbase = a.ds + ((size_t)(b * a.H + h) * nqt + qt0) * nkt * (128 * BK);
-    const bool second = NW == 8 && qt0 + 1 < nqt;  // the last workgroup of an odd tile count has one tile only
-    f32x16 dq[G::DB];
+// ------------------------------------------------------------------------------------------
+// Producer / consumer backward (default path: DP >= 128, no LSA diagonal): dK / dV + materialised dS', then dQ = dS' . K.
+//
+// Why: in the one-wave-per-SIMD kernels above every MFMA of a 512-register kernel is selected in AGPR form, so each
+// S / dP element is moved AGPR -> VGPR (and P / dS' operands back) around the element-wise stage: of ~1100 vector
+// instructions per 64 x 32 tile only ~570 are arithmetic (ISA count), and a lone wave issues one vector instruction per
+// ~4.5 cycles whatever its kind (tools/microbench/valu_issue_cost.hip) - 35 % matrix-pipe occupancy. Here a workgroup is
+// 8 waves with <= 256 registers each (two per SIMD, all MFMAs in VGPR form, no accumulator copies), split by ROLE:
+//   waves 0-3 ("producers"): 32 keys each; K / V fragments stay in registers; per 32-query block S = Q K^T and dP = dO V^T
+//       (20 MFMAs, key on the lane, accumulators initialised with the row constants -lse2/c and -delta so that
+//       P = exp2(c S') needs no subtraction), the element-wise stage, and the bf16 P / dS' fragments - exactly the
+//       B operands of the next two products - handed to the partner wave through LDS (lane l writes 4 x 16 B, lane l of
+//       the partner reads them back: no transposition);
+//   waves 4-7 ("consumers", SIMD partners of 0-3): dV^T += dO^T P, dK^T += Q^T dS' (20 MFMAs, 160 accumulator
+//       registers), the dS' block stored to HBM as two 16-B-per-lane instructions (the old kernel: 16 two-byte stores),
+//       and all LDS-DMA staging (Q / dO tiles of 32 rows into a 4-slot ring, two tiles ahead, counted vmcnt).
+// One barrier per 32-query block; the consumer works one block behind the producer. The matrix pipe of a SIMD then sees
+// 40 MFMAs per block from two waves whose element-wise / LDS phases overlap the partner's MFMAs.
+constexpr int B2_SLOTS = 5;  // tiles live at step i: i - 1 (consumer), i (waits for the consumer), i + 1 (producer), i + 2 (landing), i + 3 (being issued)
+template <int DP>
+struct Bwd2Lds {
+    using Dma = TileDma<DP, Geo<DP>::RSTR, 32, 4>;
+    bf16_t q[B2_SLOTS][Dma::LDS_ELEMS];
+    bf16_t d[B2_SLOTS][Dma::LDS_ELEMS];
+    float rc[B2_SLOTS][64];   // [0, 32): -lse2 of the slot's queries, [32, 64): -keep_prob * delta
+    u32x4 hand[2][4][4][64];  // [block parity][pair][P k-step 0, P k-step 1, dS' k-step 0, dS' k-step 1][lane]
+    u32x4 keep[2][4][2][64];  // [block parity][pair][row groups 0-1, 2-3][lane]: dropout keep words, consumer -> producer
+};
+
+// row constants for the kernel below, padded to 32-query blocks: pad rows get nlse = -1e30 (P = 0), ndelta = 0.
+// 16 lanes per (row, head) segment, as attn_delta_kernel.
+template <int DP>
+__global__ __launch_bounds__(256) void attn_delta2_kernel(AttnArgs a, float* nlse, float* ndelta, int TPQ) {
+    constexpr int CH = DP / 8;
+    const int sub = threadIdx.x & 15;
+    const long long seg = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const long long total = (long long)a.B * TPQ * a.H;
+    const bool ok = seg < total;
+    const int h = ok ? (int)(seg % a.H) : 0;
+    const long long rowp = ok ? seg / a.H : 0;  // padded row index b * TPQ + t
+    const long long b_ = rowp / TPQ;
+    const int t = (int)(rowp % TPQ);
+    const bool real = ok && t < a.T;
+    const long long row = b_ * a.T + (real ? t : 0);
+    const bf16_t* po = a.o + (size_t)row * a.ldo + h * DP;
+    const bf16_t* pd = a.dO + (size_t)row * a.lddo + h * DP;
+    float acc = 0.f;
+    if (real) {
 #pragma unroll
-    for (int d = 0; d < G::DB; ++d) zero16(dq[d]);
-    const int soff = (32 * (wave & 3) + (lane & 31)) * SSTR + 4 * h2;
-    const int toff = tr_lane_off(lane, G::RSTR);
-    const int nt = a.ldds / KT;  // every key column up to ldds was written (zeros beyond T)
-    auto stage = [&](int kt, int buf) {
-        const size_t blk = (size_t)(kt * KT / BK) * (128 * BK) + (kt * KT) % BK;  // block of this stage + key offset inside it
-        dmaS.issue(sbase + blk, 0, 128, sS[buf][0]);
-        if constexpr (NW == 8) {
-            if (second) dmaS.issue(sbase + (size_t)nkt * (128 * BK) + blk, 0, 128, sS[buf][1]);
+        for (int c = sub; c < CH; c += 16) {
+            const bf16x8 x = *(const bf16x8*)(po + 8 * c);
+            const bf16x8 y = *(const bf16x8*)(pd + 8 * c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
         }
-        dmaK.issue(kbase, KT * kt, a.T, sK[buf]);
-    };
-    stage(0, 0);
-    dma_wait_and_barrier();
-    for (int kt = 0; kt < nt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nt) stage(kt + 1, buf ^ 1);
-        const bf16_t* sp = &sS[buf][wave >> 2][soff];
-        const bf16_t* tk = &sK[buf][toff];
-#pragma unroll
-        for (int ks = 0; ks < KT / 16; ++ks) {
-            // B operand = dS'^T, k order of tr_frag / acc_to_b: slot j of lane half h2 is key 16 ks + 8 (j >> 2) + 4 h2 + (j & 3)
-            const bf16x4 lo = *(const bf16x4*)(sp + 16 * ks), hi = *(const bf16x4*)(sp + 16 * ks + 8);
-            bf16x8 bfr;
-            bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
-            bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
-#pragma unroll
-            for (int d = 0; d < G::DB; ++d) dq[d] = mfma32(tr_frag<G::RSTR>(tk, 16 * ks, 32 * d), bfr, dq[d]);
-        }
-        dma_wait_and_barrier();
     }
-    if (q < a.T) {
-        const float f = a.scale[a.scale_per_head ? h : 0] * (a.adrop.thresh8 ? a.adrop.inv_keep : 1.0f);
-        bf16_t* orow = a.dqkv + ((size_t)b * a.T + q) * a.lddqkv + h * DP;
+    acc += __shfl_xor(acc, 8);
+    acc += __shfl_xor(acc, 4);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 1);
+    if (ok && sub == 0) {
+        const size_t o = ((size_t)b_ * a.H + h) * TPQ + t;
+        nlse[o] = real ? -a.lse2[((size_t)b_ * a.H + h) * a.T + t] : NEG_BIG;
+        ndelta[o] = real ? -acc * a.adrop.keep_prob : 0.f;
+    }
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform n (the immediate must be a literal)
+DEVFN void wait_vmcnt_dyn(int n) {
+    switch (n) {
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+// raw barrier: waits for this wave's LDS operations only (a __syncthreads() would also drain the LDS-DMA queue)
+DEVFN void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+DEVFN int b2_slot(int t) { return t - B2_SLOTS * (t / B2_SLOTS); }
+
+#ifdef V1T_KCLK
+__device__ unsigned long long g_kclk[4];  // dev: shader cycles / 100 MHz ticks of one workgroup of the kernel below
+#endif
+template <int DP, bool DROP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
+    using G = Geo<DP>;
+    using Dma = typename Bwd2Lds<DP>::Dma;
+    static_assert(Dma::PW == 3, "three DMA pieces per wave and tile");
+    __shared__ __attribute__((aligned(16))) Bwd2Lds<DP> lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef V1T_KCLK
+    const unsigned long long kclk_c0 = __builtin_amdgcn_s_memtime(), kclk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int pw = wave & 3;  // pair: producer pw and consumer pw + 4 own keys [32 pw, 32 pw + 32) of the 128-key block
+    int rb, h, b;
+    decode_block(a, blockIdx.x, gridDim.x, rb, h, b);
+    const int key = rb * 128 + 32 * pw + (lane & 31);
+    const int h2 = lane >> 5;
+    const int HD = a.H * DP;
+    const bool kok = key < a.T;
+    const int nq = (a.T + 31) / 32;        // 32-query blocks
+    const int TPQ = 32 * nq;
+    const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
+    const size_t bh = (size_t)b * a.H + h;
+
+    // ---- LDS-DMA staging of the 32-row Q / dO tiles, one piece (1 KiB, one instruction) per call. Wave pair pw owns pieces
+    // 3 pw .. 3 pw + 2 of each tile (TileDma's split): the consumer stages its Q pieces, the producer its dO pieces, so both
+    // roles carry half of the issue cost (~100 cycles a piece). The third piece of pair 3 does not exist (10.5 pieces per
+    // tile): its consumer stages the row constants instead, its producer repeats piece 1 - every wave issues exactly 3
+    // operations per tile and the end-of-step vmcnt is one immediate.
+    const bool last = pw == 3;  // wave-uniform
+    auto lane_off = [&](int i, int ld, int max_row) {  // byte offset of this lane's 16 B of piece i inside the tile's rows
+        const int p = 64 * (pw * Dma::PW + i) + lane;
+        const int r = min(p / Dma::CPR, max_row), cc = min(p % Dma::CPR, DP / 8 - 1);
+        return (unsigned)((r * ld + 8 * cc) * 2);
+    };
+    auto dma16 = [&](const void* gbase, unsigned voff, const void* lds_dst) {  // scalar base + lane offset, 16 B per lane
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_dst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(gbase) : "memory");
+    };
+    auto dma4 = [&](const void* gbase, unsigned voff, const void* lds_dst) {  // 4 B per lane (row constants)
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_dst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(gbase) : "memory");
+    };
+    const bf16_t* const img = wave < 4 ? a.dO + (size_t)b * a.T * a.lddo + h * DP : qkv_b + h * DP;  // this wave's tile source
+    const int ld = wave < 4 ? a.lddo : a.ldqkv;
+    unsigned voff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) voff[i] = lane_off(i, ld, 31);
+    const float* rcg = (const float*)(a.ds + attn_ds_elems(a.B, a.H, a.T)) + bh * TPQ;  // nlse; ndelta B*H*TPQ floats behind it
+    const unsigned rc_voff = (unsigned)(((lane & 31) + (h2 ? attn_rc_floats(a.B, a.H, a.T) : 0)) * 4);
+    auto stage = [&](int t) {  // this wave's three operations of tile t
+        const int slot = b2_slot(t);
+        bf16_t* tile = wave < 4 ? lds.d[slot] : lds.q[slot];
+        const bf16_t* src = img + (size_t)32 * t * ld;
+        unsigned v[3] = {voff[0], voff[1], voff[2]};
+        if (32 * t + 32 > a.T) {
+            asm volatile("; ragged tile: rows beyond T are clamped to T - 1 (finite data; P = 0 there)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[i] = lane_off(i, ld, a.T - 1 - 32 * t);
+        }
+        dma16(src, v[0], tile + 512 * (3 * pw));
+        dma16(src, v[1], tile + 512 * (3 * pw + 1));
+        if (!last) dma16(src, v[2], tile + 512 * (3 * pw + 2));
+        else if (wave < 4) dma16(src, v[1], tile + 512 * (3 * pw + 1));
+        else dma4(rcg + 32 * t, rc_voff, lds.rc[slot]);  // lanes 0-31: -lse2/c -> rc[0..31], lanes 32-63: -keep_prob delta -> rc[32..63]
+    };
+
+    // ---- dropout of P (common.h): the lane's fixed coordinate is its key (column), the varying one the query row. A hash
+    // word serves a 2 x 2 block of (query, key); the lane's two decisions of a word sit in the bytes key & 1 and 2 + (key & 1),
+    // so after a shift by 8 (key & 1) both are decided by ONE 9-bit SWAR compare: ((w & 0x00FF00FF) | 0x01000100) - thr * 0x00010001
+    // has bit 8 / bit 24 set iff byte 0 / byte 2 >= thr (keep). The CONSUMER evaluates this for block i + 1 in the shadow of
+    // its MFMAs (8 words per block: row pairs (8 g + 4 h2 + 2 u, + 1), word index 2 g + u) and hands the 8 words to the
+    // producer through LDS, where a decision then costs a 1-bit v_bfe_i32 and a v_and instead of hash + compare + select.
+    const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
+    const uint32_t dbase = a.adrop.key + ((uint32_t)bh * T2 + (uint32_t)(2 * h2)) * ADROP_K1 + ((uint32_t)key >> 1) * ADROP_K2;
+    const uint32_t dshift = 8 * (key & 1);
+    const uint32_t dthr = a.adrop.thresh8 * 0x00010001u;
+    auto keep_word = [&](int blk, int wi) {  // wi = 2 g + u
+        const uint32_t w = mix1(dbase + (uint32_t)(16 * blk + 4 * (wi >> 1) + (wi & 1)) * ADROP_K1) >> dshift;
+        return ((w & 0x00FF00FFu) | 0x01000100u) - dthr;
+    };
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ producer
+        // static priority over the SIMD partner: the consumer's 20 MFMAs otherwise run back to back (640 cycles, kprof
+        // timeline) while this wave - in-order, one MFMA per slot - sits behind them with its vector instructions
+        __builtin_amdgcn_s_setprio(3);
+        const float sc = a.scale[a.scale_per_head ? h : 0];
+        const float c = sc * LOG2E;
+        bf16x8 kf[G::KS], vf[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            const bf16_t* rowp = qkv_b + (size_t)key * a.ldqkv + h * DP + 16 * ks + 8 * h2;
+            u32x4 t = kok ? *(const u32x4*)(rowp + HD) : u32x4{0, 0, 0, 0};
+            kf[ks] = *(bf16x8*)&t;
+            // K is pre-multiplied by c = scale log2(e) (one bf16 rounding of c k: 2^-9 relative per term, i.e. ~1e-3 absolute on
+            // the exponent c S, a quarter of the bf16 rounding P gets anyway), so that P = exp2(S') costs no multiply per element
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kf[ks][j] = (bf16_t)((float)kf[ks][j] * c);
+            u32x4 u = kok ? *(const u32x4*)(rowp + 2 * HD) : u32x4{0, 0, 0, 0};
+            vf[ks] = *(bf16x8*)&u;
+        }
+        const int roff = (lane & 31) * G::RSTR + 8 * h2;
+        // Accumulators of S' = c Q K^T - lse2 and dP (- keep_prob delta) start from the row constants of the query block
+        // (register r <-> query row 8 (r >> 2) + 4 h2 + (r & 3))
+        auto init_rows = [&](int slot, f32x16& s, f32x16& dp, float (&nd)[16]) {
+            const float* rc = lds.rc[slot];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 nl = *(const f32x4*)(rc + 8 * g + 4 * h2);
+                const f32x4 dl = *(const f32x4*)(rc + 32 + 8 * g + 4 * h2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s[4 * g + j] = nl[j];
+                    if constexpr (DROP) {
+                        nd[4 * g + j] = dl[j];
+                        dp[4 * g + j] = 0.f;
+                    } else {
+                        dp[4 * g + j] = dl[j];
+                    }
+                }
+            }
+        };
+        // One step = 2 KS "slots", each ONE MFMA of block i + 1's chains (S' over the head dimension, then dP) plus a slice of
+        // block i's element-wise stage, fenced by sched_barrier(0): the wave issues in order and an MFMA holds the issue port
+        // 8 of its 32 cycles, so the slice's vector instructions fill the rest. (sched_group_barrier pipelines did not
+        // survive hipcc's scheduler here: it put the 20 MFMAs first and the ~190 vector instructions behind them.)
+        // 20 slices dealt over the slots: 16 elements (hash words of a 4-row group with its first element, exp2, dropout, dS')
+        // and 4 packed operand fragments to the partner wave. The chains' operand fragments are read LA slots ahead.
+        constexpr int NSLOT = 2 * G::KS, LA = 6;
+        KP_DECL;
+        auto step = [&](int i, f32x16& s, f32x16& dp, float (&nd)[16], f32x16& s2, f32x16& dp2, float (&nd2)[16]) {
+            KP_STAMP(0);
+            if (i + 3 < nq) stage(i + 3);
+            const int slot = b2_slot(i + 1);  // block nq does not exist: a stale tile, results never used
+            init_rows(slot, s2, dp2, nd2);
+            // per-step base addresses kept opaque: otherwise the 2 KS fragment addresses are hoisted out of the loop as 2 KS
+            // registers and re-based with one vector instruction each per step instead of being immediates
+            unsigned qa = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.q[slot][roff];
+            unsigned da = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.d[slot][roff];
+            asm volatile("" : "+v"(qa), "+v"(da));
+            auto frag = [&](int m) {
+                const unsigned ad = (m < G::KS ? qa : da) + 32u * (unsigned)(m % G::KS);
+                return *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)ad;
+            };
+            bf16x8 fr[NSLOT];
+#pragma unroll
+            for (int m = 0; m < LA; ++m) fr[m] = frag(m);
+            u32x4 kw[2] = {};
+            if constexpr (DROP) {
+                kw[0] = lds.keep[i & 1][pw][0][lane];
+                kw[1] = lds.keep[i & 1][pw][1][lane];
+            }
+            u32x4* hb = lds.hand[i & 1][pw][0];
+            KP_STAMP(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NSLOT; ++m) {
+                if (m == NSLOT / 2) { KP_STAMP(2); }
+                if (m + LA < NSLOT) fr[m + LA] = frag(m + LA);
+                if (m < G::KS) s2 = mfma32(fr[m], kf[m], s2);
+                else dp2 = mfma32(fr[m], vf[m - G::KS], dp2);
+#pragma unroll
+                for (int it = m * 20 / NSLOT; it < (m + 1) * 20 / NSLOT; ++it) {  // 16 element slices + 4 fragment slices over the slots
+                    if (it < 16) {
+                        const int r = it, g = it >> 2, j = it & 3;
+                        const float p = fast_exp2(s[r]);
+                        if constexpr (DROP) {
+                            const int wi = 2 * g + (j >> 1);  // keep word of this row pair; bit 8 / 24: even / odd row
+                            uint32_t km;  // asm: hipcc otherwise rewrites the 1-bit sign extension + and into and + compare + select
+                            if ((j & 1) == 0) asm("v_bfe_i32 %0, %1, 8, 1" : "=v"(km) : "v"(kw[wi >> 2][wi & 3]));
+                            else asm("v_bfe_i32 %0, %1, 24, 1" : "=v"(km) : "v"(kw[wi >> 2][wi & 3]));
+                            const float pd = __uint_as_float(__float_as_uint(p) & km);
+                            dp[r] = fmaf(pd, dp[r], p * nd[r]);
+                            s[r] = pd;
+                        } else {
+                            dp[r] = p * dp[r];
+                            s[r] = p;
+                        }
+                    } else {
+                        const int f = it - 16;  // P k-step 0, P k-step 1, dS' k-step 0, dS' k-step 1
+                        hb[64 * f + lane] = __builtin_bit_cast(u32x4, acc_to_b_pk(f < 2 ? s : dp, f & 1));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            KP_STAMP(3);
+            // everything this wave staged before this step has landed (the tile read in step i + 1 among it)
+            if (i + 3 < nq) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            KP_STAMP(4);
+            lds_barrier();
+            KP_STAMP(5);
+            KP_FLUSH(i, wave, lane);
+        };
+        // block 0's chains (no element-wise stage to overlap with yet)
+        auto chains0 = [&](f32x16& s, f32x16& dp, float (&nd)[16]) {
+            init_rows(0, s, dp, nd);
+            const bf16_t* qp = &lds.q[0][roff];
+            const bf16_t* dop = &lds.d[0][roff];
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) s = mfma32(*(const bf16x8*)(qp + 16 * ks), kf[ks], s);
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) dp = mfma32(*(const bf16x8*)(dop + 16 * ks), vf[ks], dp);
+        };
+        stage(0);
+        if (nq > 1) stage(1);
+        if (nq > 2) stage(2);
+        touch(kf);
+        touch(vf);
+        touch(c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();  // tiles 0 .. 2 staged
+        f32x16 sA, dpA, sB, dpB;
+        float ndA[16], ndB[16];
+        chains0(sA, dpA, ndA);
+        for (int i = 0; i < nq; i += 2) {
+            step(i, sA, dpA, ndA, sB, dpB, ndB);
+            if (i + 1 < nq) step(i + 1, sB, dpB, ndB, sA, dpA, ndA);
+        }
+        lds_barrier();  // the consumers' last step
+#ifdef V1T_KCLK
+        if (blockIdx.x == 3000 && wave == 0 && lane == 0) {
+            g_kclk[0] = __builtin_amdgcn_s_memtime() - kclk_c0;
+            g_kclk[1] = __builtin_amdgcn_s_memrealtime() - kclk_r0;
+        }
+#endif
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    f32x16 dk[G::DB], dv[G::DB];
+#pragma unroll
+    for (int d = 0; d < G::DB; ++d) {
+        zero16(dk[d]);
+        zero16(dv[d]);
+    }
+    const int toff = tr_lane_off(lane, G::RSTR);
+    const int nkb = a.ldds / 32;  // 32-key blocks per query block
+    bf16_t* ds_wave = a.ds + ((bh * nq) * nkb + (size_t)(rb * 4 + pw)) * 1024 + lane * 8;
+    const unsigned kmask = kok ? 0xFFFFFFFFu : 0u;  // keys beyond T: zeros (the dQ GEMM multiplies them with clamped K rows)
+    const bool ktail = rb * 128 + 32 * pw + 32 > a.T;
+
+    stage(0);
+    if (nq > 1) stage(1);
+    if (nq > 2) stage(2);
+    if constexpr (DROP) {
+        u32x4 k0, k1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            k0[e] = keep_word(0, e);
+            k1[e] = keep_word(0, 4 + e);
+        }
+        lds.keep[0][pw][0][lane] = k0;
+        lds.keep[0][pw][1][lane] = k1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    KP_DECL;
+    constexpr int NSLOT = 4 * G::DB, LA = 3;  // one MFMA per slot: dV over (d block, k-step), then dK
+    for (int i = 0; i <= nq; ++i) {
+        KP_STAMP(0);
+        const bool issued = i + 3 < nq;  // wave-uniform
+        if (issued) stage(i + 3);
+        KP_STAMP(1);
+        if (i == 0) {
+            if constexpr (DROP) {  // keep words of block 1 (later ones ride between the MFMAs below)
+                u32x4 k0, k1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    k0[e] = keep_word(1, e);
+                    k1[e] = keep_word(1, 4 + e);
+                }
+                lds.keep[1][pw][0][lane] = k0;
+                lds.keep[1][pw][1][lane] = k1;
+            }
+        }
+        if (i >= 1) {
+            // consume block j: dS' to HBM, dV^T += dO^T P, dK^T += Q^T dS' (operand k order = acc_to_b_pk order)
+            const int j = i - 1, slot = b2_slot(j);
+            const u32x4* hb = lds.hand[j & 1][pw][0];
+            const u32x4 p0 = hb[lane], p1 = hb[64 + lane];
+            const u32x4 s0 = hb[128 + lane], s1 = hb[192 + lane];
+            unsigned ta = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.d[slot][toff];
+            unsigned qa = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.q[slot][toff];
+            asm volatile("" : "+v"(ta), "+v"(qa));
+            auto frag = [&](int m) {
+                const bf16_t* p = (const bf16_t*)(const __attribute__((address_space(3))) bf16_t*)(uintptr_t)(m < 2 * G::DB ? ta : qa);
+                return tr_frag<G::RSTR>(p, 16 * (m & 1), 32 * ((m % (2 * G::DB)) >> 1));
+            };
+            bf16x8 fr[NSLOT];
+#pragma unroll
+            for (int m = 0; m < LA; ++m) fr[m] = frag(m);
+            bf16_t* dst = ds_wave + (size_t)j * nkb * 1024;
+            u32x4 m0 = s0, m1 = s1;
+            if (ktail) {  // wave-uniform: only the last key block of an (image, head) has keys beyond T
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    m0[e] &= kmask;
+                    m1[e] &= kmask;
+                }
+            }
+            *(u32x4*)dst = m0;
+            *(u32x4*)(dst + 512) = m1;
+            KP_STAMP(2);
+            const bf16x8 P0 = __builtin_bit_cast(bf16x8, p0), P1 = __builtin_bit_cast(bf16x8, p1);
+            const bf16x8 S0 = __builtin_bit_cast(bf16x8, s0), S1 = __builtin_bit_cast(bf16x8, s1);
+            u32x4 kw[2] = {};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NSLOT; ++m) {
+                if (m + LA < NSLOT) fr[m + LA] = frag(m + LA);
+                const int d = (m % (2 * G::DB)) >> 1;
+                if (m < 2 * G::DB) dv[d] = mfma32(fr[m], (m & 1) ? P1 : P0, dv[d]);
+                else dk[d] = mfma32(fr[m], (m & 1) ? S1 : S0, dk[d]);
+                if constexpr (DROP) {  // keep words of block i + 1: one per slot, then the two 16-B writes
+                    if (m < 8) kw[m >> 2][m & 3] = keep_word(i + 1, m);
+                    else if (m < 10) lds.keep[(i + 1) & 1][pw][m - 8][lane] = kw[m - 8];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // everything issued before this step has landed (the tile the producers read in step i + 1 among it); this step's
+        // own three DMA operations and its two dS' stores may stay in flight
+        KP_STAMP(3);
+        if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (i >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        KP_STAMP(4);
+        lds_barrier();
+        KP_STAMP(5);
+        KP_FLUSH(i, wave, lane);
+    }
+    if (kok) {
+        const float sc = a.scale[a.scale_per_head ? h : 0];
+        const float kfac = DROP ? a.adrop.inv_keep : 1.0f;
+        const float fk = sc * kfac;
+        bf16_t* orow = a.dqkv + ((size_t)b * a.T + key) * a.lddqkv + h * DP;
 #pragma unroll
         for (int d = 0; d < G::DB; ++d)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                bf16x4 w;
+            for (int rq4 = 0; rq4 < 4; ++rq4) {
+                bf16x4 wk, wv;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(dq[d][4 * rq + j] * f);
-                *(bf16x4*)(orow + 32 * d + 8 * rq + 4 * h2) = w;
+                for (int j = 0; j < 4; ++j) {
+                    wk[j] = (bf16_t)(dk[d][4 * rq4 + j] * fk);
+                    wv[j] = (bf16_t)(dv[d][4 * rq4 + j] * kfac);
+                }
+                *(bf16x4*)(orow + HD + 32 * d + 8 * rq4 + 4 * h2) = wk;
+                *(bf16x4*)(orow + 2 * HD + 32 * d + 8 * rq4 + 4 * h2) = wv;
             }
+    }
+}
+
+// dQ = dS' . K over the materialised dS' (layout: attention.h). Workgroup = 8 waves = 8 query blocks (256 queries) of one
+// (image, head); a wave owns one 32-query block: its dS' blocks (2 KB each, key on the lane as the dK/dV kernel stored them)
+// arrive by LDS-DMA into a wave-private region and are read TRANSPOSED as the A operand (32 queries x 16 keys, natural key
+// order), K tiles of 64 keys are shared by the workgroup and read transposed as the B operand. Bound by reading dS' once from
+// HBM (2 B per (query, key)). Accumulator rows are queries in the permuted order the stored blocks imply (q_of_m below).
+template <int DP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
+    using G = Geo<DP>;
+    constexpr int KT = 64;
+    using DmaK = TileDma<DP, G::RSTR, KT, 8>;
+    __shared__ __attribute__((aligned(16))) bf16_t sS[2][8][2][1024];
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][DmaK::LDS_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rb, h, b;
+    decode_block(a, blockIdx.x, gridDim.x, rb, h, b, 256);
+    const int nq = (a.T + 31) / 32, nkb = a.ldds / 32;
+    const int qb = rb * 8 + wave;
+    const bool active = qb < nq;  // wave-uniform
+    const size_t bh = (size_t)b * a.H + h;
+    DmaK dmaK;
+    dmaK.init(lane, wave, a.ldqkv);
+    const bf16_t* kbase = a.qkv + (size_t)b * a.T * a.ldqkv + a.H * DP + h * DP;
+    const char* sbase = (const char*)(a.ds + ((bh * nq + (active ? qb : 0)) * nkb) * 1024);
+    const unsigned svoff = (unsigned)(lane * 16);  // a stage's two blocks are 4 KB contiguous: the instruction offsets advance source and LDS alike
+    f32x16 dq[G::DB];
+#pragma unroll
+    for (int d = 0; d < G::DB; ++d) zero16(dq[d]);
+    // A operand (32 queries x 16 keys, natural key order) read transposed from a stored block: chunk s = [h 2][key 32][8] holds
+    // for key k, half h the queries 16 s + 8 (j >> 2) + 4 h + (j & 3), j = 0..7. The 16-lane group gi = lane >> 4 takes chunk
+    // s = gi & 1 (A rows m = 16 s + i) and keys 8 (gi >> 1) + {0..3} (second read: + 4); lane 4 q' + p of the group supplies
+    // the address of key row q', columns 4 p .. 4 p + 3 = elements 4 (p & 1) .. of half p >> 1; lane i receives column i.
+    const int gi = lane >> 4, li = lane & 15;
+    const int aoff = (gi & 1) * 512 + ((li & 3) >> 1) * 256 + (8 * (gi >> 1) + (li >> 2)) * 8 + (li & 1) * 4;  // elements
+    const int nst = nkb / 2;  // 64-key stages
+    auto stage = [&](int st, int buf) {
+        if (active) {
+            const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&sS[buf][wave][0][0]);
+            TileDma<DP, G::RSTR>::template group<4>(sbase + (size_t)st * 4096, l0, svoff, svoff, svoff, svoff);
+        }
+        dmaK.issue(kbase, KT * st, a.T, sK[buf]);
+    };
+    stage(0, 0);
+    dma_wait_and_barrier();
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) stage(st + 1, buf ^ 1);
+        if (active) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16_t* ap = &sS[buf][wave][kb][aoff + 16 * kk * 8];
+                    const bf16x4 lo = lds_tr_read(ap), hi = lds_tr_read(ap + 4 * 8);
+                    bf16x8 afr;
+                    afr[0] = lo[0]; afr[1] = lo[1]; afr[2] = lo[2]; afr[3] = lo[3];
+                    afr[4] = hi[0]; afr[5] = hi[1]; afr[6] = hi[2]; afr[7] = hi[3];
+#pragma unroll
+                    for (int d = 0; d < G::DB; ++d)
+                        dq[d] = mfma32(afr, lds_tr_frag_nat(sK[buf], G::RSTR, 32 * kb + 16 * kk, 32 * d, lane), dq[d]);
+                }
+        }
+        dma_wait_and_barrier();
+    }
+    if (active) {
+        const float f = a.scale[a.scale_per_head ? h : 0] * (a.adrop.thresh8 ? a.adrop.inv_keep : 1.0f);
+        const int dcol = lane & 31, h2 = lane >> 5;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = acc_row(r, lane);          // A-operand row
+            const int i = m & 15;                    // position inside the stored 16-query row of chunk m >> 4
+            const int q = 32 * qb + 16 * (m >> 4) + 8 * ((i & 7) >> 2) + 4 * (i >> 3) + (i & 3);
+            if (q < a.T) {
+                bf16_t* orow = a.dqkv + ((size_t)b * a.T + q) * a.lddqkv + h * DP + dcol;
+#pragma unroll
+                for (int d = 0; d < G::DB; ++d) orow[32 * d] = (bf16_t)(dq[d][r] * f);
+            }
+        }
+        (void)h2;
     }
 }
 
@@ -974,17 +1396,12 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
     const int n = ((a.T + 127) / 128) * a.H * a.B;
     if constexpr (DP >= 128 && !DIAG) {
         if (a.ds) {
-            if (a.ldds < attn_ds_ld(a.T) || a.ldds % 64) return V1T_ERR_ARG;
+            if (a.ldds != attn_ds_ld(a.T)) return V1T_ERR_ARG;
             prof_begin(PROF_ATTN_DKV, s);
-            hipLaunchKernelGGL((attn_bwd_dkv_store_kernel<DP, DROP>), dim3(n), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
-            static const int nw = std::getenv("V1T_DQ_NW") ? atoi(std::getenv("V1T_DQ_NW")) : 8;  // dev switch
-            static const int kt = std::getenv("V1T_DQ_KT") ? atoi(std::getenv("V1T_DQ_KT")) : 64;  // dev switch
-            const dim3 g8(((a.T + 255) / 256) * a.H * a.B);
-            if (nw == 4) hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP, 4, 64>), dim3(n), dim3(256), 0, s, a);
-            else if (kt == 32) hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP, 8, 32>), g8, dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((attn_bwd_dq_gemm_kernel<DP, 8, 64>), g8, dim3(512), 0, s, a);
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP>), dim3(((a.T + 255) / 256) * a.H * a.B), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DQ, s);
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
@@ -1008,6 +1425,13 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
 }
 template <int DP>
 int launch_delta_t(const AttnArgs& a, float* delta, hipStream_t s) {
+    if (DP >= 128 && !a.mask_diag && a.ds) {  // producer / consumer backward: padded row constants behind dS'
+        const int TPQ = attn_ds_tpq(a.T);
+        float* nlse = (float*)(a.ds + attn_ds_elems(a.B, a.H, a.T));
+        const long long total = (long long)a.B * TPQ * a.H;
+        hipLaunchKernelGGL((attn_delta2_kernel<DP>), dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, s, a, nlse, nlse + attn_rc_floats(a.B, a.H, a.T), TPQ);
+        return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    }
     const long long total = (long long)a.B * a.T * a.H;
     hipLaunchKernelGGL((attn_delta_kernel<DP>), dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, s, a, delta);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
@@ -1175,6 +1599,11 @@ int launch_rollout_vecmat(const float* A, const float* rowsum, const float* v, f
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 
+#ifdef V1T_KCLK
+extern "C" int v1t_kclk_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kclk), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef V1T_KPROF
 extern "C" int v1t_kprof_read(unsigned long long* out, int n) {
     const int total = 8 * KP_NT * KP_NP;
