@@ -309,3 +309,43 @@ def test_readout_grid_backward_paths(ctx, B, N, gd, sample):
             assert rel_to_max(o["db2"].cpu(), 2 * lb2.grad) < 5e-5, tag
         else:
             assert rel_to_max(o["dmu"].cpu(), lmu.grad) < 2e-5, tag
+
+
+def test_attention_forward_pipelined_variant_subprocess():
+    """The software-pipelined forward (attn_fwd2_kernel, opt-in through V1T_ATTN_FWD_V2: the switch is read once per process)
+    against the default forward kernel on the same inputs, dropout on: same masks, same math, other summation order."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from v1t_amd import lib as L
+lib = L.load()
+dev = torch.device("cuda:0")
+B, H, T, DP = 3, 4, 1654, 160
+g = torch.Generator().manual_seed(3)
+qkv = (torch.randn(B * T, 3 * H * DP, generator=g) * 0.7).to(dev).bfloat16()
+qkv[5, :DP] *= 30  # one query with very large scores: forces the reference-rescale path (T13) in some tile
+scale = torch.tensor([DP ** -0.5], device=dev)
+o = torch.empty(B * T, H * DP, device=dev, dtype=torch.bfloat16)
+lse = torch.empty(B, H, T, device=dev)
+L.check(lib.v1t_attention_forward(qkv.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, 0.2544, 77, 8, o.data_ptr(), lse.data_ptr(), L.stream()))
+torch.cuda.synchronize()
+torch.save({"o": o.float().cpu(), "lse": lse.cpu()}, sys.argv[1])
+'''
+    outs = []
+    for v2 in (False, True):
+        path = f"/tmp/v1t_fwd_{int(v2)}.pt"
+        env = dict(os.environ)
+        env.pop("V1T_ATTN_FWD_V2", None)
+        if v2:
+            env["V1T_ATTN_FWD_V2"] = "1"
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(path))
+    a, b = outs
+    assert bool(torch.isfinite(b["o"]).all())
+    assert rel_to_max(b["o"], a["o"]) < 1e-2
+    assert float((b["lse"] - a["lse"]).abs().max()) < 2e-2

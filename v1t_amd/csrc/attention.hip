@@ -50,6 +50,35 @@ __device__ unsigned long long g_kprof[8 * KP_NT * KP_NP];  // up to 8 waves (for
 #define KP_FLUSH(kt, wave, lane)
 #endif
 
+#ifdef V1T_KSUM
+// dev-only: per-segment cycle sums over a whole workgroup (no per-step stores): KS_MARK(k) adds the cycles since the previous
+// mark to segment k; tools/ksum.py prints them for one workgroup
+__device__ unsigned long long g_ksum[8 * 8 + 2];
+#define KS_DECL unsigned long long ks_prev = __builtin_amdgcn_s_memtime(), ks_sum[8] = {}; const unsigned long long ks_c0 = ks_prev, ks_r0 = __builtin_amdgcn_s_memrealtime()
+#define KS_MARK(k)                                                   \
+    do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        const unsigned long long ks_now = __builtin_amdgcn_s_memtime(); \
+        ks_sum[k] += ks_now - ks_prev;                               \
+        ks_prev = ks_now;                                            \
+        __builtin_amdgcn_sched_barrier(0);                           \
+    } while (0)
+#define KS_END(blk, wave, lane)                                                                                   \
+    do {                                                                                                          \
+        if (blockIdx.x == (blk) && (lane) == 0) {                                                                 \
+            for (int i_ = 0; i_ < 8; ++i_) g_ksum[(wave) * 8 + i_] = ks_sum[i_];                                  \
+            if ((wave) == 0) {                                                                                    \
+                g_ksum[64] = __builtin_amdgcn_s_memtime() - ks_c0;                                                \
+                g_ksum[65] = __builtin_amdgcn_s_memrealtime() - ks_r0;                                            \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
+#else
+#define KS_DECL
+#define KS_MARK(k)
+#define KS_END(blk, wave, lane)
+#endif
+
 namespace {
 
 constexpr float NEG_BIG = -1.0e30f;
@@ -401,6 +430,278 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
                 if (a.o_lo) *(bf16x4*)(a.o_lo + (orow - a.o) + 32 * d + 8 * rq + 4 * h2) = wl;
             }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward, software-pipelined (default path: DP >= 128, no LSA diagonal). Same geometry and products as attn_fwd_kernel
+// (8 waves x 32 queries share 64-key K/V stages; S^T = K Q^T with the query on the lane, O^T += V^T P^T with P^T straight
+// from the accumulator), but a wave keeps THREE key tiles in flight: iteration t issues, one MFMA per "slot",
+//     O^T += V^T P^T of tile t - 1   (KS MFMAs)   and   S'^T = K Q^T of tile t + 1   (KS MFMAs),
+// and between them, fenced by sched_barrier(0), the element-wise stage of tile t (exp2, row sum, dropout, bf16 packing).
+// attn_fwd_kernel runs those three phases one after the other in each wave (matrix pipe ~36 % busy, kprof timeline: a
+// wave spends ~2700 cycles per tile for 640 cycles of MFMA); here the vector instructions ride in the MFMAs' shadow.
+// Q is pre-multiplied by c = scale log2(e) and the S' accumulator starts from -m (the running reference maximum of the
+// row), so P = exp2(S') needs no multiply-add; the reference moves only when a score exceeds it by FWD2_THR (in log2
+// units; bf16 / fp32 have 8 exponent bits, so 2^24 sums are harmless), which takes the (rare) un-pipelined path.
+constexpr float FWD2_THR = 24.0f;
+template <int DP, bool DROP>
+__global__ __launch_bounds__(64 * FWD_WAVES, 2) void attn_fwd2_kernel(AttnArgs a) {
+    using G = Geo<DP>;
+    // K/V staging is issued by the first-dispatched half of the workgroup only (waves 0-3): the younger half loses the
+    // issue arbitration on every slot (ksum timeline: 90 vs 70 cycles per slot; s_setprio 1 for it merely swaps the roles) and
+    // would carry its DMA pieces on top, while the older half waits for it at every stage barrier
+    constexpr int DMA_WAVES = FWD_WAVES / 2;
+    using DmaK = TileDma<DP, G::RSTR, 64, DMA_WAVES>;
+    using DmaV = TileDma<DP, G::TSTR, 64, DMA_WAVES>;
+    constexpr int NB = 3;  // stage buffers: V of stage k - 1 and K of stage k + 1 are read while stage k + 2 lands
+    __shared__ __attribute__((aligned(16))) bf16_t sK[NB][DmaK::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[NB][DmaV::LDS_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int rb, h, b;
+    decode_block(a, blockIdx.x, gridDim.x, rb, h, b, 32 * FWD_WAVES);
+    const int q = rb * (32 * FWD_WAVES) + 32 * wave + (lane & 31);
+    const int h2 = lane >> 5;
+    const int HD = a.H * DP;
+    const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
+    const bf16_t* kbase = qkv_b + HD + h * DP;
+    const bf16_t* vbase = qkv_b + 2 * HD + h * DP;
+    const float c = a.scale[a.scale_per_head ? h : 0] * LOG2E;
+    KS_DECL;
+    DmaK dmaK;
+    DmaV dmaV;
+    dmaK.init(lane, wave & (DMA_WAVES - 1), a.ldqkv);
+    dmaV.init(lane, wave & (DMA_WAVES - 1), a.ldqkv);
+    const bool loader = wave < DMA_WAVES;  // wave-uniform
+
+    bf16x8 qf[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+        u32x4 t = (q < a.T) ? *(const u32x4*)(qkv_b + (size_t)q * a.ldqkv + h * DP + 16 * ks + 8 * h2) : u32x4{0, 0, 0, 0};
+        qf[ks] = *(bf16x8*)&t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16_t)((float)qf[ks][j] * c);
+    }
+    f32x16 o[G::DB];
+#pragma unroll
+    for (int d = 0; d < G::DB; ++d) zero16(o[d]);
+    float m2 = 0.f, lsum = 0.f;  // reference maximum of the row (scaled log2 domain); per-lane partial sum of exp2(S' )
+
+    // dropout: lane-fixed coordinate = q (row), varying = key (common.h)
+    const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
+    const uint32_t dbase = a.adrop.key + ((uint32_t)(b * a.H + h) * T2 + ((uint32_t)q >> 1)) * ADROP_K1 + (uint32_t)(2 * h2) * ADROP_K2;
+    const uint32_t sh_even = 16 * (q & 1), sh_odd = sh_even + 8;
+    const int koff = (lane & 31) * G::RSTR + 8 * h2;
+    const int voff = tr_lane_off(lane, G::TSTR);
+    const int nt = (a.T + 31) / 32, ns = (nt + 1) / 2;
+
+    auto kptr = [&](int t) { return &sK[(t >> 1) % NB][32 * (t & 1) * G::RSTR + koff]; };
+    auto vptr = [&](int t) { return &sV[(t >> 1) % NB][32 * (t & 1) * G::TSTR + voff]; };
+    auto stage = [&](int st) {
+        if (loader) {
+            dmaK.issue(kbase, 64 * st, a.T, sK[st % NB]);
+            dmaV.issue(vbase, 64 * st, a.T, sV[st % NB]);
+        }
+    };
+    // S'^T of tile t, un-pipelined (prologue and the rescale path): accumulator starts from `init`. Fenced per MFMA so that the
+    // fragments of these rarely executed paths do not all sit in registers at once (the kernel is at the 256-register cap).
+    auto chain_s = [&](int t, f32x16& s, float init) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = init;
+        const bf16_t* kp = kptr(t);
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            s = mfma32(*(const bf16x8*)(kp + 16 * ks), qf[ks], s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto chain_pv = [&](int t, const bf16x8& p0, const bf16x8& p1) {
+        const bf16_t* vp = vptr(t);
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) {
+            o[d] = mfma32(tr_frag<G::TSTR>(vp, 0, 32 * d), p0, o[d]);
+            o[d] = mfma32(tr_frag<G::TSTR>(vp, 16, 32 * d), p1, o[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto mask_tail = [&](int t, f32x16& s) {  // keys beyond T (last tile only): P = 0
+        if (32 * t + 32 > a.T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = (32 * t + acc_row(r, lane) >= a.T) ? NEG_BIG : s[r];
+        }
+    };
+    auto row_max = [&](const f32x16& s) {
+        mfma_result_fence();
+        float pmax = vmax3(s[0], s[1], s[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) pmax = vmax3(pmax, s[r], s[r + 1]);
+        return half_max(vmax2(pmax, s[15]));
+    };
+    // element r of tile t: S' -> exp2, row sum, dropout (x 1/keep in the epilogue); result back in s[r]
+    uint32_t w0 = 0, w1 = 0;
+    auto element = [&](int t, f32x16& s, int r) {
+        const int g = r >> 2, j = r & 3;
+        if constexpr (DROP) {
+            if (j == 0) {
+                const uint32_t x0 = dbase + (uint32_t)(16 * t + 4 * g) * ADROP_K2;
+                w0 = mix1(x0);
+                w1 = mix1(x0 + ADROP_K2);
+            }
+        }
+        const float p = fast_exp2(s[r]);
+        lsum += p;
+        if constexpr (DROP) {
+            const bool keep = __builtin_amdgcn_ubfe(j < 2 ? w0 : w1, (j & 1) ? sh_odd : sh_even, 8u) >= a.adrop.thresh8;
+            s[r] = keep ? p : 0.f;
+        } else {
+            s[r] = p;
+        }
+    };
+
+    // ---- prologue: stages 0 and 1 staged, tile 0 fixes the reference maximum
+    stage(0);
+    if (ns > 1) stage(1);
+    touch(qf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    KS_MARK(7);
+    f32x16 sA, sB;
+    chain_s(0, sA, 0.f);
+    mask_tail(0, sA);
+    m2 = row_max(sA);  // tile 0 relative to itself: pmax = 0 (initial value)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sA[r] -= m2;
+    bf16x8 p0, p1;  // P^T of the previous tile (B operand of its P . V), pending; zeros before tile 0 (its P . V adds nothing)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p0[j] = p1[j] = (bf16_t)0.f;
+
+    // One iteration: tile t's scores are in `s` (relative to m2), tile t - 1's P^T pending in (p0, p1); issues P.V of t - 1 and
+    // the score chain of t + 1 into `s2` around the element-wise stage of t.
+    constexpr int NSLOT = 2 * G::KS, LA = 3;
+    float pmax = 0.f;  // row maximum of the tile about to be processed, relative to m2 (computed inside the previous iteration)
+    auto iteration = [&](int t, f32x16& s, f32x16& s2) {
+        KS_MARK(0);
+        const int tp = max(t - 1, 0);
+        mask_tail(t, s);
+        // reference check (T13): a score above m2 + THR moves the reference; everything still at the old reference is scaled
+        // exactly once: O, the row sum, the pending P^T of tile t - 1 and the scores of this tile (tile t + 1's chain starts
+        // from the new reference below)
+        if (!__all(pmax <= FWD2_THR)) {
+            const float mn = m2 + fmaxf(pmax, 0.f);
+            const float alpha = fast_exp2(m2 - mn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // the pending P^T of tile t - 1 is still at the old reference: scale it as well
+                p0[j] = (bf16_t)((float)p0[j] * alpha);
+                p1[j] = (bf16_t)((float)p1[j] * alpha);
+            }
+#pragma unroll
+            for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            lsum *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] -= mn - m2;
+            m2 = mn;
+        }
+        KS_MARK(1);
+        unsigned ka = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)kptr(t + 1);
+        unsigned va = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)vptr(tp);
+        asm volatile("" : "+v"(ka), "+v"(va));  // opaque bases: fragment addresses stay immediates
+        const bf16_t* vp = (const bf16_t*)(const __attribute__((address_space(3))) bf16_t*)(uintptr_t)va;
+        // slot m < KS: S'^T chain of tile t + 1 over the head dimension (first, so that its row maximum can be taken in the
+        // later slots); m >= KS: O^T += V^T P^T of tile t - 1 (d block (m - KS) >> 1, k-step m & 1)
+        auto frag = [&](int m) {
+            if (m >= G::KS) return tr_frag<G::TSTR>(vp, 16 * (m & 1), 32 * ((m - G::KS) >> 1));
+            return *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(ka + 32u * (unsigned)m);
+        };
+        bf16x8 fr[NSLOT];
+#pragma unroll
+        for (int m = 0; m < LA; ++m) fr[m] = frag(m);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s2[r] = -m2;
+        bf16x8 n0, n1;
+        float mx = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NSLOT; ++m) {
+            if (m + LA < NSLOT) fr[m + LA] = frag(m + LA);
+            if (m < G::KS) s2 = mfma32(fr[m], qf[m], s2);
+            else o[(m - G::KS) >> 1] = mfma32(fr[m], (m & 1) ? p1 : p0, o[(m - G::KS) >> 1]);
+            // 16 element slices + 2 packing slices dealt over the slots of this iteration
+#pragma unroll
+            for (int it = m * 18 / NSLOT; it < (m + 1) * 18 / NSLOT; ++it) {
+                if (it < 16) element(t, s, it);
+                else if (it == 16) n0 = acc_to_b_pk(s, 0);
+                else n1 = acc_to_b_pk(s, 1);
+            }
+            // row maximum of tile t + 1 (its chain ended KS slots ago... two slots ago at the earliest)
+            if (m == G::KS + 2) {
+                mfma_result_fence();
+                mx = vmax3(s2[0], s2[1], s2[2]);
+                mx = vmax3(mx, s2[3], s2[4]);
+                mx = vmax3(mx, s2[5], s2[6]);
+            } else if (m == G::KS + 4) {
+                mx = vmax3(mx, s2[7], s2[8]);
+                mx = vmax3(mx, s2[9], s2[10]);
+                mx = vmax3(mx, s2[11], s2[12]);
+            } else if (m == G::KS + 6) {
+                mx = vmax3(mx, s2[13], s2[14]);
+                pmax = half_max(vmax2(mx, s2[15]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        p0 = n0;
+        p1 = n1;
+        KS_MARK(2);
+    };
+    // stage bookkeeping around iteration t (odd t = 2 k + 1 reads K of stage k + 1 for the first time): wait for that stage,
+    // barrier (every wave is past V of stage k - 1), then stage k + 2 goes into the freed buffer
+    auto sync_stage = [&](int t) {
+        if ((t & 1) && (t >> 1) + 1 < ns) {
+            KS_MARK(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            KS_MARK(3);
+            __builtin_amdgcn_s_barrier();
+            KS_MARK(4);
+            if ((t >> 1) + 2 < ns) stage((t >> 1) + 2);
+            KS_MARK(5);
+        }
+    };
+    if (nt > 1) {
+        sync_stage(1);  // tile 2 (stage 1) is read by iteration 1; iteration 0 below needs tile 1 only
+    }
+    for (int t = 0; t < nt; t += 2) {
+        iteration(t, sA, sB);
+        if (t + 1 < nt) {
+            if (t + 1 > 1) sync_stage(t + 1);
+            iteration(t + 1, sB, sA);
+        }
+    }
+    KS_MARK(0);
+    chain_pv(nt - 1, p0, p1);
+    KS_MARK(6);
+
+    const float ltot = lsum + __shfl_xor(lsum, 32);
+    const float inv = (DROP ? a.adrop.inv_keep : 1.0f) / ltot;
+    if (q < a.T) {
+        if (h2 == 0) a.lse2[((size_t)b * a.H + h) * a.T + q] = m2 + log2f(ltot);
+        bf16_t* orow = a.o + ((size_t)b * a.T + q) * a.ldo + h * DP;
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                bf16x4 w, wl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = o[d][4 * rq + j] * inv;
+                    w[j] = (bf16_t)v;
+                    wl[j] = aux_plane(v, w[j], a.lo_f16);
+                }
+                *(bf16x4*)(orow + 32 * d + 8 * rq + 4 * h2) = w;
+                if (a.o_lo) *(bf16x4*)(a.o_lo + (orow - a.o) + 32 * d + 8 * rq + 4 * h2) = wl;
+            }
+    }
+    KS_MARK(6);
+    KS_END(1500, wave, lane);
 }
 
 // delta[b][h][t] = keep_prob * sum_d dO * O. 16 lanes per (row, head) segment: a load instruction reads 256 contiguous
@@ -835,6 +1136,17 @@ template <int DP, bool DROP, bool DIAG>
 int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
     dim3 grid(((a.T + 32 * FWD_WAVES - 1) / (32 * FWD_WAVES)) * a.H * a.B);
     prof_begin(PROF_ATTN_FWD, s);
+    // dev switch: the software-pipelined kernel. Measured a tie to +3 % SLOWER than attn_fwd_kernel at the 112-image shape
+    // (995 vs 965 us): its slots run at the vector-issue floor, but the two waves of a SIMD no longer cover each other's
+    // serial phases, and cycles saved come back as a lower clock (1.78-1.97 GHz under this load)
+    static const bool v2 = std::getenv("V1T_ATTN_FWD_V2") != nullptr;
+    if constexpr (DP >= 128 && !DIAG) {
+        if (v2) {
+            hipLaunchKernelGGL((attn_fwd2_kernel<DP, DROP>), grid, dim3(64 * FWD_WAVES), 0, s, a);
+            prof_end(PROF_ATTN_FWD, s);
+            return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+        }
+    }
     hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG>), grid, dim3(64 * FWD_WAVES), 0, s, a);
     prof_end(PROF_ATTN_FWD, s);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
@@ -964,6 +1276,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
 #ifdef V1T_KCLK
     const unsigned long long kclk_c0 = __builtin_amdgcn_s_memtime(), kclk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    KS_DECL;
     const int pw = wave & 3;  // pair: producer pw and consumer pw + 4 own keys [32 pw, 32 pw + 32) of the 128-key block
     int rb, h, b;
     decode_block(a, blockIdx.x, gridDim.x, rb, h, b);
@@ -1040,9 +1353,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
 
     if (wave < 4) {
         // ------------------------------------------------------------------ producer
-        // static priority over the SIMD partner: the consumer's 20 MFMAs otherwise run back to back (640 cycles, kprof
-        // timeline) while this wave - in-order, one MFMA per slot - sits behind them with its vector instructions
-        __builtin_amdgcn_s_setprio(3);
+        // (static priorities - s_setprio for either role - change nothing measurable here: A/B within 1 %)
         const float sc = a.scale[a.scale_per_head ? h : 0];
         const float c = sc * LOG2E;
         bf16x8 kf[G::KS], vf[G::KS];
@@ -1085,11 +1396,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         // survive hipcc's scheduler here: it put the 20 MFMAs first and the ~190 vector instructions behind them.)
         // 20 slices dealt over the slots: 16 elements (hash words of a 4-row group with its first element, exp2, dropout, dS')
         // and 4 packed operand fragments to the partner wave. The chains' operand fragments are read LA slots ahead.
-        constexpr int NSLOT = 2 * G::KS, LA = 6;
+        constexpr int NSLOT = 2 * G::KS, LA = 3;
         KP_DECL;
-        auto step = [&](int i, f32x16& s, f32x16& dp, float (&nd)[16], f32x16& s2, f32x16& dp2, float (&nd2)[16]) {
+        auto step = [&](auto issued_tag, int i, f32x16& s, f32x16& dp, float (&nd)[16], f32x16& s2, f32x16& dp2, float (&nd2)[16]) {
+            constexpr bool ISSUED = decltype(issued_tag)::value;
             KP_STAMP(0);
-            if (i + 3 < nq) stage(i + 3);
+            KS_MARK(0);
+            if constexpr (ISSUED) stage(i + 3);
+            KS_MARK(1);
             const int slot = b2_slot(i + 1);  // block nq does not exist: a stale tile, results never used
             init_rows(slot, s2, dp2, nd2);
             // per-step base addresses kept opaque: otherwise the 2 KS fragment addresses are hoisted out of the loop as 2 KS
@@ -1111,6 +1425,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
             }
             u32x4* hb = lds.hand[i & 1][pw][0];
             KP_STAMP(1);
+            KS_MARK(2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < NSLOT; ++m) {
@@ -1143,12 +1458,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             KP_STAMP(3);
+            KS_MARK(3);
             // everything this wave staged before this step has landed (the tile read in step i + 1 among it)
-            if (i + 3 < nq) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            if constexpr (ISSUED) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             KP_STAMP(4);
+            KS_MARK(4);
             lds_barrier();
             KP_STAMP(5);
+            KS_MARK(5);
             KP_FLUSH(i, wave, lane);
         };
         // block 0's chains (no element-wise stage to overlap with yet)
@@ -1172,11 +1490,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         f32x16 sA, dpA, sB, dpB;
         float ndA[16], ndB[16];
         chains0(sA, dpA, ndA);
-        for (int i = 0; i < nq; i += 2) {
-            step(i, sA, dpA, ndA, sB, dpB, ndB);
-            if (i + 1 < nq) step(i + 1, sB, dpB, ndB, sA, dpA, ndA);
+        KS_MARK(6);
+        {
+            int i = 0;
+            for (; i + 4 < nq; i += 2) {  // steady state: both steps stage a tile
+                step(std::true_type{}, i, sA, dpA, ndA, sB, dpB, ndB);
+                step(std::true_type{}, i + 1, sB, dpB, ndB, sA, dpA, ndA);
+            }
+            for (; i < nq; i += 2) {
+                if (i + 3 < nq) step(std::true_type{}, i, sA, dpA, ndA, sB, dpB, ndB);
+                else step(std::false_type{}, i, sA, dpA, ndA, sB, dpB, ndB);
+                if (i + 1 < nq) step(std::false_type{}, i + 1, sB, dpB, ndB, sA, dpA, ndA);
+            }
         }
         lds_barrier();  // the consumers' last step
+        KS_MARK(7);
+        KS_END(3000, wave, lane);
 #ifdef V1T_KCLK
         if (blockIdx.x == 3000 && wave == 0 && lane == 0) {
             g_kclk[0] = __builtin_amdgcn_s_memtime() - kclk_c0;
@@ -1202,93 +1531,100 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     stage(0);
     if (nq > 1) stage(1);
     if (nq > 2) stage(2);
-    if constexpr (DROP) {
-        u32x4 k0, k1;
+    auto keep_block = [&](int blk) {  // all 8 keep words of a block at once (prologue / step 0; later ones ride between the MFMAs)
+        if constexpr (DROP) {
+            u32x4 k0, k1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            k0[e] = keep_word(0, e);
-            k1[e] = keep_word(0, 4 + e);
+            for (int e = 0; e < 4; ++e) {
+                k0[e] = keep_word(blk, e);
+                k1[e] = keep_word(blk, 4 + e);
+            }
+            lds.keep[blk & 1][pw][0][lane] = k0;
+            lds.keep[blk & 1][pw][1][lane] = k1;
         }
-        lds.keep[0][pw][0][lane] = k0;
-        lds.keep[0][pw][1][lane] = k1;
-    }
+    };
+    keep_block(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    KS_MARK(6);
+    // step 0: nothing to consume yet
+    if (nq > 3) stage(3);
+    keep_block(1);
+    if (nq > 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     lds_barrier();
     KP_DECL;
     constexpr int NSLOT = 4 * G::DB, LA = 3;  // one MFMA per slot: dV over (d block, k-step), then dK
-    for (int i = 0; i <= nq; ++i) {
+    // step i >= 1: consume block j = i - 1 (dS' to HBM, dV^T += dO^T P, dK^T += Q^T dS'; operand k order = acc_to_b_pk order) and,
+    // if ISSUED, stage tile i + 3. The hand-off reads go first so that their latency hides behind the DMA issue.
+    auto cstep = [&](auto issued_tag, int i) {
+        constexpr bool ISSUED = decltype(issued_tag)::value;
         KP_STAMP(0);
-        const bool issued = i + 3 < nq;  // wave-uniform
-        if (issued) stage(i + 3);
+        KS_MARK(0);
+        const int j = i - 1, slot = b2_slot(j);
+        const u32x4* hb = lds.hand[j & 1][pw][0];
+        const u32x4 p0 = hb[lane], p1 = hb[64 + lane];
+        const u32x4 s0 = hb[128 + lane], s1 = hb[192 + lane];
+        if constexpr (ISSUED) stage(i + 3);
         KP_STAMP(1);
-        if (i == 0) {
-            if constexpr (DROP) {  // keep words of block 1 (later ones ride between the MFMAs below)
-                u32x4 k0, k1;
+        KS_MARK(1);
+        unsigned ta = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.d[slot][toff];
+        unsigned qa = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.q[slot][toff];
+        asm volatile("" : "+v"(ta), "+v"(qa));
+        auto frag = [&](int m) {
+            const bf16_t* p = (const bf16_t*)(const __attribute__((address_space(3))) bf16_t*)(uintptr_t)(m < 2 * G::DB ? ta : qa);
+            return tr_frag<G::RSTR>(p, 16 * (m & 1), 32 * ((m % (2 * G::DB)) >> 1));
+        };
+        bf16x8 fr[NSLOT];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    k0[e] = keep_word(1, e);
-                    k1[e] = keep_word(1, 4 + e);
-                }
-                lds.keep[1][pw][0][lane] = k0;
-                lds.keep[1][pw][1][lane] = k1;
+        for (int m = 0; m < LA; ++m) fr[m] = frag(m);
+        bf16_t* dst = ds_wave + (size_t)j * nkb * 1024;
+        u32x4 m0 = s0, m1 = s1;
+        if (ktail) {  // wave-uniform: only the last key block of an (image, head) has keys beyond T
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m0[e] &= kmask;
+                m1[e] &= kmask;
             }
         }
-        if (i >= 1) {
-            // consume block j: dS' to HBM, dV^T += dO^T P, dK^T += Q^T dS' (operand k order = acc_to_b_pk order)
-            const int j = i - 1, slot = b2_slot(j);
-            const u32x4* hb = lds.hand[j & 1][pw][0];
-            const u32x4 p0 = hb[lane], p1 = hb[64 + lane];
-            const u32x4 s0 = hb[128 + lane], s1 = hb[192 + lane];
-            unsigned ta = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.d[slot][toff];
-            unsigned qa = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.q[slot][toff];
-            asm volatile("" : "+v"(ta), "+v"(qa));
-            auto frag = [&](int m) {
-                const bf16_t* p = (const bf16_t*)(const __attribute__((address_space(3))) bf16_t*)(uintptr_t)(m < 2 * G::DB ? ta : qa);
-                return tr_frag<G::RSTR>(p, 16 * (m & 1), 32 * ((m % (2 * G::DB)) >> 1));
-            };
-            bf16x8 fr[NSLOT];
+        *(u32x4*)dst = m0;
+        *(u32x4*)(dst + 512) = m1;
+        KP_STAMP(2);
+        KS_MARK(2);
+        const bf16x8 P0 = __builtin_bit_cast(bf16x8, p0), P1 = __builtin_bit_cast(bf16x8, p1);
+        const bf16x8 S0 = __builtin_bit_cast(bf16x8, s0), S1 = __builtin_bit_cast(bf16x8, s1);
+        u32x4 kw[2] = {};
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < LA; ++m) fr[m] = frag(m);
-            bf16_t* dst = ds_wave + (size_t)j * nkb * 1024;
-            u32x4 m0 = s0, m1 = s1;
-            if (ktail) {  // wave-uniform: only the last key block of an (image, head) has keys beyond T
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    m0[e] &= kmask;
-                    m1[e] &= kmask;
-                }
+        for (int m = 0; m < NSLOT; ++m) {
+            if (m + LA < NSLOT) fr[m + LA] = frag(m + LA);
+            const int d = (m % (2 * G::DB)) >> 1;
+            if (m < 2 * G::DB) dv[d] = mfma32(fr[m], (m & 1) ? P1 : P0, dv[d]);
+            else dk[d] = mfma32(fr[m], (m & 1) ? S1 : S0, dk[d]);
+            if constexpr (DROP) {  // keep words of block i + 1: one per slot, then the two 16-B writes
+                if (m < 8) kw[m >> 2][m & 3] = keep_word(i + 1, m);
+                else if (m < 10) lds.keep[(i + 1) & 1][pw][m - 8][lane] = kw[m - 8];
             }
-            *(u32x4*)dst = m0;
-            *(u32x4*)(dst + 512) = m1;
-            KP_STAMP(2);
-            const bf16x8 P0 = __builtin_bit_cast(bf16x8, p0), P1 = __builtin_bit_cast(bf16x8, p1);
-            const bf16x8 S0 = __builtin_bit_cast(bf16x8, s0), S1 = __builtin_bit_cast(bf16x8, s1);
-            u32x4 kw[2] = {};
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < NSLOT; ++m) {
-                if (m + LA < NSLOT) fr[m + LA] = frag(m + LA);
-                const int d = (m % (2 * G::DB)) >> 1;
-                if (m < 2 * G::DB) dv[d] = mfma32(fr[m], (m & 1) ? P1 : P0, dv[d]);
-                else dk[d] = mfma32(fr[m], (m & 1) ? S1 : S0, dk[d]);
-                if constexpr (DROP) {  // keep words of block i + 1: one per slot, then the two 16-B writes
-                    if (m < 8) kw[m >> 2][m & 3] = keep_word(i + 1, m);
-                    else if (m < 10) lds.keep[(i + 1) & 1][pw][m - 8][lane] = kw[m - 8];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
         // everything issued before this step has landed (the tile the producers read in step i + 1 among it); this step's
         // own three DMA operations and its two dS' stores may stay in flight
         KP_STAMP(3);
-        if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (i >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        KS_MARK(3);
+        if constexpr (ISSUED) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         KP_STAMP(4);
+        KS_MARK(4);
         lds_barrier();
         KP_STAMP(5);
+        KS_MARK(5);
         KP_FLUSH(i, wave, lane);
+    };
+    {
+        int i = 1;
+        for (; i + 3 < nq; ++i) cstep(std::true_type{}, i);
+        for (; i <= nq; ++i) cstep(std::false_type{}, i);
     }
+    KS_MARK(0);
     if (kok) {
         const float sc = a.scale[a.scale_per_head ? h : 0];
         const float kfac = DROP ? a.adrop.inv_keep : 1.0f;
@@ -1308,6 +1644,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
                 *(bf16x4*)(orow + 2 * HD + 32 * d + 8 * rq4 + 4 * h2) = wv;
             }
     }
+    KS_MARK(7);
+    KS_END(3000, wave, lane);
 }
 
 // dQ = dS' . K over the materialised dS' (layout: attention.h). Workgroup = 8 waves = 8 query blocks (256 queries) of one
@@ -1599,6 +1937,11 @@ int launch_rollout_vecmat(const float* A, const float* rowsum, const float* v, f
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 
+#ifdef V1T_KSUM
+extern "C" int v1t_ksum_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ksum), sizeof(unsigned long long) * 66) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef V1T_KCLK
 extern "C" int v1t_kclk_read(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kclk), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -1;
