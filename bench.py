@@ -112,11 +112,39 @@ def main():
     args, ds = sensorium_config(neurons)
     torch.manual_seed(args.seed)  # identical initial core on every rank
     model = v1t_amd.Model(args, ds).to(dev)
+    torch.manual_seed(args.seed + 7919 * (rank + 1))  # after the (identical) initialisation: per-rank draws of eps / DropPath
     sharding = MouseSharding(args.mouse_ids, rank=rank, world=world, batch_size=args.batch_size)
     trainer = Trainer(args, model, ds, sharding=sharding)
     batches = {m: make_batch(args, m, neurons[m], args.batch_size, dev, seed=i) for i, m in enumerate(args.mouse_ids) if m in sharding.local_mice()}
 
     lib = L.load()
+    if world > 1:
+        # self-check of the exchange before anything is timed: the overlapped, bucketed all-reduce the trainer uses must give
+        # the sums of one blocking all-reduce over the same buffer; otherwise fall back to the blocking form (and say so)
+        core = model.core
+        core.prepare()
+        core._arena.attach_grads()
+        n = core._arena.param_floats
+        probe = torch.arange(n, device=dev, dtype=torch.float32).remainder_(97.0).mul_(rank + 1.0)
+        ref = probe.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        if trainer.overlap:
+            try:
+                core._arena.grad[:n].copy_(probe)
+                sharding.attach_block_events(core)
+                sharding.wait_all(sharding.reduce_core_overlapped(core))
+                torch.cuda.synchronize()
+                ok = bool(torch.allclose(core._arena.grad[:n], ref, rtol=1e-5, atol=1e-3))
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: overlapped exchange raised {e!r}", file=sys.stderr, flush=True)
+                ok = False
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) < 1.0:
+                if rank == 0:
+                    print("[bench] overlapped exchange failed its self-check: using the blocking all-reduce", file=sys.stderr, flush=True)
+                trainer.overlap = False
+        core._arena.grad.zero_()
     for _ in range(a.warmup):
         trainer.train_step(batches)
     torch.cuda.synchronize()
@@ -180,7 +208,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: default V1T (4 blocks, D=155, 4 heads, MLP 488, T=1654) + Gaussian2d, 7 mice x "
                                    f"{a.neurons} neurons, input 1x144x256 -> 36x64, batch 16 per mouse, dropout+sampling on, AdamW+L1",
-                       "global_batch": sharding.images_per_step(), "parallelism": f"mouse-dp{world}"},
+                       "global_batch": sharding.images_per_step(), "parallelism": f"mouse-dp{world}",
+                       "exchange": ("bucketed async all-reduce behind per-block events" if trainer.overlap else "blocking all-reduce") if world > 1 else "none"},
             "loss": loss,
             "model_tflops_per_s": round(fl["train_per_image"] * images / dt / 1e12, 2),
             "model_frac_of_bf16_peak": round(fl["train_per_image"] * images / dt / 1e12 / (PEAK_BF16_TFLOPS * world), 4),

@@ -92,6 +92,16 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
                      const float* behaviors, int mouse_idx, int batch, const void* workspace,
                      void* scratch, long long scratch_bytes, int training, uint64_t seed,
                      const float* path_scale, const float* gout, float* grads, void* stream);
+/* Same, recording hipEvent block_done[k] (num_blocks entries, each may be NULL) on `stream` as soon as every gradient of
+ * block k's attention / MLP parameters (state-dict keys core.transformer.blocks.k.{mha,mlp}.*) is complete - blocks finish
+ * last to first - so that the data-parallel exchange of that block's slice of the gradient arena (reference train.py:97-111
+ * accumulates the same sums on one device) can start while the earlier blocks are still in their backward. The BehaviorMLP
+ * and patch-embedding gradients are complete when the call's work is. */
+int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* shadow, const float* images,
+                            const float* behaviors, int mouse_idx, int batch, const void* workspace,
+                            void* scratch, long long scratch_bytes, int training, uint64_t seed,
+                            const float* path_scale, const float* gout, float* grads, void* const* block_done,
+                            void* stream);
 
 /* keep-mask of one dropout stream, for replaying the exact mask in a CPU check.
  * stream ids: 8*block + {0: attention P (rows B*H*T, cols T), 1: proj out, 2: fc1 out, 3: fc2 out}

@@ -111,3 +111,89 @@ def test_replica_rank_shares_a_mouse():
 
 def test_eight_ranks_every_mouse_cut_collectives():
     _run(8, list("ABCDEFG"))  # 14 images per rank: all seven mice shared by neighbouring ranks (seven 2-rank groups)
+
+
+# ---- overlapped (bucketed, asynchronous) exchange and gather_mice on the real core arena ---------------------------------
+def _core_worker(rank, world, port, q):
+    import numpy as np
+
+    import v1t_amd
+    from v1t_amd.synthetic import default_args, make_ds
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mice = list("ABCDEFG")
+    neurons = {m: 20 + i for i, m in enumerate(mice)}
+    args = default_args(input_shape=(1, 36, 64), resize_image=0, num_blocks=3, emb_dim=32, mlp_dim=48, num_heads=2)
+    args.output_shapes = {m: (n,) for m, n in neurons.items()}
+    torch.manual_seed(0)
+    model = v1t_amd.Model(args, make_ds(neurons))  # CPU: constructors + flat arenas only, no kernels
+    core = model.core
+    core._arena.ensure()
+    core._arena.attach_grads()
+    sh = MouseSharding(mice, rank=rank, world=world, batch_size=16)
+    buckets = core.grad_buckets()
+    assert [k for k, _, _ in buckets[:3]] == [2, 1, 0] and all(k == -1 for k, _, _ in buckets[3:])  # blocks complete last to first
+    n = core._arena.param_floats
+    g = torch.Generator().manual_seed(1000 + rank)
+    local = torch.randn(n, generator=g)
+    core._arena.grad[:n] = local
+    sh.wait_all(sh.reduce_core_overlapped(core))
+    bucketed = core._arena.grad[:n].clone()
+    core._arena.grad[:n] = local
+    sh.reduce_core(core._arena)
+    single = core._arena.grad[:n].clone()
+    # cut mice: concurrent group reductions == sequential ones
+    arenas = {m: model.mouse_arena(m) for m in sh.local_mice()}
+    for m, a in arenas.items():
+        a.attach_grads()
+        a.grad[:] = float(rank + 1) * (1 + mice.index(m))
+    sh.wait_all(sh.reduce_mice_overlapped(arenas))
+    shared = {m: float(arenas[m].grad[0]) for m in sh.shared_mice()}
+    # gather_mice: every rank ends up with the owner's values and step count
+    for m in mice:
+        a = model.mouse_arena(m)
+        with torch.no_grad():
+            a.data.fill_(100.0 * (sh.owners[m][0] + 1) if rank == sh.owners[m][0] else -1.0)
+        mom, var = a.moments()
+        mom.fill_(float(rank))
+        a.step = 7 if rank == sh.owners[m][0] else 0
+    opt = object()
+    sh.gather_mice(model, opt)
+    gathered = {m: (float(model.mouse_arena(m).data[0]), float(model.mouse_arena(m).exp_avg[0]), model.mouse_arena(m).step) for m in mice}
+    q.put((rank, bool(torch.allclose(bucketed, single, rtol=1e-5, atol=1e-5)), float(single.abs().sum()), shared, {m: list(sh.owners[m]) for m in mice}, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_core(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_core_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=180) for _ in range(world)]
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    sums = set()
+    for rank, same, total, shared, owners, gathered in res:
+        assert same, rank  # same sums; a ring all-reduce adds the ranks in an order that depends on the element's chunk: last bits only
+        sums.add(round(total, 0))
+        for m, v in shared.items():
+            assert v == sum(float(r + 1) for r in owners[m]) * (1 + "ABCDEFG".index(m)), (rank, m, v)
+        for m, (val, mom, step) in gathered.items():
+            src = owners[m][0]
+            assert val == 100.0 * (src + 1) and mom == float(src) and step == 7, (rank, m, val, mom, step)
+    assert len(sums) == 1  # every rank holds the same reduced core gradient
+
+
+def test_bucketed_reduce_and_gather_world2():
+    _run_core(2)
+
+
+def test_bucketed_reduce_and_gather_world4():
+    _run_core(4)
+
+
+def test_bucketed_reduce_and_gather_world8():
+    _run_core(8)

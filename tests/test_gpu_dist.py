@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _step(rank, world, port, q):
+def _step(rank, world, port, q, overlap=True):
     """One train_step with the optimizer replaced by a recorder of the (reduced) gradient arenas."""
     import torch.distributed as dist
 
@@ -35,6 +35,7 @@ def _step(rank, world, port, q):
     from v1t_amd.synthetic import make_ds
     from v1t_amd.trainer import Trainer
 
+    os.environ["V1T_DIST_OVERLAP"] = "1" if overlap else "0"  # read by Trainer.__init__
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -62,11 +63,11 @@ def _step(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _run(world):
+def _run(world, overlap=True):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_step, args=(r, world, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_step, args=(r, world, port, q, overlap)) for r in range(world)]
     [p.start() for p in ps]
     res = [q.get(timeout=300) for _ in range(world)]
     [p.join(timeout=120) for p in ps]
@@ -87,3 +88,70 @@ def test_two_rank_step_equals_single_rank_step():
     assert rel(two[0][2]["A"], ref["A"]) < 2e-3 and rel(two[1][2]["C"], ref["C"]) < 2e-3  # whole mice stay local
     assert "C" not in two[0][2] and "A" not in two[1][2]
     assert abs(two[0][3] + two[1][3] - loss1) <= 1e-4 * abs(loss1)     # the local losses add up to the global one
+    # the default above is the overlapped exchange (per-block buckets behind the backward's events on a communication stream,
+    # concurrent group reductions); the blocking single-shot exchange gives the same reduced gradients
+    blocking = _run(2, overlap=False)
+    for a_, b_ in zip(two, blocking):
+        assert a_[1] == b_[1]
+        for k in a_[2]:
+            assert rel(a_[2][k], b_[2][k]) < 2e-3, k  # float atomics inside the backward: two runs differ in the last bits
+
+
+def _rccl_single_rank(port, q):
+    """One rank, backend nccl (= RCCL): the mechanics of the overlapped exchange on the real library - per-block events recorded
+    by v1t_vit_backward_events, the communication stream waiting on them, asynchronous all-reduces over arena slices, the
+    stream-side wait - with a world of one, where an all-reduce(SUM) must return its input."""
+    import torch.distributed as dist
+
+    from oracle import v1t_oracle as O
+    from oracle import weights as W
+    from tests.helpers import build_native_model
+    from v1t_amd.dist import MouseSharding
+    from v1t_amd.losses import elu1_poisson_loss
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    dev = torch.device("cuda:0")
+    cfg = O.Config(num_blocks=3, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 96}, p_dropout=0.0, t_dropout=0.0)
+    model, _ = build_native_model(cfg, W.make_state_dict(cfg, 17), dev)
+    model.train(False)
+    core = model.core
+    core.prepare()
+    core._arena.attach_grads()
+    core._arena.grad.zero_()
+    sh = MouseSharding(["A"], rank=0, world=1, batch_size=4)
+    sh.world = 2  # take the multi-rank code path; the process group itself has one rank
+    sh.attach_block_events(core)
+    assert core._block_events is not None and len(core._block_events) == 3
+    b = {k: v.to(dev) for k, v in W.make_batch(cfg, "A", 4, 17).items()}
+    u = model(inputs=b["image"], mouse_id="A", behaviors=b["behavior"], pupil_centers=b["pupil_center"], activate=False)[0]
+    loss, _ = elu1_poisson_loss(u, b["response"], 4500.0, 4)
+    loss.backward()
+    works = sh.reduce_core_overlapped(core)
+    sh.wait_all(works)
+    torch.cuda.synchronize()
+    after = core._arena.grad.clone()
+    # reference: the same backward without events / exchange
+    core._block_events = None
+    core._arena.grad.zero_()
+    u = model(inputs=b["image"], mouse_id="A", behaviors=b["behavior"], pupil_centers=b["pupil_center"], activate=False)[0]
+    loss, _ = elu1_poisson_loss(u, b["response"], 4500.0, 4)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = core._arena.grad.clone()
+    err = float((after - ref).abs().max() / (ref.abs().max() + 1e-30))
+    q.put((len(works), err, bool(all(e.query() for e in sh.__dict__.get("_unused", [])))))
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_mechanics_on_rccl_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank, args=(_free_port(), q))
+    p.start()
+    n_works, err, _ = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert n_works >= 4  # 3 block buckets + the late ranges
+    assert err < 2e-3  # float atomics inside the backward: two runs differ in the last bits

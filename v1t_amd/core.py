@@ -127,10 +127,15 @@ class _VitFn(torch.autograd.Function):
         core._arena.attach_grads()
         sb = lib.v1t_vit_scratch_bytes(core._plan, ctx.B)
         scratch = torch.empty(sb, dtype=torch.uint8, device=gout.device)
+        evs = core._block_events  # data-parallel trainer: one event per block, recorded when its gradients are complete
+        ev_arr = None
+        if evs is not None:
+            ev_arr = (C.c_void_p * len(evs))(*[e.cuda_event for e in evs])
         L.check(
-            lib.v1t_vit_backward(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), ctx.images.data_ptr(),
-                                 L.ptr(ctx.behaviors), ctx.mouse_idx, ctx.B, ctx.ws.data_ptr(), scratch.data_ptr(), sb,
-                                 int(ctx.training), ctx.seed, L.ptr(ctx.path_scale), gout.data_ptr(), core._arena.grad.data_ptr(), L.stream()),
+            lib.v1t_vit_backward_events(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), ctx.images.data_ptr(),
+                                        L.ptr(ctx.behaviors), ctx.mouse_idx, ctx.B, ctx.ws.data_ptr(), scratch.data_ptr(), sb,
+                                        int(ctx.training), ctx.seed, L.ptr(ctx.path_scale), gout.data_ptr(), core._arena.grad.data_ptr(),
+                                        ev_arr, L.stream()),
             "vit_backward",
         )
         ctx.ws = None
@@ -238,6 +243,7 @@ class ViTCore(Core):
         self._anchor = torch.zeros((), requires_grad=True)
         self._seed_state = int(getattr(args, "seed", 1234)) * 1000003 + 12345
         self._last_ws = None
+        self._block_events = None  # set by the data-parallel trainer (dist.MouseSharding.reduce_core_overlapped)
         self._path_scale_override = None  # tests: (num_blocks, 2, B) factors to replay instead of drawing them
         self.num_blocks = int(args.num_blocks)
 
@@ -350,6 +356,44 @@ class ViTCore(Core):
         if key != self._packed_key:
             L.check(L.load().v1t_vit_pack(self._plan, a.data.data_ptr(), self._shadow.data_ptr(), L.stream()), "vit_pack")
             self._packed_key = key
+
+    def grad_buckets(self) -> t.List[t.Tuple[int, int, int]]:
+        """(block, start, n) float ranges of the gradient arena in the order the backward completes them: blocks last to
+        first (their attention + MLP parameters, contiguous), then (-1, ...) ranges complete only when the whole backward
+        is: the patch embedding in front of block 0 and every block's BehaviorMLP tail."""
+        a = self._arena
+        names = {id(p): k for k, p in self.named_parameters()}
+        blocks: t.Dict[int, t.List[t.Tuple[int, int]]] = {}
+        late: t.List[t.Tuple[int, int]] = []
+        for sl in sorted((x for x in a.slots if x.is_param), key=lambda x: x.offset):
+            key = names[id(sl.tensor)]
+            if key.startswith("transformer.blocks.") and ".b-mlp." not in key:
+                blocks.setdefault(int(key.split(".")[2]), []).append((sl.offset, sl.numel))
+            else:
+                late.append((sl.offset, sl.numel))
+
+        def runs(rs):
+            out = []
+            for o, n in rs:
+                if out and out[-1][0] + out[-1][1] == o:
+                    out[-1][1] += n
+                else:
+                    out.append([o, n])
+            return [(int(o), int(n)) for o, n in out]
+
+        res = []
+        for k in sorted(blocks, reverse=True):
+            r = runs(blocks[k])
+            assert len(r) == 1, "a block's attention + MLP parameters are contiguous in the arena"
+            res.append((k, r[0][0], r[0][1]))
+        res += [(-1, o, n) for o, n in runs(late)]
+        assert sum(n for _, _, n in res) == a.param_floats
+        return res
+
+    def fold_rank(self, rank: int) -> None:
+        """Distinct dropout streams per data-parallel rank (parameters stay identical): the counter-based masks are keyed by
+        (seed, site, local row), so without this every rank would drop the same positions of its own images."""
+        self._seed_state = (self._seed_state ^ (0x9E3779B97F4A7C15 * (rank + 1))) & 0xFFFFFFFFFFFFFFFF if rank else self._seed_state
 
     def mark_updated(self) -> None:
         """Call after parameters were changed through raw pointers (fused optimizer)."""

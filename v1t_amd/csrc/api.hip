@@ -665,6 +665,13 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
 int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, const float* images, const float* behaviors,
                      int mouse_idx, int B, const void* workspace, void* scratch, long long scratch_bytes, int training,
                      uint64_t seed, const float* path_scale, const float* gout, float* grads, void* stream) {
+    return v1t_vit_backward_events(h, arena, shadow, images, behaviors, mouse_idx, B, workspace, scratch, scratch_bytes, training, seed, path_scale,
+                                   gout, grads, nullptr, stream);
+}
+int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* shadow, const float* images, const float* behaviors,
+                            int mouse_idx, int B, const void* workspace, void* scratch, long long scratch_bytes, int training,
+                            uint64_t seed, const float* path_scale, const float* gout, float* grads, void* const* block_done,
+                            void* stream) {
     if (!h || !arena || !shadow || !images || !workspace || !scratch || !gout || !grads || B <= 0) return V1T_ERR_ARG;
     const WsLayout w = ws_layout(h, B, true);
     const ScratchLayout sl = scratch_layout(h, B);
@@ -790,6 +797,8 @@ int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, c
         }
         lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
         CHECK(launch_ln_bwd(lb, s));
+        // every gradient of block k's attention / MLP parameters is now in `grads` (its BehaviorMLP's follow at the end)
+        if (block_done && block_done[k] && hipEventRecord((hipEvent_t)block_done[k], s) != hipSuccess) return V1T_ERR_LAUNCH;
     }
     // ---- patch embedding backward (gin = grad wrt x0)
     PatchArgs pa{};

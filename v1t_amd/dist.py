@@ -91,6 +91,7 @@ class MouseSharding:
                 if len(self.owners[m]) > 1:
                     self.groups[m] = dist.new_group(ranks=self.owners[m])
         self.batch_size = batch_size
+        self._comm_stream = None
 
     def local_mice(self) -> t.List[str]:
         return [m for m in self.mouse_ids if self.rank in self.owners[m]]
@@ -106,6 +107,8 @@ class MouseSharding:
         return self.batch_size * len(self.mouse_ids)
 
     def reduce_core(self, arena) -> None:
+        """One blocking all-reduce(SUM) over the whole core gradient arena (the reference accumulates, never averages:
+        train.py:97-111)."""
         if self.world > 1:
             dist.all_reduce(arena.grad[: arena.param_floats], op=dist.ReduceOp.SUM)
 
@@ -113,6 +116,80 @@ class MouseSharding:
         g = self.groups.get(mouse_id)
         if g is not None:
             dist.all_reduce(arena.grad, op=dist.ReduceOp.SUM, group=g)
+
+    # ---- overlapped exchange -------------------------------------------------------------------------------------------
+    def reduce_core_overlapped(self, core, bucket_mb: float = 0.0) -> t.List[t.Any]:
+        """Bucketed, asynchronous all-reduce(SUM) of the core gradient arena, one bucket per transformer block (2.2 MB fp32
+        for the default V1T) launched in the order the backward completes them (`ViTCore.grad_buckets`): on the GPU each
+        collective is enqueued on a communication stream behind the event the HIP backward recorded for its block
+        (`v1t_vit_backward_events`), so block k's exchange runs over xGMI while blocks k-1 .. 0 are still in their backward;
+        the patch-embedding / BehaviorMLP ranges follow when the backward is complete. Returns the work handles:
+        `wait_all()` them before the optimizer step. Same sums as `reduce_core` (up to the order in which a ring all-reduce adds
+        the ranks, which depends on an element's chunk: last bits)."""
+        works: t.List[t.Any] = []
+        if self.world <= 1:
+            return works
+        arena = core._arena
+        grad = arena.grad
+        buckets = core.grad_buckets()
+        if not grad.is_cuda:
+            for _, o, n in buckets:
+                works.append(dist.all_reduce(grad[o:o + n], op=dist.ReduceOp.SUM, async_op=True))
+            return works
+        cur = torch.cuda.current_stream()
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        comm = self._comm_stream
+        done = torch.cuda.Event()
+        done.record(cur)  # everything the backward launched (host side: all of it is already enqueued)
+        evs = core._block_events
+        with torch.cuda.stream(comm):
+            for k, o, n in buckets:
+                comm.wait_event(evs[k] if (k >= 0 and evs is not None) else done)
+                works.append(dist.all_reduce(grad[o:o + n], op=dist.ReduceOp.SUM, async_op=True))
+        return works
+
+    def reduce_mice_overlapped(self, arenas: t.Dict[str, t.Any]) -> t.List[t.Any]:
+        """The group reductions of this rank's cut mice, issued together (different groups: they do not serialise) instead
+        of one blocking collective after the other. Collectives are still issued in global mouse order on every rank."""
+        works = []
+        for m in self.shared_mice():
+            g = self.groups.get(m)
+            if g is not None:
+                works.append(dist.all_reduce(arenas[m].grad, op=dist.ReduceOp.SUM, group=g, async_op=True))
+        return works
+
+    @staticmethod
+    def wait_all(works: t.Sequence[t.Any]) -> None:
+        for w in works:
+            w.wait()  # RCCL: makes the current stream wait for the collective; gloo: blocks the host
+
+    def attach_block_events(self, core) -> None:
+        """Create the per-block events the HIP backward records (GPU only; created by a first record)."""
+        if self.world > 1 and core._arena.grad is not None and core._arena.grad.is_cuda and core._block_events is None:
+            evs = [torch.cuda.Event() for _ in range(core.num_blocks)]
+            for e in evs:
+                e.record()
+            core._block_events = evs
+
+    # ---- making every rank whole again (checkpoint / validation / evaluation) -----------------------------------------
+    def gather_mice(self, model, optimizer=None) -> None:
+        """Per-mouse arenas (readout + shifters, and their AdamW moments / step) live only on their owner ranks while training.
+        Before anything looks at the full model - a checkpoint, validation, evaluation - broadcast each mouse's arena from
+        its first owner to every rank. Collective: every rank calls it."""
+        if self.world <= 1:
+            return
+        for m in self.mouse_ids:
+            src = self.owners[m][0]
+            a = model.mouse_arena(m)
+            dist.broadcast(a.data, src=src)
+            if optimizer is not None:
+                mom, var = a.moments()
+                dist.broadcast(mom, src=src)
+                dist.broadcast(var, src=src)
+                st = torch.tensor([float(a.step)], dtype=torch.float64, device=a.data.device)
+                dist.broadcast(st, src=src)
+                a.step = int(st.item())
 
 
 def init_from_env(backend: t.Optional[str] = None) -> t.Tuple[int, int, int]:

@@ -58,8 +58,11 @@ def log_metrics(results: t.Dict[str, t.Dict[str, t.Any]]) -> t.Dict[str, float]:
 
 
 @torch.no_grad()
-def validate(args, ds: t.Dict[str, t.Any], model, criterion, epoch: int = 0) -> t.Dict[str, float]:
-    """reference train.py:160-190"""
+def validate(args, ds: t.Dict[str, t.Any], model, criterion, epoch: int = 0, sharding=None) -> t.Dict[str, float]:
+    """reference train.py:160-190. `sharding`: under mouse-sharded data parallelism the per-mouse modules are current only on
+    their owner ranks: they are gathered first (collective: every rank calls this)."""
+    if sharding is not None:
+        sharding.gather_mice(model)
     model.train(False)
     device = model.device
     mbs = getattr(args, "micro_batch_size", args.batch_size)
@@ -97,8 +100,10 @@ def inference(ds, model, micro_batch_size: int, device: torch.device = None) -> 
 
 
 @torch.no_grad()
-def evaluate(args, ds: t.Dict[str, t.Any], model, print_result: bool = False) -> t.Dict[str, float]:
-    """reference utils/utils.py:103-199: the three challenge metrics per mouse and their averages."""
+def evaluate(args, ds: t.Dict[str, t.Any], model, print_result: bool = False, sharding=None) -> t.Dict[str, float]:
+    """reference utils/utils.py:103-199: the three challenge metrics per mouse and their averages. `sharding`: as `validate`."""
+    if sharding is not None:
+        sharding.gather_mice(model)
     names = ["single_trial_correlation", "correlation_to_average", "feve"]
     results: t.Dict[str, t.Dict[str, float]] = {k: {} for k in names}
     device = model.device

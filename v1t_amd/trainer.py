@@ -141,6 +141,14 @@ class Trainer:
         # reference's loop does (default: all local mouse-batches in one pass)
         self.core_group = int(os.environ.get("V1T_CORE_GROUP", "7"))
         self.batch_core = self.core_group > 1
+        # overlapped exchange (per-block buckets behind the backward's events) by default over RCCL; gloo moves device tensors
+        # through the host and its asynchronous form is pathologically slow there (424 vs 34 ms per step, 2 ranks on one GPU),
+        # so it keeps the blocking single-shot all-reduce. V1T_DIST_OVERLAP=0 / 1 forces either form (dev, tests).
+        ov = os.environ.get("V1T_DIST_OVERLAP", "")
+        backend = torch.distributed.get_backend() if (self.sharding.world > 1 and torch.distributed.is_initialized()) else ""
+        self.overlap = (ov == "1") or (ov != "0" and backend == "nccl")
+        if self.sharding.world > 1:
+            model.core.fold_rank(self.sharding.rank)
 
     def train_step(self, batches: t.Dict[str, t.Dict[str, torch.Tensor]]) -> t.Dict[str, torch.Tensor]:
         """batches: mouse_id -> full batch (image, behavior, pupil_center, response) on the device.
@@ -149,8 +157,11 @@ class Trainer:
         model.train(True)
         core = model.core
         core.prepare()
+        if self.sharding.world > 1 and self.overlap:
+            self.sharding.attach_block_events(core)
         losses = []
         units = []
+        single_pass = True  # one core backward per step: its per-block events are the step's
         for mouse_id, sl in self.sharding.local_units():
             b = batches[mouse_id]
             full = b["image"].shape[0]
@@ -161,6 +172,7 @@ class Trainer:
         if self.core_group > 1 and len(units) > 1 and core.behavior_mode != 4:
             # groups of local mouse-batches through the shared core in one pass, one backward per group (gradients sum as
             # train.py:97-111)
+            single_pass = len(units) <= self.core_group
             for i in range(0, len(units), self.core_group):
                 grp = units[i:i + self.core_group]
                 us = model.forward_mice([(m, b) for m, b, _ in grp], activate=False)
@@ -176,14 +188,24 @@ class Trainer:
                 model.join_streams()  # the readout backward kernels wrote into the mouse arenas on their side streams
                 losses += [l_.detach() for l_ in ls]
         else:
+            single_pass = len(units) <= 1
             for mouse_id, b, full in units:
                 u, _, _ = model(inputs=b["image"], mouse_id=mouse_id, behaviors=b["behavior"], pupil_centers=b["pupil_center"], activate=False)
                 loss, _ = elu1_poisson_loss(u, b["response"], self.ds_sizes[mouse_id], full)
                 loss.backward()
                 losses.append(loss.detach())
-        self.sharding.reduce_core(core._arena)
-        for mouse_id in self.sharding.shared_mice():
-            self.sharding.reduce_mouse(mouse_id, model.mouse_arena(mouse_id))
+        # data-parallel exchange: the core buckets were enqueued behind the per-block events of the backward (they overlap its
+        # tail), the cut mice's group reductions run concurrently; everything is awaited (stream-side) before the optimizer
+        sh = self.sharding
+        if sh.world > 1:
+            if self.overlap and single_pass:
+                works = sh.reduce_core_overlapped(core)
+                works += sh.reduce_mice_overlapped({m: model.mouse_arena(m) for m in sh.shared_mice()})
+                sh.wait_all(works)
+            else:
+                sh.reduce_core(core._arena)
+                for mouse_id in sh.shared_mice():
+                    sh.reduce_mouse(mouse_id, model.mouse_arena(mouse_id))
         # optimizer: core (L1 once per mouse-batch of the global step), then the local mice's arenas
         if not core.frozen:
             ca = core._arena
