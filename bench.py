@@ -2,18 +2,25 @@
 
 Metric (BASELINE.json): training images/sec at batch 16 x 7 mice on 1/2/4/8 MI355X.
 One "step" = one mouse-batch of 16 images per mouse for 7 mice (fwd + bwd, gradients summed) + one
-optimizer step = 112 images (reference train.py:97-111). Workload = BASELINE config C2: default V1T
+optimizer step = 112 images (reference train.py:97-111). Default workload = BASELINE config C2: default V1T
 (4 blocks, D=155, 4 heads x 155, MLP 488, T=1654 tokens), 7 mice x 8000 neurons, input 1x144x256
 resized to 1x36x64 by the cropper stage (inside the timed region), bf16 MFMA / fp32 accumulate,
 dropout ON (p=0.0229 / 0.2544, counter-based masks), readout position sampling ON, AdamW + L1.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config c2|c4|c5|c1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: per-mouse data parallelism (config C3): mice are sharded over ranks, the shared core's gradient
-arena is all-reduced (SUM) over RCCL; total work per step is fixed (112 images) => "scaling": "strong".
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel timed
-live with hipEvents on its stream) and, at N = 1, `cpu_baseline` (the CPU oracle timed on the host).
+--config (one JSON line each; the default c2 is the headline the driver records):
+    c2  BASELINE configs[1] (above)                  c4  configs[3]: Franke-shaped 2x36x64 input, behavior_mode 3, 7 mice x 1121 neurons
+    c1  configs[0]: 1-block / 64-d ViT, 1 mouse, 256 neurons, batch 8 (training step, on the GPU path)
+    c5  configs[4]: eval forward + attention rollout at batch 256 - ROW-CHAIN rollout (16 MFLOP / image), not the 27 GFLOP
+        (T x T) matrix chain of the reference algorithm, of which only row 0 is used (utils/attention_rollout.py:118)
+
+N > 1: per-mouse data parallelism (config C3): mice are sharded over ranks, the shared core's gradient arena is
+all-reduced (SUM) over RCCL in per-block buckets behind the backward; total work per step is fixed (112 images)
+=> "scaling": "strong". Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel timed
+live with hipEvents on its stream; HBM traffic from the tracked PMC summary profiles/r02_pmc_attention.json, which must
+describe the launch shape of this run) and, at N = 1, `cpu_baseline` (the CPU oracle timed on the host).
 """
 from __future__ import annotations
 
@@ -30,11 +37,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_attention.json")
 
 
 def algorithmic_flops(args, n_neurons: int) -> dict:
     """unpadded dims, multiply-add = 2 FLOPs."""
-    c, h, w = 1, 36, 64
+    c, h, w = args.core_input_shape
     P, s = args.patch_size, args.patch_stride
     L = ((h - P) // s + 1) * ((w - P) // s + 1)
     T, D, H, M = L + 1, args.emb_dim, args.num_heads, int(args.mlp_dim)
@@ -43,43 +51,135 @@ def algorithmic_flops(args, n_neurons: int) -> dict:
     return {"T": T, "fwd_per_image": fwd, "train_per_image": 3 * fwd, "attn_fwd_per_image_block": 4 * H * T * T * D}
 
 
-def cpu_baseline(seconds_budget: float = 30.0) -> dict:
-    """The CPU oracle (oracle/v1t_oracle.py, verified against the reference in the build container)
-    timed on this host: default-V1T single-mouse train step (fwd + bwd, fp32) on a bounded sample."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline() -> dict:
+    """The CPU oracle (oracle/v1t_oracle.py, verified against the reference in the build container) timed on this host, fp32,
+    3 reps after one warm-up per leg: C2 train step and eval forward of one mouse, C1 train step. `value` is the
+    C2 training rate (the leg that compares with the headline metric)."""
     from oracle import v1t_oracle as O
     from oracle import weights as W
 
     cores = min(os.cpu_count() or 1, 32)  # more threads than this only adds contention at these GEMM sizes
     torch.set_num_threads(cores)
-    cfg = W.config_c2({"A": 8000})
-    sd = W.make_state_dict(cfg)
-    B = 2
-    batch = W.make_batch(cfg, "A", B)
-    eps = W.make_eps(cfg, "A", B)
 
-    def step():
+    def timed(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    legs = {}
+    t_start = time.time()
+    cfg = W.config_c2({"A": 8000})  # C2: default V1T, one mouse x 8000 neurons
+    sd = W.make_state_dict(cfg)
+    Bt, Be = 4, 8
+    bt, eps = W.make_batch(cfg, "A", Bt), W.make_eps(cfg, "A", Bt)
+    be = W.make_batch(cfg, "A", Be)
+
+    def c2_train():
         sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
-        loss, reg, _ = O.total_loss(cfg, sdd, batch, "A", 4500.0, eps=eps, batch_size=16)
+        loss, reg, _ = O.total_loss(cfg, sdd, bt, "A", 4500.0, eps=eps, batch_size=16)
         (loss + reg).backward()
 
-    step()  # warm-up
-    t0 = time.time()
-    n = 0
-    while True:
-        step()
-        n += 1
-        if time.time() - t0 > seconds_budget * 0.5 or n >= 8:  # about 10-15 s of CPU work
-            break
-    dt = (time.time() - t0) / n
-    return {"value": round(B / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 train step (fwd+bwd, no dropout masks), default V1T, 1 mouse x 8000 neurons, B={B}, {n} reps after 1 warm-up, torch {torch.__version__} CPU, {cores} threads"}
+    def c2_eval():
+        with torch.no_grad():
+            O.model_forward(cfg, sd, be["image"], "A", be["behavior"], be["pupil_center"])
+
+    legs["c2_train"] = {"images_per_s": round(Bt / timed(c2_train), 3), "batch": Bt}
+    legs["c2_eval"] = {"images_per_s": round(Be / timed(c2_eval), 3), "batch": Be}
+    cfg1 = W.config_c1()  # C1: 1-block / 64-d ViT, 256 neurons, batch 8
+    sd1 = W.make_state_dict(cfg1)
+    b1, e1 = W.make_batch(cfg1, "A", 8), W.make_eps(cfg1, "A", 8)
+
+    def c1_train():
+        sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd1.items()}
+        loss, reg, _ = O.total_loss(cfg1, sdd, b1, "A", 4500.0, eps=e1, batch_size=8)
+        (loss + reg).backward()
+
+    legs["c1_train"] = {"images_per_s": round(8 / timed(c1_train), 3), "batch": 8}
+    return {"value": legs["c2_train"]["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "legs": legs,
+            "sample": f"oracle fp32 (no dropout masks): C2 train step (fwd+bwd) 1 mouse x 8000 neurons B={Bt}, C2 eval forward B={Be}, C1 train step B=8; "
+                      f"median of 3 reps after 1 warm-up each, {time.time() - t_start:.0f} s in all, torch {torch.__version__} CPU, {cores} of "
+                      f"{os.cpu_count()} hardware threads"}
 
 
-# (FETCH_SIZE, WRITE_SIZE) in KiB per 112-image launch (all 7 mouse-batches of the default shape in one core pass), dropout
-# on: profiles/r01_pmc_attention_fetch_write.txt, tools/pmc_bench.sh (separate --pmc passes; FETCH_SIZE x2 on gfx950)
-PMC_IMAGES = 112
-PMC_KIB = {"attn_fwd": (422222.9, 522369.0), "attn_bwd_fused": (166139.7 * 7, 104235.2 * 7), "attn_bwd_dkv_store": (623565.6, 2895070.2),
-           "attn_bwd_dq_gemm": (1368689.1, 234988.2)}
+def pmc_traffic(kernel: str, images: int, H: int, T: int, DP: int):
+    """HBM bytes per launch of `kernel` from the tracked PMC summary (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes:
+    tools/pmc_bench.sh, MI355X_MICROARCH.md). Fails when the file is missing or was measured on another launch shape
+    (the traffic of these kernels is proportional to the images of a launch; heads, tokens and head dim must be equal)."""
+    if not os.path.exists(PMC_FILE):
+        raise SystemExit(f"bench.py: {PMC_FILE} is missing (collect it with tools/pmc_bench.sh on the GPU box)")
+    d = json.load(open(PMC_FILE))
+    sh = d["shape"]
+    if (sh["H"], sh["T"], sh["DP"]) != (H, T, DP):
+        raise SystemExit(f"bench.py: {PMC_FILE} was measured on shape {sh}, this run launches H={H} T={T} DP={DP}")
+    if kernel not in d["kernels"]:
+        raise SystemExit(f"bench.py: {PMC_FILE} has no entry for kernel {kernel}")
+    k = d["kernels"][kernel]
+    return (2 * k["fetch_kib"] + k["write_kib"]) * 1024.0 * images / k["images"]
+
+
+KERNELS = {0: ("attn_fwd", "attn_fwd (S = QK^T, softmax, dropout, P.V)", 1.0),
+           1: ("attn_bwd_dq2", "attn_bwd_dq2 (dQ = dS' . K over the materialised dS')", 0.5),
+           2: ("attn_bwd_dkv2", "attn_bwd_dkv2 (producer/consumer dK/dV + dS': the products S, dP, dV, dK)", 2.0)}
+
+
+def run_rollout(a, dev):
+    """C5: eval forward (keeping q/k and the log-sum-exp) + head-max of the recomputed probabilities + rollout rows."""
+    import v1t_amd
+    from v1t_amd import lib as L
+    from v1t_amd.rollout import attention_rollouts
+    from v1t_amd.synthetic import make_batch, sensorium_config
+
+    B = 256
+    args, ds = sensorium_config({"A": a.neurons})
+    args.core_input_shape = (1, 36, 64)
+    torch.manual_seed(args.seed)
+    model = v1t_amd.Model(args, ds).to(dev).train(False)
+    b = make_batch(args, "A", a.neurons, B, dev, seed=0)
+    lib = L.load()
+    with torch.no_grad():
+        images, _ = model.image_cropper(b["image"], "A", b["behavior"], b["pupil_center"])
+        for _ in range(max(a.warmup, 1)):
+            heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], "A")
+        torch.cuda.synchronize()
+        L.check(lib.v1t_profile_enable(0, a.steps * args.num_blocks + 8))
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], "A")
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    launches, total_ms = C.c_int(), C.c_double()
+    L.check(lib.v1t_profile_read(C.byref(launches), C.byref(total_ms)))
+    L.check(lib.v1t_profile_enable(-1, 0))
+    fl = algorithmic_flops(args, a.neurons)
+    avg_ms = total_ms.value / max(launches.value, 1)
+    per_launch = fl["attn_fwd_per_image_block"] * B
+    achieved = per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    return {
+        "metric": "eval forward + attention rollout images/sec at batch 256 (BASELINE configs[4])", "value": round(B * a.steps / dt, 2), "unit": "images/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16+fp16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: default V1T eval forward at batch 256 + attention rollout, ROW-CHAIN form (head-max of the "
+                               "recomputed P per block, then 4 vector-matrix products: 16 MFLOP / image; the reference's (T x T) matrix chain, 27 GFLOP / "
+                               f"image, is not executed - only its row 0 is used downstream), heat-maps {tuple(heat.shape)} included", "global_batch": B},
+        "model_tflops_per_s": round(fl["fwd_per_image"] * B * a.steps / dt / 1e12, 2),
+        "roofline": {"kernel": KERNELS[0][1] + ", eval (no dropout)", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic("attn_fwd_eval", B, args.num_heads, fl["T"], 160),
+                     "launches": launches.value, "avg_ms": round(avg_ms, 4), "flops_per_launch": per_launch},
+    }
 
 
 def main():
@@ -87,8 +187,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--neurons", type=int, default=8000)
+    ap.add_argument("--neurons", type=int, default=None)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c4", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="roofline.traffic = null instead of reading the tracked PMC summary (used while collecting it)")
     ap.add_argument("--profile-class", type=int, default=2, help="kernel class timed with hipEvents (see include/v1t_amd.h)")
     a = ap.parse_args()
 
@@ -96,7 +198,7 @@ def main():
     import v1t_amd
     from v1t_amd import lib as L
     from v1t_amd.dist import MouseSharding, init_from_env
-    from v1t_amd.synthetic import MOUSE_IDS, make_batch, sensorium_config
+    from v1t_amd.synthetic import MOUSE_IDS, default_args, make_batch, make_ds, sensorium_config
     from v1t_amd.trainer import Trainer
 
     rank, local, world = init_from_env()
@@ -108,8 +210,42 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    neurons = {m: a.neurons for m in MOUSE_IDS}
-    args, ds = sensorium_config(neurons)
+    if a.config == "c5":
+        if world > 1:
+            raise SystemExit("config c5 is a single-GPU inference measurement")
+        a.neurons = a.neurons or 8000
+        line = run_rollout(a, dev)
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+        return
+
+    if a.config == "c2":
+        n_neur = a.neurons or 8000
+        neurons = {m: n_neur for m in MOUSE_IDS}
+        args, ds = sensorium_config(neurons)
+        args.core_input_shape = (1, 36, 64)
+        workload = (f"BASELINE configs[1]: default V1T (4 blocks, D=155, 4 heads, MLP 488, T=1654) + Gaussian2d, 7 mice x {n_neur} neurons, input "
+                    "1x144x256 -> 36x64, batch 16 per mouse, dropout+sampling on, AdamW+L1")
+        metric = "training images/sec at batch 16x7 mice (V1T core vit + gaussian2d readout)"
+    elif a.config == "c4":
+        n_neur = a.neurons or 1121
+        neurons = {m: n_neur for m in MOUSE_IDS}
+        args, ds = sensorium_config(neurons, input_shape=(2, 36, 64), ds_name="franke2022", behavior_mode=3)
+        args.core_input_shape = (2, 36, 64)
+        workload = ("BASELINE configs[3]: Franke2022-shaped 2-channel input 2x36x64 (no resize), behavior_mode 3 (BehaviorMLP token injection), default V1T, "
+                    f"7 mice x {n_neur} neurons, batch 16 per mouse, dropout+sampling on, AdamW+L1")
+        metric = "training images/sec at batch 16x7 mice, Franke-shaped input (BASELINE configs[3])"
+    else:  # c1
+        n_neur = a.neurons or 256
+        neurons = {"A": n_neur}
+        args = default_args(input_shape=(1, 36, 64), resize_image=0, num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, batch_size=8)
+        args.output_shapes = {"A": (n_neur,)}
+        args.mouse_ids = ["A"]
+        args.core_input_shape = (1, 36, 64)
+        ds = make_ds(neurons, seed=args.seed)
+        workload = f"BASELINE configs[0]: 1-block / 64-d ViT (4 heads, MLP 128), 1 mouse (36x64 gray, {n_neur} neurons), batch 8, training step"
+        metric = "training images/sec at batch 8, 1 mouse (BASELINE configs[0] on the GPU path)"
     torch.manual_seed(args.seed)  # identical initial core on every rank
     model = v1t_amd.Model(args, ds).to(dev)
     torch.manual_seed(args.seed + 7919 * (rank + 1))  # after the (identical) initialisation: per-rank draws of eps / DropPath
@@ -171,30 +307,21 @@ def main():
 
     if rank == 0:
         images = sharding.images_per_step() * a.steps
-        fl = algorithmic_flops(args, a.neurons)
-        # dominant kernel: attn_bwd_dkv_store (dK/dV of flash backward + the materialised dS'): 4 of the 5 algorithmic
-        # products of the backward (S, dP, dV, dK) = 2.0 x forward attention FLOPs per launch; the fifth (dQ = dS' . K) is
-        # the separate HBM-bound GEMM attn_bwd_dq_gemm (class 1, 0.5 x). With V1T_ATTN_BWD_DS=0 class 2 is the fused
-        # recompute kernel instead (all 5 products, 2.5 x) - the label below follows the switch.
-        fused = os.environ.get("V1T_ATTN_BWD_DS", "1") == "0"
-        names = {0: "attn_fwd", 1: "attn_bwd_dq_gemm (dQ = dS' . K)", 2: "attn_bwd_fused (dQ + dK/dV bodies)" if fused else "attn_bwd_dkv_store (dK/dV + dS')"}
-        mult = {0: 1.0, 1: 0.5, 2: 2.5 if fused else 2.0}[a.profile_class] if a.profile_class in (0, 1, 2) else 0.0
+        fl = algorithmic_flops(args, n_neur)
+        # dominant kernel (class 2): the producer / consumer dK/dV kernel = 4 of the 5 algorithmic products of the flash backward
+        # (S, dP, dV, dK) = 2.0 x the forward attention FLOPs per launch; the fifth (dQ = dS' . K) is the HBM-bound GEMM (class 1)
+        key, label, mult = KERNELS.get(a.profile_class, (None, str(a.profile_class), 0.0))
         # images per launch: the trainer runs the shared core over all local mouse-batches at once (one launch per block)
         units = sharding.local_units()
         per_rank = sum(args.batch_size if sl is None else (sl.stop - sl.start) for _, sl in units)
         imgs_launch = min(per_rank, trainer.core_group * args.batch_size) if (trainer.batch_core and len(units) > 1) else args.batch_size
         per_launch = mult * fl["attn_fwd_per_image_block"] * imgs_launch
-        # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, KiB, separate --pmc
-        # passes: profiles/r01_pmc_attention_fetch_write.txt, tools/pmc_attn.sh); recorded, not collected live, and
-        # only valid for the shape it was measured on (16 images x 4 heads x 1654 tokens x 160 padded head dim)
-        default_shape = args.batch_size == 16 and a.neurons == 8000
-        traffic = {0: PMC_KIB["attn_fwd"], 1: PMC_KIB["attn_bwd_dq_gemm"], 2: PMC_KIB["attn_bwd_fused" if fused else "attn_bwd_dkv_store"]}.get(a.profile_class)
-        # (measured on 112-image launches; the kernels' traffic is proportional to the images of a launch)
-        traffic = (2 * traffic[0] + traffic[1]) * 1024 * imgs_launch / PMC_IMAGES if (default_shape and traffic) else None
+        DPad = (args.emb_dim + 31) // 32 * 32
+        traffic = pmc_traffic(key, imgs_launch, args.num_heads, fl["T"], DPad) if (key and DPad >= 128 and not a.no_pmc) else None
         avg_ms = total_ms.value / max(launches.value, 1)
         achieved = per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         line = {
-            "metric": "training images/sec at batch 16x7 mice (V1T core vit + gaussian2d readout)",
+            "metric": metric,
             "value": round(images / dt, 2),
             "unit": "images/s",
             "n_gpus": world,
@@ -206,14 +333,12 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16+fp16",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: default V1T (4 blocks, D=155, 4 heads, MLP 488, T=1654) + Gaussian2d, 7 mice x "
-                                   f"{a.neurons} neurons, input 1x144x256 -> 36x64, batch 16 per mouse, dropout+sampling on, AdamW+L1",
-                       "global_batch": sharding.images_per_step(), "parallelism": f"mouse-dp{world}",
+            "config": {"workload": workload, "global_batch": sharding.images_per_step(), "parallelism": f"mouse-dp{world}",
                        "exchange": ("bucketed async all-reduce behind per-block events" if trainer.overlap else "blocking all-reduce") if world > 1 else "none"},
             "loss": loss,
             "model_tflops_per_s": round(fl["train_per_image"] * images / dt / 1e12, 2),
             "model_frac_of_bf16_peak": round(fl["train_per_image"] * images / dt / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
-            "roofline": {"kernel": names.get(a.profile_class, str(a.profile_class)), "bound": "mfma", "achieved": round(achieved, 2),
+            "roofline": {"kernel": label, "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches": launches.value, "avg_ms": round(avg_ms, 4), "flops_per_launch": per_launch},
         }
