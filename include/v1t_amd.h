@@ -33,7 +33,7 @@ const char* v1t_error_string(int code);
 /* ---------------------------------------------------------------- ViT core (core/vit.py:365-436) */
 typedef struct v1t_vit_config {
     int in_channels, in_h, in_w;      /* core input shape = ImageCropper.output_shape (model.py:78) */
-    int patch_size, patch_stride, patch_mode; /* vit.py:384-391; patch_mode 0/1 supported natively */
+    int patch_size, patch_stride, patch_mode; /* vit.py:384-391; patch_mode 0 (unfold+linear), 1 (conv), 2 (SPT), 3 (dual PatchNorm): all native */
     int emb_dim, num_heads, mlp_dim, num_blocks; /* vit.py:392-398; head dim = emb_dim (vit.py:218) */
     int behavior_mode;                /* 0 none, 2/3 shared B-MLP, 4 per-mouse B-MLP (vit.py:157-202) */
     int num_mice;                     /* B-MLP instances when behavior_mode == 4, else ignored */

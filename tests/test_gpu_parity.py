@@ -445,6 +445,20 @@ def test_attention_rollout_vs_reference_golden(golden, dev):
     assert corr > 0.9995
     # head-max maps: rows sum to (rowsum - 1); probabilities in [0, 1]
     assert float(maps[0].min()) >= 0.0 and float(maps[0].max()) <= 1.0
+    # Recorder-compatible surface: (outputs, attentions (B, blocks, 1, T, T)); the reference's own rollout of those maps (its
+    # first step, the max over the head axis, is the identity on them) restated by the oracle gives the same rows
+    from v1t_amd.rollout import Recorder
+
+    rec = Recorder(model.core)
+    out, attn = rec(b["image"], b["behavior"], b["pupil_center"], "A")
+    T = model.core.num_tokens
+    assert attn.shape == (2, cfg.num_blocks, 1, T, T) and out.shape == (2, *model.core.output_shape)
+    for i in range(2):
+        r = O.attention_rollout_row(attn[i].cpu())
+        assert rel_to_max(r.numpy(), ref_rows[i]) < 2e-3
+    assert rec.eject() is model.core
+    with pytest.raises(AssertionError):
+        rec(b["image"], b["behavior"], b["pupil_center"], "A")
 
 
 def test_attention_rollout_vs_oracle_default_size(dev):

@@ -1,24 +1,27 @@
 // v1t_amd — fused attention kernels (gfx950). See attention.h.
 //
-// Common geometry: workgroup = 4 waves, one (batch, head); a wave owns 32 rows (queries in the
-// forward and dQ kernels, keys in the dK/dV kernel) and walks the other axis in tiles of 32.
 // All products are "swapped" so that the softmax axis bookkeeping is lane-local:
-//   forward : S^T[key][q] = K . Q^T   (A = K tile rows from LDS, B = Q fragments in registers)
+//   forward (attn_fwd_kernel; 8 waves x 32 queries share each 64-key K/V stage):
+//             S^T[key][q] = K . Q^T   (A = K tile rows from LDS, B = Q fragments in registers)
 //             q sits on the lane, the 32 keys of a tile in 16 registers x 2 lane halves, so the
 //             row max/sum is 15 in-lane ops + one cross-half exchange;
 //             O^T[d][q] += V^T . P^T   (A = V tile read TRANSPOSED with ds_read_b64_tr_b16,
 //             B = the S^T accumulator converted to bf16 in place — no LDS round trip).
-//   dQ      : same orientation; dQ^T[d][q] += K^T . dS^T.
-//   dK/dV   : S[q][key] = Q . K^T (key on the lane), dV^T += dO^T . P, dK^T += Q^T . dS.
-// The backward is split into a dQ kernel and a dK/dV kernel (7 MFMA products instead of 5): a
-// single-kernel backward needs fp32 atomics for dQ, and at T=1654, dh=160 those atomic bytes
-// (B*H*T*160*4 per 128-key block) exceed the chip's ~1.3 TB/s atomic rate by far.
+//   backward, default (head dim >= 128, no LSA diagonal): 5 MFMA products.
+//             attn_bwd_dkv2_kernel: producer / consumer wave roles, key on the lane: S = Q . K^T, dP = dO . V^T (producers),
+//             dV^T += dO^T . P, dK^T += Q^T . dS' (consumers); the bf16 dS' = P (dP - delta) is also stored to HBM and
+//             attn_bwd_dq2_kernel computes dQ = dS' . K as a streaming GEMM over it. A single-kernel backward would need
+//             fp32 atomics for dQ: at T=1654, dh=160 those bytes (B*H*T*160*4 per 128-key block, 3 GB per 112-image launch)
+//             exceed the chip's ~1.3 TB/s atomic rate by far.
+//   backward, LSA (diagonal mask + learnable per-head scale) and small head dims: attn_bwd_dq_body + attn_bwd_dkv_body
+//             (4 waves, one wave per SIMD, 7 products: S and dP are recomputed in the dQ body), fused in one launch.
 //
-// The element-wise work between the MFMAs shares the SIMD's issue slots with them, so it is kept
-// branch-free and minimal: dropout / LSA-diagonal / tail masking are template parameters (no runtime
+// The element-wise work between the MFMAs shares the SIMD's vector issue port with them (an MFMA holds it 8 of its 32
+// cycles; a lone wave issues one vector instruction per ~4.5 cycles whatever its kind: tools/microbench/valu_issue_cost.hip),
+// so it is kept branch-free and minimal: dropout / LSA-diagonal / tail masking are template parameters (no runtime
 // flags in the loop), only the last tile carries bounds checks, the softmax scale is folded into the
-// exp2 argument (one fma + one v_exp per element), 1/keep and the score scale are folded into the
-// epilogue, and the dropout mask costs one 32-bit hash per 2x2 (query, key) block (common.h).
+// exp2 argument, 1/keep and the score scale are folded into the epilogue, and the dropout mask costs one 32-bit hash per
+// 2x2 (query, key) block (common.h).
 #include <type_traits>
 
 #include <cstdlib>

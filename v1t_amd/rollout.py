@@ -32,6 +32,7 @@ def rollout_rows(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, p
     core.train(False)
     try:
         tokens = core.forward_tokens(images, mouse_id, behaviors, pupil_centers, keep_workspace=True)
+        core._last_tokens = tokens
     finally:
         core.train(was_training)
     lib = L.load()
@@ -58,6 +59,37 @@ def rollout_rows(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, p
             maps.append(A[:, :, :T].clone())
     rows = v[:, 1:]
     return (rows, maps[::-1]) if return_headmax else rows
+
+
+class Recorder(torch.nn.Module):
+    """Counterpart of the reference `Recorder` (attention_rollout.py:15-77) for the native core. The reference hooks every
+    block's `Attention.attend` (nn.Softmax) module; the fused attention has no such module - P is never materialised - so the
+    hook surface cannot exist. This class offers the same constructor / `forward` / `eject` / `clear` and returns what the
+    reference's own `attention_rollouts(attentions, image_shape)` consumes: `attentions` of shape (B, blocks, 1, T, T) holding
+    the MAX OVER HEADS of the softmax probabilities (recomputed from the saved q/k and log-sum-exp by `v1t_rollout_headmax`).
+    The reference's first step is exactly that maximum (`torch.max(attention, dim=1)`, :105), which over a singleton head axis
+    is the identity, so its heat-maps come out the same while the tensor is `heads` times smaller (43.8 MB instead of 175 MB
+    per image at the default size). Per-head probabilities are not available from the native core."""
+
+    def __init__(self, core: ViTCore):
+        super().__init__()
+        self.core = core
+        self.ejected = False
+
+    def eject(self):
+        self.ejected = True
+        return self.core
+
+    def clear(self):
+        torch.cuda.empty_cache()
+
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor, behaviors: torch.Tensor, pupil_centers: torch.Tensor, mouse_id: str):
+        assert not self.ejected, "recorder has been ejected, cannot be used anymore"
+        core = self.core
+        _, maps = rollout_rows(core, images, behaviors, pupil_centers, mouse_id, return_headmax=True)
+        tokens = core._last_tokens
+        return core.tokens_to_output(tokens), torch.stack(maps, dim=1)[:, :, None]
 
 
 @torch.no_grad()
