@@ -157,6 +157,12 @@ int v1t_readout_grid_backward_ws(int B, int N, int gd, const float* src, const f
                                  const float* eps, const float* dgrid, float* dW0, float* db0, float* dW2,
                                  float* db2, float* dmu_free, float* dsigma, float* dshift, void* ws,
                                  long long ws_bytes, void* stream);
+/* The readout's position noise (gaussian2d.py:219-221: `norm = mu.new(...).normal_()`): n standard normal deviates from the
+ * counter hash of (seed, stream_id), Box-Muller pairs; stateless (a step's draw can be replayed), one launch. */
+int v1t_normal_fill(float* out, long long n, uint64_t seed, uint32_t stream_id, void* stream);
+/* out[r][0..na) = a[r][:], out[r][na..na+nb) = b[r][:], out rows ldo floats apart: the BehaviorMLP input
+ * torch.cat((behaviors, pupil_centers), dim=-1) (vit.py:431-432) written straight into a shared batch buffer. */
+int v1t_concat2(const float* a, int na, const float* b, int nb, int rows, float* out, int ldo, void* stream);
 /* CoreShifter MLP 2->5->5->2, tanh after every layer (core_shifter.py:24-40; model.py:86-92) */
 int v1t_core_shifter_forward(int B, const float* pupil, const float* W0, const float* b0, const float* W2,
                              const float* b2, const float* W4, const float* b4, float* shift, void* stream);

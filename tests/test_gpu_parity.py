@@ -534,3 +534,60 @@ def test_core_batched_over_mice_equals_per_mouse(dev, variant):
     model.core.behavior_mode = 4
     with pytest.raises(NotImplementedError):
         model.core.forward_many([b["image"] for _, b in pairs], [m for m, _ in pairs], [b["behavior"] for _, b in pairs], [b["pupil_center"] for _, b in pairs])
+
+
+@pytest.mark.parametrize("variant", [{}, {"behavior_mode": 0, "shift_mode": 0}, {"disable_grid_predictor": True, "behavior_mode": 2}, {"input_shape": (2, 36, 64)}])
+def test_native_step_equals_autograd_step(dev, variant):
+    """Trainer's autograd-free step (_NativeStep: the C-ABI entry points called directly, persistent buffers, in-kernel eps) against
+    the nn.Module + autograd path on the same model, batches and replayed eps: every gradient arena and the loss."""
+    from v1t_amd.synthetic import make_ds
+    from v1t_amd.trainer import Trainer
+
+    cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B", "C"), num_neurons={"A": 96, "B": 50, "C": 130},
+                   p_dropout=0.0, t_dropout=0.0, **variant)
+    sd = W.make_state_dict(cfg, 21)
+    sizes = {"A": 4, "B": 4, "C": 4}
+    batches = {m: {k: v.to(dev) for k, v in W.make_batch(cfg, m, sizes[m], 21).items()} for m in cfg.mouse_ids}
+    eps = {m: W.make_eps(cfg, m, sizes[m], 21).to(dev) for m in cfg.mouse_ids}
+    recs = []
+    for native in (False, True):
+        model, args = build_native_model(cfg, sd, dev)
+        args.batch_size = 4
+        tr = Trainer(args, model, make_ds(cfg.num_neurons))
+        tr.native = native
+        if native:
+            tr.eps_override = eps
+        else:
+            for m in cfg.mouse_ids:
+                ro = model.readouts[m]
+                ro.forward = (lambda inputs, sample=None, shifts=None, eps=None, _o=ro.forward, _e=eps[m]: _o(inputs, sample=sample, shifts=shifts, eps=_e))
+        rec = {}
+        names = {id(model.core._arena): "core", **{id(model.mouse_arena(m)): m for m in cfg.mouse_ids}}
+        tr.opt.step_arena = lambda arena, ranges, zero_grad=True, _r=rec, _n=names: _r.__setitem__(_n[id(arena)], arena.grad.detach().clone())
+        out = tr.train_step(batches)
+        torch.cuda.synchronize()
+        assert (len(tr._native_cache) == 1 and next(iter(tr._native_cache.values())) is not None) == native
+        recs.append((rec, float(out["loss"])))
+    (ref, loss_ref), (got, loss) = recs
+    assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref)
+    assert set(ref) == set(got) == {"core", "A", "B", "C"}
+    for k in ref:
+        assert rel_to_max(got[k], ref[k]) < 2e-3, k  # float atomics in both paths: last bits
+
+
+def test_native_step_eps_statistics(dev):
+    """The in-kernel position noise (v1t_normal_fill, Box-Muller over the counter hash) is standard normal, differs from step to
+    step and from mouse to mouse, and is reproducible for a given (seed, stream)."""
+    from v1t_amd import lib as L
+
+    lib = L.load()
+    n = 2_000_001
+    a, b, c = (torch.empty(n, device=dev) for _ in range(3))
+    L.check(lib.v1t_normal_fill(a.data_ptr(), n, 1234, 0x10000, L.stream()))
+    L.check(lib.v1t_normal_fill(b.data_ptr(), n, 1234, 0x10000, L.stream()))
+    L.check(lib.v1t_normal_fill(c.data_ptr(), n, 1234, 0x10100, L.stream()))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(a.mean())) < 3e-3 and abs(float(a.std()) - 1) < 3e-3
+    assert abs(float((a ** 3).mean())) < 1e-2 and abs(float((a ** 4).mean()) - 3) < 3e-2  # skewness 0, kurtosis 3
+    assert abs(float((a[:-1] * a[1:]).mean())) < 3e-3 and abs(float((a * c).mean())) < 3e-3  # neighbours / streams uncorrelated
+    assert float(a.abs().max()) < 6.5 and bool(torch.isfinite(a).all())

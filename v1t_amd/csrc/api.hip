@@ -940,6 +940,14 @@ int v1t_readout_grid_backward_ws(int B, int N, int gd, const float* src, const f
     a.eps = eps; a.dgrid = dgrid; a.dW0 = dW0; a.db0 = db0; a.dW2 = dW2; a.db2 = db2; a.dmu_free = dmu_free; a.dsigma = dsigma; a.dshift = dshift;
     return launch_grid_bwd(a, ws, (size_t)(ws_bytes < 0 ? 0 : ws_bytes), (hipStream_t)stream);
 }
+int v1t_normal_fill(float* out, long long n, uint64_t seed, uint32_t stream_id, void* stream) {
+    if (!out || n < 0) return V1T_ERR_ARG;
+    return launch_normal_fill(out, n, seed, stream_id, (hipStream_t)stream);
+}
+int v1t_concat2(const float* a, int na, const float* b, int nb, int rows, float* out, int ldo, void* stream) {
+    if (!out || rows < 0 || na < 0 || nb < 0 || (na && !a) || (nb && !b) || ldo < na + nb) return V1T_ERR_ARG;
+    return launch_concat2(a, na, b, nb, rows, out, ldo, (hipStream_t)stream);
+}
 int v1t_core_shifter_forward(int B, const float* pupil, const float* W0, const float* b0, const float* W2, const float* b2, const float* W4,
                              const float* b4, float* shift, void* stream) {
     if (!pupil || !W0 || !b0 || !W2 || !b2 || !W4 || !b4 || !shift) return V1T_ERR_ARG;

@@ -47,3 +47,5 @@ struct ShifterArgs {
 };
 int launch_shifter_fwd(const ShifterArgs& a, hipStream_t s);
 int launch_shifter_bwd(const ShifterArgs& a, hipStream_t s);
+int launch_normal_fill(float* out, long long n, uint64_t seed, uint32_t stream_id, hipStream_t s);
+int launch_concat2(const float* a, int na, const float* b, int nb, int rows, float* out, int ldo, hipStream_t s);

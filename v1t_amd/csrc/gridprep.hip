@@ -377,3 +377,40 @@ int launch_shifter_bwd(const ShifterArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(shifter_bwd_kernel, dim3(1), dim3(256), 0, s, a);
     return ok();
 }
+
+// ---- standard normal deviates from the counter hash (the readout's position noise eps ~ N(0, I), gaussian2d.py:219-221):
+// element pair (2 i, 2 i + 1) = Box-Muller of two 24-bit uniforms hashed from (key, i). Stateless, so the draw of a step is a
+// function of (seed, stream id) and can be replayed; replaces a torch normal_() launch on torch's Philox stream.
+__global__ __launch_bounds__(256) void normal_fill_kernel(float* out, long long n, uint32_t key) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // pair index
+    if (2 * i >= n) return;
+    const uint32_t h1 = mix32(key + (uint32_t)i * 0x9E3779B1u), h2 = mix32(h1 ^ 0x85EBCA77u ^ (uint32_t)(i >> 32));
+    const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    out[2 * i] = r * cs;
+    if (2 * i + 1 < n) out[2 * i + 1] = r * sn;
+}
+int launch_normal_fill(float* out, long long n, uint64_t seed, uint32_t stream_id, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    const long long pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, out, n, drop_key(seed, stream_id));
+    return ok();
+}
+// out[r][0 .. na) = a[r][:], out[r][na .. na + nb) = b[r][:]  (the BehaviorMLP input cat(behaviors, pupil_centers), vit.py:431-432,
+// written straight into a batch buffer shared by several mice)
+__global__ __launch_bounds__(256) void concat2_kernel(const float* a, int na, const float* b, int nb, int rows, float* out, int ldo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int w = na + nb;
+    if (i >= rows * w) return;
+    const int r = i / w, c = i % w;
+    out[(size_t)r * ldo + c] = c < na ? a[(size_t)r * na + c] : b[(size_t)r * nb + (c - na)];
+}
+int launch_concat2(const float* a, int na, const float* b, int nb, int rows, float* out, int ldo, hipStream_t s) {
+    const int n = rows * (na + nb);
+    if (n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(concat2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, na, b, nb, rows, out, ldo);
+    return ok();
+}

@@ -65,6 +65,8 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_gaussian2d_backward_ws": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     "v1t_readout_grid_forward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 11),
     "v1t_readout_grid_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 17),
+    "v1t_normal_fill": (c_int, [c_void_p, c_ll, c_u64, c_u32, c_void_p]),
+    "v1t_concat2": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "v1t_core_shifter_forward": (c_int, [c_int] + [c_void_p] * 9),
     "v1t_core_shifter_backward": (c_int, [c_int] + [c_void_p] * 15),
     "v1t_elu1_poisson": (c_int, [c_void_p, c_void_p, c_ll, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -14,6 +14,8 @@ MI355X-first differences (same math):
 from __future__ import annotations
 
 import contextlib
+import ctypes as C
+import math
 import os
 import typing as t
 
@@ -125,6 +127,195 @@ class FusedAdamW:
                     "adamw_step")
 
 
+class _NativeStep:
+    """One optimizer step's forward + backward for a fixed list of (mouse, n images) units WITHOUT torch autograd or ATen
+    kernels on the way: every buffer is allocated once, the C-ABI entry points are called directly in the order autograd would
+    run them, gradients land in the flat arenas. Same math as `Model.forward_mice` + `elu1_poisson_loss` + `.backward()` (what the
+    reference's loop over mice computes, train.py:42-116); what disappears is ~130 small launches per step (zero-fills, copies,
+    cat / stack / add kernels, torch's Philox normal_()) and the autograd bookkeeping on the host - the fixed cost that limits
+    the data-parallel speed-up when a rank only has 14 images.
+
+    Falls back (returns None from `build`) when the configuration needs something only the module path does: per-mouse
+    BehaviorMLPs (behavior_mode 4), a learned image shifter / centre crop / behaviour-as-channels in the cropper, stochastic depth,
+    another readout type, or a readout whose `forward` was overridden on the instance (tests inject eps that way)."""
+
+    @staticmethod
+    def build(trainer: "Trainer", units: t.Sequence[t.Tuple[str, t.Dict[str, torch.Tensor], int]]) -> t.Optional["_NativeStep"]:
+        from .readout import Gaussian2DReadout
+
+        model = trainer.model
+        core, crop = model.core, model.image_cropper
+        if core.behavior_mode == 4 or core.frozen or core.drop_path_rate > 0 or not units:
+            return None
+        if crop.image_shifter is not None or crop.crop_scale < 1 or crop.behavior_mode == 1:
+            return None
+        for m, _, _ in units:
+            ro = model.readouts[m]
+            if type(ro) is not Gaussian2DReadout or "forward" in ro.__dict__:
+                return None
+            if model.core_shifter is not None and len(model.core_shifter[m].mlp) != 6:
+                return None
+        return _NativeStep(trainer, units)
+
+    def __init__(self, trainer: "Trainer", units):
+        model = trainer.model
+        core = model.core
+        lib = L.load()
+        dev = core._arena.data.device
+        self.sig = tuple((m, int(b["image"].shape[0])) for m, b, _ in units)
+        self.B = sum(n for _, n in self.sig)
+        B, T, DP = self.B, core.num_tokens, core.padded_dim
+        c, h, w = core.input_shape
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.img = torch.empty((B, c, h, w), **f32)
+        self.nbeh = {0: 0, 2: 3, 3: 5}[core.behavior_mode if core.behavior_mode in (2, 3) else 0]
+        self.beh = torch.empty((B, max(self.nbeh, 1)), **f32) if self.nbeh else None
+        self.tokens = torch.empty((B, T, DP), **f32)
+        self.gout = torch.empty((B, T, DP), **f32)
+        self.ws_bytes = int(lib.v1t_vit_workspace_bytes(core._plan, B, 1))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.sb = int(lib.v1t_vit_scratch_bytes(core._plan, B))
+        self.scratch = torch.empty(self.sb, dtype=torch.uint8, device=dev)
+        # zeroed once per step: the per-unit loss scalars and the d shift accumulators
+        nz = len(units) + sum(2 * n for _, n in self.sig)
+        self.zeros = torch.zeros(nz, **f32)
+        self.tails = []
+        zo = len(units)
+        C_, gh, gw = core.output_shape
+        for i, (m, n) in enumerate(self.sig):
+            ro = model.readouts[m]
+            N = ro.num_neurons
+            t_ = dict(m=m, n=n, N=N, ro=ro, loss=self.zeros[i:i + 1], dshift=self.zeros[zo:zo + 2 * n].view(n, 2))
+            zo += 2 * n
+            t_["shift"] = torch.empty((n, 2), **f32) if model.core_shifter is not None else None
+            t_["eps"] = torch.empty((n, N, 2), **f32)
+            t_["grid"] = torch.empty((n, N, 2), **f32)
+            t_["dgrid"] = torch.empty((n, N, 2), **f32)
+            t_["u"] = torch.empty((n, N), **f32)
+            t_["yhat"] = torch.empty((n, N), **f32)
+            t_["du"] = torch.empty((n, N), **f32)
+            t_["rws"] = torch.empty(max(int(lib.v1t_gaussian2d_backward_ws_bytes(n, gh, gw, N)), 1), dtype=torch.uint8, device=dev)
+            t_["gws"] = torch.empty(max(int(lib.v1t_readout_grid_backward_ws_bytes(n, N)), 1), dtype=torch.uint8, device=dev)
+            self.tails.append(t_)
+        self.geom = (C_, gh, gw, T, DP)
+        self.generation = None  # arena generations the cached pointers belong to
+
+    def _pointers(self, trainer: "Trainer") -> None:
+        """Data / gradient pointers of every per-mouse parameter (views of the mouse arenas; re-derived when an arena was rebuilt)."""
+        model = trainer.model
+        gen = tuple(model.mouse_arena(t_["m"]).generation for t_ in self.tails)
+        if gen == self.generation:
+            return
+        for t_ in self.tails:
+            a = model.mouse_arena(t_["m"])
+            a.attach_grads()
+            slot = {id(s.tensor): s for s in a.slots}
+            gptr = lambda p: a.grad.data_ptr() + 4 * slot[id(p)].offset  # noqa: E731
+            ro = t_["ro"]
+            ro.feature_storage()
+            t_["feat"], t_["dfeat"], t_["FS"] = a.data.data_ptr() + 4 * slot[id(ro.features)].offset, gptr(ro.features), ro.feat_stride
+            t_["bias"], t_["dbias"] = (ro.bias.data_ptr(), gptr(ro.bias)) if ro.bias is not None else (None, None)
+            t_["sigma"], t_["dsigma"] = ro.sigma.data_ptr(), gptr(ro.sigma)
+            if ro._predicted_grid:
+                l0, l2 = ro.mu_transform[0], ro.mu_transform[2]
+                t_["gd"], t_["src"] = int(ro.source_grid.shape[1]), ro.source_grid.data_ptr()
+                t_["gp"] = [l0.weight.data_ptr(), l0.bias.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr()]
+                t_["dgp"] = [gptr(l0.weight), gptr(l0.bias), gptr(l2.weight), gptr(l2.bias)]
+                t_["mu"], t_["dmu"] = None, None
+            else:
+                t_["gd"], t_["src"], t_["gp"], t_["dgp"] = 0, None, [None] * 4, [None] * 4
+                t_["mu"], t_["dmu"] = ro._mu.data_ptr(), gptr(ro._mu)
+            if model.core_shifter is not None:
+                ml = model.core_shifter[t_["m"]].mlp
+                ps = [ml[0].weight, ml[0].bias, ml[2].weight, ml[2].bias, ml[4].weight, ml[4].bias]
+                t_["sp"], t_["dsp"] = [p.data_ptr() for p in ps], [gptr(p) for p in ps]
+        self.generation = gen
+
+    def run(self, trainer: "Trainer", units) -> torch.Tensor:
+        model = trainer.model
+        core, crop = model.core, model.image_cropper
+        lib = L.load()
+        self._pointers(trainer)
+        C_, gh, gw, T, DP = self.geom
+        main = torch.cuda.current_stream()
+        st = main.cuda_stream
+        self.zeros.zero_()
+        self.gout.zero_()
+        # ---- inputs straight into the shared batch buffers
+        off = 0
+        for (m, b, _), (_, n) in zip(units, self.sig):
+            src = b["image"]
+            if src.dtype != torch.float32 or not src.is_contiguous():
+                src = src.to(torch.float32).contiguous()
+            dst = self.img[off:off + n]
+            if crop.resize is not None:
+                L.check(lib.v1t_resize_bilinear(src.data_ptr(), n * src.shape[1], src.shape[2], src.shape[3], dst.data_ptr(), crop.resize[0], crop.resize[1], st),
+                        "resize_bilinear")
+            else:
+                dst.copy_(src)
+            if self.nbeh:
+                beh, pup = b["behavior"].to(torch.float32).contiguous(), b["pupil_center"].to(torch.float32).contiguous()
+                L.check(lib.v1t_concat2(beh.data_ptr(), 3, pup.data_ptr() if self.nbeh == 5 else None, 2 if self.nbeh == 5 else 0, n,
+                                        self.beh[off:off + n].data_ptr(), self.nbeh, st), "concat2")
+            off += n
+        # ---- shared core, one pass over all units
+        seed = core._next_seed()
+        L.check(lib.v1t_vit_forward(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), self.img.data_ptr(), L.ptr(self.beh), 0, self.B,
+                                    self.ws.data_ptr(), self.ws_bytes, 1, 1, seed, None, self.tokens.data_ptr(), st), "vit_forward")
+        core._last_ws = (self.ws, self.B, True)
+        # ---- per-mouse tails (shifter, sample positions, readout, loss and all their backward) on side streams
+        streams = model._side_streams(len(units)) if (model.readout_streams and len(units) > 1) else None
+        trainer._eps_state = (trainer._eps_state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        off = 0
+        for i, ((m, b, full), t_) in enumerate(zip(units, self.tails)):
+            n, N, ro = t_["n"], t_["N"], t_["ro"]
+            if streams:
+                streams[i].wait_stream(main)
+            with (torch.cuda.stream(streams[i]) if streams else contextlib.nullcontext()):
+                s_ = torch.cuda.current_stream().cuda_stream
+                pup = b["pupil_center"].to(torch.float32).contiguous()
+                y = b["response"].to(torch.float32).contiguous()
+                if t_["shift"] is not None:
+                    L.check(lib.v1t_core_shifter_forward(n, pup.data_ptr(), *t_["sp"], t_["shift"].data_ptr(), s_), "core_shifter_forward")
+                ov = trainer.eps_override.get(m) if trainer.eps_override else None
+                if ov is not None:
+                    t_["eps"].copy_(ov.reshape(n, N, 2))
+                else:
+                    L.check(lib.v1t_normal_fill(t_["eps"].data_ptr(), n * N * 2, trainer._eps_state, 0x10000 + 256 * trainer.mouse_ids.index(m) + trainer.sharding.rank, s_),
+                            "normal_fill")
+                if t_["mu"] is not None:
+                    with torch.no_grad():
+                        ro._mu.clamp_(min=-1, max=1)  # gaussian2d.py:212-215 (acts on the free parameter only)
+                L.check(lib.v1t_readout_grid_forward(n, N, t_["gd"], t_["src"], *t_["gp"], t_["mu"], t_["sigma"], t_["eps"].data_ptr(), L.ptr(t_["shift"]),
+                                                     t_["grid"].data_ptr(), s_), "readout_grid_forward")
+                zptr = self.tokens.data_ptr() + 4 * (off * T * DP + DP)  # this unit's images, CLS row skipped
+                gptr = self.gout.data_ptr() + 4 * (off * T * DP + DP)
+                L.check(lib.v1t_gaussian2d_forward(zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["bias"], t_["u"].data_ptr(), s_),
+                        "gaussian2d_forward")
+                scale = math.sqrt(trainer.ds_sizes[m] / full)
+                L.check(lib.v1t_elu1_poisson(t_["u"].data_ptr(), y.data_ptr(), n * N, scale, 1.0, t_["yhat"].data_ptr(), t_["du"].data_ptr(), t_["loss"].data_ptr(), s_),
+                        "elu1_poisson")
+                L.check(lib.v1t_gaussian2d_backward_ws(zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["du"].data_ptr(), gptr, T * DP, DP,
+                                                       t_["dgrid"].data_ptr(), t_["dfeat"], t_["dbias"], t_["rws"].data_ptr(), t_["rws"].numel(), s_), "gaussian2d_backward")
+                L.check(lib.v1t_readout_grid_backward_ws(n, N, t_["gd"], t_["src"], *t_["gp"], t_["mu"], t_["sigma"], t_["eps"].data_ptr(), t_["dgrid"].data_ptr(),
+                                                         *t_["dgp"], t_["dmu"], t_["dsigma"], t_["dshift"].data_ptr() if t_["shift"] is not None else None,
+                                                         t_["gws"].data_ptr(), t_["gws"].numel(), s_), "readout_grid_backward")
+                if t_["shift"] is not None:
+                    L.check(lib.v1t_core_shifter_backward(n, pup.data_ptr(), *t_["sp"], t_["dshift"].data_ptr(), *t_["dsp"], s_), "core_shifter_backward")
+            off += n
+        if streams:
+            for s_i in streams:
+                main.wait_stream(s_i)
+        # ---- shared core backward (gradients accumulate into the core arena; per-block events for the data-parallel exchange)
+        core._arena.attach_grads()
+        evs = core._block_events
+        ev_arr = (C.c_void_p * len(evs))(*[e.cuda_event for e in evs]) if evs is not None else None
+        L.check(lib.v1t_vit_backward_events(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), self.img.data_ptr(), L.ptr(self.beh), 0, self.B,
+                                            self.ws.data_ptr(), self.scratch.data_ptr(), self.sb, 1, seed, None, self.gout.data_ptr(), core._arena.grad.data_ptr(),
+                                            ev_arr, st), "vit_backward")
+        return self.zeros[:len(units)]
+
+
 class Trainer:
     def __init__(self, args, model: Model, ds: t.Dict[str, t.Any], sharding: t.Optional[MouseSharding] = None):
         self.args, self.model = args, model
@@ -149,6 +340,11 @@ class Trainer:
         self.overlap = (ov == "1") or (ov != "0" and backend == "nccl")
         if self.sharding.world > 1:
             model.core.fold_rank(self.sharding.rank)
+        # V1T_NATIVE_STEP=0 (dev): forward / backward through the nn.Module + autograd path instead of the direct C-ABI sequence
+        self.native = os.environ.get("V1T_NATIVE_STEP", "1") != "0"
+        self._native_cache: t.Dict[t.Any, t.Optional[_NativeStep]] = {}
+        self._eps_state = (int(getattr(args, "seed", 1234)) * 2654435761 + 97) & 0xFFFFFFFFFFFFFFFF
+        self.eps_override: t.Optional[t.Dict[str, torch.Tensor]] = None  # tests: mouse -> (n, N, 2) position noise to replay
 
     def train_step(self, batches: t.Dict[str, t.Dict[str, torch.Tensor]]) -> t.Dict[str, torch.Tensor]:
         """batches: mouse_id -> full batch (image, behavior, pupil_center, response) on the device.
@@ -169,7 +365,17 @@ class Trainer:
                 b = {k: v[sl] for k, v in b.items()}
             model.mouse_arena(mouse_id).attach_grads()
             units.append((mouse_id, b, full))
-        if self.core_group > 1 and len(units) > 1 and core.behavior_mode != 4:
+        native = None
+        if self.native and (len(units) <= self.core_group or len(units) == 1) and units and units[0][1]["image"].is_cuda:
+            key = tuple((m, int(b["image"].shape[0])) for m, b, _ in units)
+            if key not in self._native_cache:
+                self._native_cache[key] = _NativeStep.build(self, units)
+            native = self._native_cache[key]
+            if native is not None and any("forward" in model.readouts[m].__dict__ for m, _, _ in units):
+                native = None  # a test overrode a readout's forward on the instance
+        if native is not None:
+            losses = [native.run(self, units)]
+        elif self.core_group > 1 and len(units) > 1 and core.behavior_mode != 4:
             # groups of local mouse-batches through the shared core in one pass, one backward per group (gradients sum as
             # train.py:97-111)
             single_pass = len(units) <= self.core_group
@@ -217,6 +423,8 @@ class Trainer:
             a = model.mouse_arena(mouse_id)
             # one launch per (L1 coefficient, optimizer group) run: readouts / image_cropper / core_shifter keep their own lr
             self.opt.step_arena(a, [(o, n, c, self.opt.group_lr(g)) for o, n, c, g in model.mouse_step_ranges(mouse_id)])
+        if native is not None:
+            return {"loss": losses[0].sum()}
         return {"loss": torch.stack(losses).sum() if losses else torch.zeros((), device=core._arena.data.device)}
 
     @torch.no_grad()
