@@ -1654,82 +1654,106 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
 // dQ = dS' . K over the materialised dS' (layout: attention.h). Workgroup = 8 waves = 8 query blocks (256 queries) of one
 // (image, head); a wave owns one 32-query block: its dS' blocks (2 KB each, key on the lane as the dK/dV kernel stored them)
 // arrive by LDS-DMA into a wave-private region and are read TRANSPOSED as the A operand (32 queries x 16 keys, natural key
-// order), K tiles of 64 keys are shared by the workgroup and read transposed as the B operand. Bound by reading dS' once from
-// HBM (2 B per (query, key)). Accumulator rows are queries in the permuted order the stored blocks imply (q_of_m below).
+// order), K tiles are shared by the workgroup and read transposed as the B operand. Bound by reading dS' once from HBM
+// (2 B per (query, key)) through the LDS-DMA path: 32-key stages in a 3-deep ring behind a counted vmcnt. Accumulator rows are queries in the permuted
+// order the stored blocks imply (see the epilogue).
 template <int DP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
     using G = Geo<DP>;
-    constexpr int KT = 64;
+    // QPW query blocks per wave: a workgroup covers 8 x QPW x 32 = 512 queries, so a head's K tiles are streamed by 4 workgroups
+    // instead of 7 (at 256 queries K re-reads from L2 were 40 % of the bytes the LDS-DMA path moved, and that path - ~24 GB/s per
+    // CU - is what bounds this kernel)
+    constexpr int KT = 32, NBUF = 3, QPW = 2;  // 3 x 43 KB of LDS: two stages in flight while one is consumed
     using DmaK = TileDma<DP, G::RSTR, KT, 8>;
-    __shared__ __attribute__((aligned(16))) bf16_t sS[2][8][2][1024];
-    __shared__ __attribute__((aligned(16))) bf16_t sK[2][DmaK::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) bf16_t sS[NBUF][8][QPW][1024];
+    __shared__ __attribute__((aligned(16))) bf16_t sK[NBUF][DmaK::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, h, b;
-    decode_block(a, blockIdx.x, gridDim.x, rb, h, b, 256);
+    decode_block(a, blockIdx.x, gridDim.x, rb, h, b, 256 * QPW);
     const int nq = (a.T + 31) / 32, nkb = a.ldds / 32;
-    const int qb = rb * 8 + wave;
-    const bool active = qb < nq;  // wave-uniform
     const size_t bh = (size_t)b * a.H + h;
     DmaK dmaK;
     dmaK.init(lane, wave, a.ldqkv);
     const bf16_t* kbase = a.qkv + (size_t)b * a.T * a.ldqkv + a.H * DP + h * DP;
-    const char* sbase = (const char*)(a.ds + ((bh * nq + (active ? qb : 0)) * nkb) * 1024);
-    const unsigned svoff = (unsigned)(lane * 16);  // a stage's two blocks are 4 KB contiguous: the instruction offsets advance source and LDS alike
-    f32x16 dq[G::DB];
+    // this wave's query blocks: rb * 8 QPW + wave + 8 u (interleaved, so that the ragged last workgroup keeps every wave busy)
+    int qb[QPW];
+    const char* sbase[QPW];
+    int nact = 0;
 #pragma unroll
-    for (int d = 0; d < G::DB; ++d) zero16(dq[d]);
+    for (int u = 0; u < QPW; ++u) {
+        qb[u] = rb * 8 * QPW + wave + 8 * u;
+        if (qb[u] < nq) nact = u + 1;  // wave-uniform; blocks are active in order of u
+        sbase[u] = (const char*)(a.ds + ((bh * nq + min(qb[u], nq - 1)) * nkb) * 1024);
+    }
+    const unsigned svoff = (unsigned)(lane * 16);  // a block is 2 KB contiguous: the instruction offset advances source and LDS alike
+    f32x16 dq[QPW][G::DB];
+#pragma unroll
+    for (int u = 0; u < QPW; ++u)
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) zero16(dq[u][d]);
     // A operand (32 queries x 16 keys, natural key order) read transposed from a stored block: chunk s = [h 2][key 32][8] holds
     // for key k, half h the queries 16 s + 8 (j >> 2) + 4 h + (j & 3), j = 0..7. The 16-lane group gi = lane >> 4 takes chunk
     // s = gi & 1 (A rows m = 16 s + i) and keys 8 (gi >> 1) + {0..3} (second read: + 4); lane 4 q' + p of the group supplies
     // the address of key row q', columns 4 p .. 4 p + 3 = elements 4 (p & 1) .. of half p >> 1; lane i receives column i.
     const int gi = lane >> 4, li = lane & 15;
     const int aoff = (gi & 1) * 512 + ((li & 3) >> 1) * 256 + (8 * (gi >> 1) + (li >> 2)) * 8 + (li & 1) * 4;  // elements
-    const int nst = nkb / 2;  // 64-key stages
-    auto stage = [&](int st, int buf) {
-        if (active) {
-            const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&sS[buf][wave][0][0]);
-            TileDma<DP, G::RSTR>::template group<4>(sbase + (size_t)st * 4096, l0, svoff, svoff, svoff, svoff);
-        }
+    const int nst = nkb;  // 32-key stages
+    // vector-memory operations this wave issues per stage: its own dS' blocks (2 pieces each) + its share of the K tile
+    const int nops = 2 * nact + min(DmaK::PW, max(0, DmaK::NINST - wave * DmaK::PW));
+    auto stage = [&](int st) {
+        const int buf = st % NBUF;
+#pragma unroll
+        for (int u = 0; u < QPW; ++u)
+            if (u < nact) {
+                const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&sS[buf][wave][u][0]);
+                TileDma<DP, G::RSTR>::template group<2>(sbase[u] + (size_t)st * 2048, l0, svoff, svoff, 0, 0);
+            }
         dmaK.issue(kbase, KT * st, a.T, sK[buf]);
     };
-    stage(0, 0);
-    dma_wait_and_barrier();
+    stage(0);
+    if (nst > 1) stage(1);
     for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nst) stage(st + 1, buf ^ 1);
-        if (active) {
+        const int buf = st % NBUF;
+        // stage st has landed for this wave (the younger stage may fly), then for the workgroup
+        const int younger = min(NBUF - 2, nst - 1 - st);
+        wait_vmcnt_dyn(younger * nops);
+        __builtin_amdgcn_s_barrier();  // also: every wave is past stage st - 1, whose buffer the next DMA overwrites
+        if (st + NBUF - 1 < nst) stage(st + NBUF - 1);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 kfr[G::DB];
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16_t* ap = &sS[buf][wave][kb][aoff + 16 * kk * 8];
+            for (int d = 0; d < G::DB; ++d) kfr[d] = lds_tr_frag_nat(sK[buf], G::RSTR, 16 * kk, 32 * d, lane);
+#pragma unroll
+            for (int u = 0; u < QPW; ++u)
+                if (u < nact) {
+                    const bf16_t* ap = &sS[buf][wave][u][aoff + 16 * kk * 8];
                     const bf16x4 lo = lds_tr_read(ap), hi = lds_tr_read(ap + 4 * 8);
                     bf16x8 afr;
                     afr[0] = lo[0]; afr[1] = lo[1]; afr[2] = lo[2]; afr[3] = lo[3];
                     afr[4] = hi[0]; afr[5] = hi[1]; afr[6] = hi[2]; afr[7] = hi[3];
 #pragma unroll
-                    for (int d = 0; d < G::DB; ++d)
-                        dq[d] = mfma32(afr, lds_tr_frag_nat(sK[buf], G::RSTR, 32 * kb + 16 * kk, 32 * d, lane), dq[d]);
+                    for (int d = 0; d < G::DB; ++d) dq[u][d] = mfma32(afr, kfr[d], dq[u][d]);
                 }
         }
-        dma_wait_and_barrier();
     }
-    if (active) {
-        const float f = a.scale[a.scale_per_head ? h : 0] * (a.adrop.thresh8 ? a.adrop.inv_keep : 1.0f);
-        const int dcol = lane & 31, h2 = lane >> 5;
+    const float f = a.scale[a.scale_per_head ? h : 0] * (a.adrop.thresh8 ? a.adrop.inv_keep : 1.0f);
+    const int dcol = lane & 31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = acc_row(r, lane);          // A-operand row
-            const int i = m & 15;                    // position inside the stored 16-query row of chunk m >> 4
-            const int q = 32 * qb + 16 * (m >> 4) + 8 * ((i & 7) >> 2) + 4 * (i >> 3) + (i & 3);
-            if (q < a.T) {
-                bf16_t* orow = a.dqkv + ((size_t)b * a.T + q) * a.lddqkv + h * DP + dcol;
+    for (int u = 0; u < QPW; ++u)
+        if (u < nact) {
 #pragma unroll
-                for (int d = 0; d < G::DB; ++d) orow[32 * d] = (bf16_t)(dq[d][r] * f);
+            for (int r = 0; r < 16; ++r) {
+                const int m = acc_row(r, lane);          // A-operand row
+                const int i = m & 15;                    // position inside the stored 16-query row of chunk m >> 4
+                const int q = 32 * qb[u] + 16 * (m >> 4) + 8 * ((i & 7) >> 2) + 4 * (i >> 3) + (i & 3);
+                if (q < a.T) {
+                    bf16_t* orow = a.dqkv + ((size_t)b * a.T + q) * a.lddqkv + h * DP + dcol;
+#pragma unroll
+                    for (int d = 0; d < G::DB; ++d) orow[32 * d] = (bf16_t)(dq[u][d][r] * f);
+                }
             }
         }
-        (void)h2;
-    }
 }
 
 template <int DP, bool DROP, bool DIAG>
@@ -1742,7 +1766,7 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
-            hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP>), dim3(((a.T + 255) / 256) * a.H * a.B), dim3(512), 0, s, a);
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP>), dim3(((a.T + 511) / 512) * a.H * a.B), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DQ, s);
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
