@@ -11,7 +11,7 @@ from v1t_amd import lib as L  # noqa: E402
 L.LIB_PATH = L.LIB_PATH.replace("libv1t_amd.so", "libv1t_amd_ksum.so")
 lib = L.load()
 dev = torch.device("cuda:0")
-B, H, T, DP = 112, 4, 1654, 160
+B, H, T, DP = int(os.environ.get("ATTN_B", "112")), 4, 1654, 160
 p = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2544
 g = torch.Generator().manual_seed(0)
 qkv = (torch.randn(B * T, 3 * H * DP, generator=g) * 0.7).to(dev).bfloat16()

@@ -57,8 +57,8 @@ __device__ unsigned long long g_kprof[8 * KP_NT * KP_NP];  // up to 8 waves (for
 // dev-only: per-segment cycle sums over a whole workgroup (no per-step stores): KS_MARK(k) adds the cycles since the previous
 // mark to segment k; tools/ksum.py prints them for one workgroup
 __device__ unsigned long long g_ksum[8 * 8 + 2];
-#define KS_DECL unsigned long long ks_prev = __builtin_amdgcn_s_memtime(), ks_sum[8] = {}; const unsigned long long ks_c0 = ks_prev, ks_r0 = __builtin_amdgcn_s_memrealtime()
-#define KS_MARK(k)                                                   \
+#define KS_DECL unsigned long long ks_prev = __builtin_amdgcn_s_memtime(), ks_sum[9] = {}; const unsigned long long ks_c0 = ks_prev, ks_r0 = __builtin_amdgcn_s_memrealtime()
+#define KS_MARK_(k)                                                  \
     do {                                                             \
         __builtin_amdgcn_sched_barrier(0);                           \
         const unsigned long long ks_now = __builtin_amdgcn_s_memtime(); \
@@ -66,6 +66,13 @@ __device__ unsigned long long g_ksum[8 * 8 + 2];
         ks_prev = ks_now;                                            \
         __builtin_amdgcn_sched_barrier(0);                           \
     } while (0)
+#ifdef V1T_KSUM_PRO  // prologue / epilogue breakdown: the steps' marks all go to segment 7, KSP_MARK(k) to segment k
+#define KS_MARK(k) KS_MARK_(8)
+#define KSP_MARK(k) KS_MARK_(k)
+#else
+#define KS_MARK(k) KS_MARK_(k)
+#define KSP_MARK(k)
+#endif
 #define KS_END(blk, wave, lane)                                                                                   \
     do {                                                                                                          \
         if (blockIdx.x == (blk) && (lane) == 0) {                                                                 \
@@ -79,6 +86,7 @@ __device__ unsigned long long g_ksum[8 * 8 + 2];
 #else
 #define KS_DECL
 #define KS_MARK(k)
+#define KSP_MARK(k)
 #define KS_END(blk, wave, lane)
 #endif
 
@@ -1264,7 +1272,7 @@ DEVFN void wait_vmcnt_dyn(int n) {
 }
 // raw barrier: waits for this wave's LDS operations only (a __syncthreads() would also drain the LDS-DMA queue)
 DEVFN void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-DEVFN int b2_slot(int t) { return t - B2_SLOTS * (t / B2_SLOTS); }
+DEVFN int b2_slot(int t) { return (t + 3) - B2_SLOTS * ((t + 3) / B2_SLOTS); }  // tiles 0, 1 in slots 3, 4: slots 0-2 hold K / V images during the prologue
 
 #ifdef V1T_KCLK
 __device__ unsigned long long g_kclk[4];  // dev: shader cycles / 100 MHz ticks of one workgroup of the kernel below
@@ -1339,6 +1347,36 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         else dma4(rcg + 32 * t, rc_voff, lds.rc[slot]);  // lanes 0-31: -lse2/c -> rc[0..31], lanes 32-63: -keep_prob delta -> rc[32..63]
     };
 
+    // ---- prologue: the workgroup's K / V rows (128 keys) as eight 32-row tile images in ring slots 0-2 and the hand-off
+    // area (pair p's keys -> q[p] = K, d[p] = V; pair 3: hand), all unused until tiles 2 .. arrive, from which the producers read their MFMA fragments. Whole rows through registers: consumer p + 4
+    // loads K tile p, producer p V tile p, ten 16-B-per-lane loads of consecutive chunks each (full lines), then ten 16-B LDS
+    // writes. History: (1) the fragments straight from HBM (16 B per lane, two lanes per row, 80 instructions per workgroup) held
+    // the vector memory path for 10 k cycles with every other first access of the workgroup queued behind them - 18 k of a
+    // 155 k-cycle workgroup passed before the first step; (2) LDS-DMA like the Q / dO tiles: 14 k, bound by that path's ~11 B per
+    // cycle and CU (140 KB with tiles 0-2); (3) this: the loads use the ordinary path while the DMA path carries tiles 0-2.
+    // Keys beyond T are clamped to row T - 1: finite data, their P / dS' columns are masked where they leave the workgroup.
+    constexpr int KV_IT = (32 * (DP / 8) + 63) / 64;
+    u32x4 kvreg[KV_IT];
+    auto load_kv = [&]() {
+        const bf16_t* src = qkv_b + h * DP + (wave < 4 ? 2 * HD : HD);
+#pragma unroll
+        for (int it = 0; it < KV_IT; ++it) {
+            const int p = min(64 * it + lane, 32 * (DP / 8) - 1);
+            const int r = min(rb * 128 + 32 * pw + p / (DP / 8), a.T - 1), cc = p % (DP / 8);
+            kvreg[it] = *(const u32x4*)(src + (size_t)r * a.ldqkv + 8 * cc);
+        }
+    };
+    static_assert(sizeof(lds.hand) >= 2 * 32 * G::RSTR * sizeof(bf16_t), "two tile images fit the hand-off area");
+    auto kv_image = [&](bool v) -> bf16_t* { return last ? (bf16_t*)&lds.hand[0][0][0][0] + (v ? 32 * G::RSTR : 0) : (v ? lds.d[pw] : lds.q[pw]); };
+    auto store_kv = [&]() {
+        bf16_t* tile = kv_image(wave < 4);
+#pragma unroll
+        for (int it = 0; it < KV_IT; ++it) {
+            const int p = 64 * it + lane;
+            if (p < 32 * (DP / 8)) *(u32x4*)(tile + (p / (DP / 8)) * G::RSTR + 8 * (p % (DP / 8))) = kvreg[it];
+        }
+    };
+
     // ---- dropout of P (common.h): the lane's fixed coordinate is its key (column), the varying one the query row. A hash
     // word serves a 2 x 2 block of (query, key); the lane's two decisions of a word sit in the bytes key & 1 and 2 + (key & 1),
     // so after a shift by 8 (key & 1) both are decided by ONE 9-bit SWAR compare: ((w & 0x00FF00FF) | 0x01000100) - thr * 0x00010001
@@ -1360,19 +1398,32 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         const float sc = a.scale[a.scale_per_head ? h : 0];
         const float c = sc * LOG2E;
         bf16x8 kf[G::KS], vf[G::KS];
+        load_kv();
+        stage(0);
+        if (nq > 1) stage(1);
+        KSP_MARK(0);
+        store_kv();  // (waits for the loads only: the compiler counts its own; the DMA operations behind them stay in flight)
+        KSP_MARK(1);
+        lds_barrier();  // K / V images written
+        KSP_MARK(2);
+        const int roff = (lane & 31) * G::RSTR + 8 * h2;
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            const bf16_t* rowp = qkv_b + (size_t)key * a.ldqkv + h * DP + 16 * ks + 8 * h2;
-            u32x4 t = kok ? *(const u32x4*)(rowp + HD) : u32x4{0, 0, 0, 0};
-            kf[ks] = *(bf16x8*)&t;
-            // K is pre-multiplied by c = scale log2(e) (one bf16 rounding of c k: 2^-9 relative per term, i.e. ~1e-3 absolute on
-            // the exponent c S, a quarter of the bf16 rounding P gets anyway), so that P = exp2(S') costs no multiply per element
+            kf[ks] = *(const bf16x8*)(kv_image(false) + roff + 16 * ks);
+            vf[ks] = *(const bf16x8*)(kv_image(true) + roff + 16 * ks);
+        }
+        // K is pre-multiplied by c = scale log2(e) (one bf16 rounding of c k: 2^-9 relative per term, i.e. ~1e-3 absolute on
+        // the exponent c S, a quarter of the bf16 rounding P gets anyway), so that P = exp2(S') costs no multiply per element
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j) kf[ks][j] = (bf16_t)((float)kf[ks][j] * c);
-            u32x4 u = kok ? *(const u32x4*)(rowp + 2 * HD) : u32x4{0, 0, 0, 0};
-            vf[ks] = *(bf16x8*)&u;
-        }
-        const int roff = (lane & 31) * G::RSTR + 8 * h2;
+        touch(kf);
+        touch(vf);
+        KSP_MARK(3);
+        lds_barrier();  // every producer holds its fragments: slots 0-2 are free for tiles 2 ..
+        if (nq > 2) stage(2);
+        KSP_MARK(4);
         // Accumulators of S' = c Q K^T - lse2 and dP (- keep_prob delta) start from the row constants of the query block
         // (register r <-> query row 8 (r >> 2) + 4 h2 + (r & 3))
         auto init_rows = [&](int slot, f32x16& s, f32x16& dp, float (&nd)[16]) {
@@ -1474,25 +1525,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         };
         // block 0's chains (no element-wise stage to overlap with yet)
         auto chains0 = [&](f32x16& s, f32x16& dp, float (&nd)[16]) {
-            init_rows(0, s, dp, nd);
-            const bf16_t* qp = &lds.q[0][roff];
-            const bf16_t* dop = &lds.d[0][roff];
+            init_rows(b2_slot(0), s, dp, nd);
+            const bf16_t* qp = &lds.q[b2_slot(0)][roff];
+            const bf16_t* dop = &lds.d[b2_slot(0)][roff];
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) s = mfma32(*(const bf16x8*)(qp + 16 * ks), kf[ks], s);
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) dp = mfma32(*(const bf16x8*)(dop + 16 * ks), vf[ks], dp);
         };
-        stage(0);
-        if (nq > 1) stage(1);
-        if (nq > 2) stage(2);
-        touch(kf);
-        touch(vf);
-        touch(c);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();  // tiles 0 .. 2 staged
         f32x16 sA, dpA, sB, dpB;
         float ndA[16], ndB[16];
-        chains0(sA, dpA, ndA);
+        chains0(sA, dpA, ndA);  // block 0's chains while tiles 1 and 2 land
+        KSP_MARK(5);
+        if (nq > 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // tile 1 (step 0 reads it); tile 2 is waited for in step 0
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        KSP_MARK(6);
         KS_MARK(6);
         {
             int i = 0;
@@ -1508,7 +1556,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         }
         lds_barrier();  // the consumers' last step
         KS_MARK(7);
-        KS_END(3000, wave, lane);
+        KS_END(gridDim.x / 2 + 88, wave, lane);
 #ifdef V1T_KCLK
         if (blockIdx.x == 3000 && wave == 0 && lane == 0) {
             g_kclk[0] = __builtin_amdgcn_s_memtime() - kclk_c0;
@@ -1519,6 +1567,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     }
 
     // ---------------------------------------------------------------------- consumer
+    load_kv();
+    stage(0);
+    if (nq > 1) stage(1);
+    KSP_MARK(0);
     f32x16 dk[G::DB], dv[G::DB];
 #pragma unroll
     for (int d = 0; d < G::DB; ++d) {
@@ -1530,10 +1582,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     bf16_t* ds_wave = a.ds + ((bh * nq) * nkb + (size_t)(rb * 4 + pw)) * 1024 + lane * 8;
     const unsigned kmask = kok ? 0xFFFFFFFFu : 0u;  // keys beyond T: zeros (the dQ GEMM multiplies them with clamped K rows)
     const bool ktail = rb * 128 + 32 * pw + 32 > a.T;
-
-    stage(0);
-    if (nq > 1) stage(1);
-    if (nq > 2) stage(2);
     auto keep_block = [&](int blk) {  // all 8 keep words of a block at once (prologue / step 0; later ones ride between the MFMAs)
         if constexpr (DROP) {
             u32x4 k0, k1;
@@ -1547,14 +1595,26 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         }
     };
     keep_block(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_kv();
+    KSP_MARK(1);
+    lds_barrier();  // K / V images written
+    KSP_MARK(2);
+    lds_barrier();  // the producers hold their K / V fragments: slots 0-2 are free
+    if (nq > 2) stage(2);
+    KSP_MARK(3);
+    if (nq > 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
+    KSP_MARK(6);
     KS_MARK(6);
     // step 0: nothing to consume yet
     if (nq > 3) stage(3);
     keep_block(1);
+    KSP_MARK(4);
     if (nq > 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
+    KSP_MARK(5);
     KP_DECL;
     constexpr int NSLOT = 4 * G::DB, LA = 3;  // one MFMA per slot: dV over (d block, k-step), then dK
     // step i >= 1: consume block j = i - 1 (dS' to HBM, dV^T += dO^T P, dK^T += Q^T dS'; operand k order = acc_to_b_pk order) and,
@@ -1628,11 +1688,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         for (; i <= nq; ++i) cstep(std::false_type{}, i);
     }
     KS_MARK(0);
-    if (kok) {
+    // ---- epilogue: dK / dV rows leave as whole 320-B rows. The accumulators hold, per key (lane), 4 consecutive head dims per
+    // register group: stored directly that is 8 B per lane over 32 rows per instruction, 160 instructions a wave whose ~20 k
+    // partial-line writes drain for ~15 k cycles into the NEXT workgroup's prologue (its first loads queue behind them). After
+    // the last barrier nobody reads the tile ring any more: the wave transposes through its own two slots and writes 16-B
+    // chunks, 3.2 rows per instruction.
+    {
         const float sc = a.scale[a.scale_per_head ? h : 0];
         const float kfac = DROP ? a.adrop.inv_keep : 1.0f;
         const float fk = sc * kfac;
-        bf16_t* orow = a.dqkv + ((size_t)b * a.T + key) * a.lddqkv + h * DP;
+        bf16_t* const tk = lds.q[pw];
+        bf16_t* const tv = lds.d[pw];
+        const int wo = (lane & 31) * G::RSTR + 4 * h2;
 #pragma unroll
         for (int d = 0; d < G::DB; ++d)
 #pragma unroll
@@ -1643,12 +1710,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
                     wk[j] = (bf16_t)(dk[d][4 * rq4 + j] * fk);
                     wv[j] = (bf16_t)(dv[d][4 * rq4 + j] * kfac);
                 }
-                *(bf16x4*)(orow + HD + 32 * d + 8 * rq4 + 4 * h2) = wk;
-                *(bf16x4*)(orow + 2 * HD + 32 * d + 8 * rq4 + 4 * h2) = wv;
+                *(bf16x4*)(tk + wo + 32 * d + 8 * rq4) = wk;
+                *(bf16x4*)(tv + wo + 32 * d + 8 * rq4) = wv;
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
+        constexpr int CPRD = DP / 8;  // 16-B chunks per row
+        const int key0 = rb * 128 + 32 * pw;
+        bf16_t* const obase = a.dqkv + ((size_t)b * a.T + key0) * a.lddqkv + h * DP;
+#pragma unroll
+        for (int it = 0; it < (32 * CPRD + 63) / 64; ++it) {
+            const int pch = 64 * it + lane;
+            const int row = pch / CPRD, ch = pch - row * CPRD;
+            if (pch < 32 * CPRD && key0 + row < a.T) {
+                const u32x4 xk = *(const u32x4*)(tk + row * G::RSTR + 8 * ch);
+                const u32x4 xv = *(const u32x4*)(tv + row * G::RSTR + 8 * ch);
+                bf16_t* o = obase + (size_t)row * a.lddqkv + 8 * ch;
+                *(u32x4*)(o + HD) = xk;
+                *(u32x4*)(o + 2 * HD) = xv;
+            }
+        }
     }
+    KSP_MARK(7);
     KS_MARK(7);
-    KS_END(3000, wave, lane);
+    KS_END(gridDim.x / 2 + 88, wave, lane);
 }
 
 // dQ = dS' . K over the materialised dS' (layout: attention.h). Workgroup = 8 waves = 8 query blocks (256 queries) of one

@@ -279,9 +279,12 @@ class Model(nn.Module):
             outputs = self.elu1(outputs)
         return outputs, images, image_grids
 
-    def forward_mice(self, batches: t.Sequence[t.Tuple[str, t.Dict[str, torch.Tensor]]], activate: bool = True) -> t.List[torch.Tensor]:
+    def forward_mice(self, batches: t.Sequence[t.Tuple[str, t.Dict[str, torch.Tensor]]], activate: bool = True, join: bool = True) -> t.List[torch.Tensor]:
         """`forward` for several (mouse_id, batch) pairs with ONE pass through the shared core (ViTCore.forward_many);
-        cropper, shifter and readout stay per mouse. Returns the per-pair outputs in order."""
+        cropper, shifter and readout stay per mouse. Returns the per-pair outputs in order. The per-mouse tails run on side
+        streams; with `join` (default) the current stream waits for them before the outputs are returned, so they can be used
+        like any other tensor. `join=False` (the trainer: the loss and its backward stay on the mouse's stream) leaves that to
+        the caller (`join_streams`)."""
         images = [self.image_cropper(b["image"], mouse_id=m, behaviors=b["behavior"], pupil_centers=b["pupil_center"])[0] for m, b in batches]
         zs = self.core.forward_many(images, [m for m, _ in batches], [b["behavior"] for _, b in batches], [b["pupil_center"] for _, b in batches])
         outs = []
@@ -301,6 +304,10 @@ class Model(nn.Module):
                 y = self.readouts(z, mouse_id=m, shifts=shifts)
                 outs.append(self.elu1(y) if activate else y)
         self._last_streams = streams
+        if streams and join:
+            for s_, y in zip(streams, outs):
+                main.wait_stream(s_)
+                y.record_stream(main)  # allocated on the side stream, used on this one
         return outs
 
     def _side_streams(self, n: int):

@@ -381,7 +381,7 @@ class Trainer:
             single_pass = len(units) <= self.core_group
             for i in range(0, len(units), self.core_group):
                 grp = units[i:i + self.core_group]
-                us = model.forward_mice([(m, b) for m, b, _ in grp], activate=False)
+                us = model.forward_mice([(m, b) for m, b, _ in grp], activate=False, join=False)
                 st = getattr(model, "_last_streams", None)
                 ls = []
                 for i, ((m, b, full), u) in enumerate(zip(grp, us)):
