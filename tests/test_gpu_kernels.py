@@ -349,3 +349,48 @@ torch.save({"o": o.float().cpu(), "lse": lse.cpu()}, sys.argv[1])
     assert bool(torch.isfinite(b["o"]).all())
     assert rel_to_max(b["o"], a["o"]) < 1e-2
     assert float((b["lse"] - a["lse"]).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("emb,images", [(64, 3), (155, 2), (96, 5)])
+def test_fused_layernorm_gemm_equals_two_kernels(emb, images):
+    """LN1 -> QKV and LN2 -> FC1 as one A-stationary launch (gemm.hip ln_gemm_kernel, 256-row workgroups) against ln_fwd + gemm_nt
+    (V1T_LN_FUSE=0, read once per process: two subprocesses): core output, loss gradient of every core parameter. Row counts that
+    are no multiple of 128 / 256 (the second 128-row half of the last workgroup is empty or ragged)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from oracle import v1t_oracle as O
+from oracle import weights as W
+from tests.helpers import build_native_model
+emb, images = int(sys.argv[2]), int(sys.argv[3])
+dev = torch.device("cuda:0")
+cfg = O.Config(num_blocks=2, emb_dim=emb, mlp_dim=2 * emb + 24, num_heads=4, mouse_ids=("A",), num_neurons={"A": 40})
+sd = W.make_state_dict(cfg, 5)
+model, _ = build_native_model(cfg, sd, dev)
+model.train(False)
+b = {k: v.to(dev) for k, v in W.make_batch(cfg, "A", images, 5).items()}
+model.core.prepare()
+model.core._arena.attach_grads()
+model.core._arena.grad.zero_()
+u = model(inputs=b["image"], mouse_id="A", behaviors=b["behavior"], pupil_centers=b["pupil_center"], activate=False)[0]
+(u * torch.linspace(-1, 1, u.numel(), device=dev).view_as(u)).sum().backward()
+torch.cuda.synchronize()
+torch.save({"u": u.detach().cpu(), "g": model.core._arena.grad.cpu()}, sys.argv[1])
+'''
+    outs = []
+    for fuse in ("0", "1"):
+        path = f"/tmp/v1t_lnfuse_{fuse}.pt"
+        env = dict(os.environ, V1T_LN_FUSE=fuse)
+        r = subprocess.run([sys.executable, "-c", code, path, str(emb), str(images)], env=env, capture_output=True, text=True,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(path))
+    a, b = outs
+    assert bool(torch.isfinite(b["u"]).all()) and bool(torch.isfinite(b["g"]).all())
+    # same arithmetic up to the summation order of the row statistics (a rounding flip of a 16-bit operand now and then)
+    assert rel_to_max(b["u"], a["u"]) < 1e-3
+    assert rel_to_max(b["g"], a["g"]) < 5e-3

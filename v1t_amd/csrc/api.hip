@@ -217,6 +217,17 @@ static const int g_nosplit = std::getenv("V1T_NOSPLIT") ? atoi(std::getenv("V1T_
 // hi + lo planes and three MFMAs (0.07 of the bound, 2.4x the GEMM time). The second plane of every forward activation /
 // weight holds the one or the other; the bf16 "hi" planes are what the backward reads either way.
 static const int g_fwd_f16 = (std::getenv("V1T_FWD_BF16X3") && atoi(std::getenv("V1T_FWD_BF16X3"))) ? 0 : 1;
+// LayerNorm followed by the GEMM that reads it: one fused A-stationary launch where the shape allows (gemm.h, launch_ln_gemm;
+// fp16 operands, K = DP <= 160, N % 128 == 0), else the two kernels. V1T_LN_FUSE=0 (dev): always the two kernels.
+static const int g_ln_fuse = (std::getenv("V1T_LN_FUSE") && !atoi(std::getenv("V1T_LN_FUSE"))) ? 0 : 1;
+static inline int ln_then_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t s) {
+    if (g_ln_fuse) {
+        const int rc = launch_ln_gemm(l, g, epi, s);
+        if (rc != V1T_ERR_UNSUPPORTED) return rc;
+    }
+    const int rc = launch_ln_fwd(l, s);
+    return rc != V1T_OK ? rc : launch_gemm_nt(g, epi, s);
+}
 static inline void fwd_operands(GemmNTArgs& g) {
     if (!g_fwd_f16) return;
     g.f16 = 1;  // the producers wrote fp16 into the second planes (EPI_BIAS_GELU writes C2_lo the same way)
@@ -607,14 +618,12 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         l1.gamma = arena + b.ln1w; l1.beta = arena + b.ln1b; l1.z = z1; l1.z_lo = (bf16_t*)(wb + w.z1_lo); l1.lo_f16 = g_fwd_f16;
         l1.mean = (float*)(wb + w.mean1); l1.rstd = (float*)(wb + w.rstd1);
         l1.rows = R; l1.T = h->T; l1.D = D; l1.DP = DP; l1.eps = h->c.ln_eps; l1.ones_col = -1;
-        CHECK(launch_ln_fwd(l1, s));
-
         GemmNTArgs g{};
         g.A = z1; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_qkv); g.ldb = DP; g.M = R; g.N = 3 * HDP; g.K = DP; g.C = qkv; g.ldc = 3 * HDP;
         g.A_lo = (const bf16_t*)(wb + w.z1_lo); g.B_lo = (const bf16_t*)(sh + b.s_qkv_lo);
         if (g_nosplit & 1) g.A_lo = g.B_lo = nullptr;
         fwd_operands(g);
-        CHECK(launch_gemm_nt(g, EPI_BF16, s));
+        CHECK(ln_then_gemm(l1, g, EPI_BF16, s));
 
         AttnArgs at{};
         at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = o; at.ldo = HDP; at.o_lo = (bf16_t*)(wb + w.o_lo); at.lo_f16 = g_fwd_f16; at.lse2 = (float*)(wb + w.lse2);
@@ -637,8 +646,6 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         l2.mean = (float*)(wb + w.mean2); l2.rstd = (float*)(wb + w.rstd2);
         l2.rows = R; l2.T = h->T; l2.D = D; l2.DP = DP; l2.eps = h->c.ln_eps;
         l2.ones_col = (DP > D && h->blk[k].fc1b >= 0) ? DP - 1 : -1;  // d(fc1 bias) comes out of the dW1 GEMM
-        CHECK(launch_ln_fwd(l2, s));
-
         g = GemmNTArgs{};
         g.A = z2; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_fc1); g.ldb = DP; g.M = R; g.N = MP; g.K = DP; g.C = hpre; g.ldc = MP;
         g.A_lo = (const bf16_t*)(wb + w.z2_lo); g.B_lo = (const bf16_t*)(sh + b.s_fc1_lo); g.C2_lo = (bf16_t*)(wb + w.hact_lo);
@@ -646,7 +653,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         fwd_operands(g);
         g.C2 = hact; g.ldc2 = MP; g.bias = b.s_fc1b >= 0 ? (const float*)(sh + b.s_fc1b) : nullptr;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
-        CHECK(launch_gemm_nt(g, EPI_BIAS_GELU, s));
+        CHECK(ln_then_gemm(l2, g, EPI_BIAS_GELU, s));
 
         g = GemmNTArgs{};
         g.A = hact; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc2); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = xo; g.ldc = DP;

@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "gemm.h"
+#include "elementwise.h"
 
 namespace {
 
@@ -418,6 +419,181 @@ int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// LayerNorm fused into the GEMM that consumes it (LN1 -> QKV, LN2 -> FC1; K = DP <= 160), A-STATIONARY: a workgroup of 8
+// waves owns 256 rows. Each wave loads its 32 rows of the fp32 residual stream straight in MFMA A-fragment order (lane = row,
+// half rows on the two 32-lane halves: the row statistics are 80 in-lane adds and one exchange with lane ^ 32), normalises
+// them in registers, writes the bf16 plane the backward's weight-gradient GEMM reads (+ mean / rstd, + the injected
+// residual) and keeps the fp16 A fragments of the whole K extent (DP / 16 x 4 VGPRs) for the rest of the kernel. It then
+// walks over ALL column tiles of the weight (128 columns each, [128][DP] fp16 double-buffered in LDS), so the activation is
+// read from HBM once instead of once per column tile and never written / re-read as an fp16 plane, and the LayerNorm launch
+// disappears. Against ln_fwd + gemm_nt on the default V1T (112 images, 185 k rows): the QKV GEMM fetched 59 MB x 12 column
+// tiles + 614 KB of weights x 1448 row tiles through L2 - per CU that is its ~11.7 B / cycle fetch limit (outstanding misses x
+// latency), i.e. the old kernel was bound by its re-reads; here a workgroup fetches 160 KB of x and 614 KB of W.
+// Epilogues: EPI_BF16 (QKV) and EPI_BIAS_GELU (FC1; gelu' in the fragment order of 128-row tiles, as gemm_nt writes it).
+template <int DP, int EPI>
+__global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs g) {
+    constexpr int KS = DP / 16, NBLK = 4, BN = 128, LS = DP + 8, NTH = 512, KC = DP / 8;
+    constexpr int B_CHUNKS = BN * KC, B_ITERS = (B_CHUNKS + NTH - 1) / NTH;
+    constexpr int CS = BN + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LS];
+    __shared__ __attribute__((aligned(16))) bf16_t stg[8][32 * CS];
+    __shared__ __attribute__((aligned(16))) float sgb[2][DP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r31 = lane & 31, h2 = lane >> 5;
+    const int m0 = blockIdx.x * 256;
+    const int row = m0 + 32 * wave + r31;
+    const bool rok = row < l.rows;
+    const int rr = rok ? row : l.rows - 1;
+    const int ntn = g.N / BN;
+
+    u32x4 rb[B_ITERS];
+    auto gload = [&](int tn) {
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + NTH * i, brow = c / KC, kc = c % KC;
+            if (c < B_CHUNKS) rb[i] = *(const u32x4*)(g.B + (size_t)(tn * BN + brow) * g.ldb + 8 * kc);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + NTH * i, brow = c / KC, kc = c % KC;
+            if (c < B_CHUNKS) *(u32x4*)(&sB[buf][brow * LS + 8 * kc]) = rb[i];
+        }
+    };
+    gload(0);  // in flight during the LayerNorm
+    if (tid < DP) {
+        sgb[0][tid] = tid < l.D ? l.gamma[tid] : 0.f;
+        sgb[1][tid] = tid < l.D ? l.beta[tid] : 0.f;
+    }
+
+    // ---- LayerNorm of this lane's half row (columns 16 ks + 8 h2 + e)
+    float xv[KS][8];
+    {
+        const float* xp = l.x + (size_t)rr * DP + 8 * h2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 a = *(const f32x4*)(xp + 16 * ks), b = *(const f32x4*)(xp + 16 * ks + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[ks][e] = a[e];
+                xv[ks][4 + e] = b[e];
+            }
+        }
+        if (l.inject) {
+            const float* ip = l.inject + (size_t)(rr / l.T) * DP + 8 * h2;
+            float* op = l.xout + (size_t)row * DP + 8 * h2;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f32x4 a = *(const f32x4*)(ip + 16 * ks), b = *(const f32x4*)(ip + 16 * ks + 4);
+                f32x4 oa, ob;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    oa[e] = xv[ks][e] += a[e];
+                    ob[e] = xv[ks][4 + e] += b[e];
+                }
+                if (rok) {
+                    *(f32x4*)(op + 16 * ks) = oa;
+                    *(f32x4*)(op + 16 * ks + 4) = ob;
+                }
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (ks >= KS - 2 && 16 * ks + 8 * h2 + e >= l.D) xv[ks][e] = 0.f;  // pad columns (D > DP - 32) stay out of the statistics
+            sum += xv[ks][e];
+        }
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum / l.D;
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = (ks >= KS - 2 && 16 * ks + 8 * h2 + e >= l.D) ? 0.f : xv[ks][e] - mean;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 32);
+    const float rstd = rsqrtf(q / l.D + l.eps);
+    if (rok && h2 == 0) {
+        l.mean[row] = mean;
+        l.rstd[row] = rstd;
+    }
+    __syncthreads();  // gamma / beta staged
+    bf16x8 afrag[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c0 = 16 * ks + 8 * h2;
+        const f32x4 g0 = *(const f32x4*)&sgb[0][c0], g1 = *(const f32x4*)&sgb[0][c0 + 4];
+        const f32x4 b0 = *(const f32x4*)&sgb[1][c0], b1 = *(const f32x4*)&sgb[1][c0 + 4];
+        bf16x8 zh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int cc = c0 + e;
+            const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
+            float z = (xv[ks][e] - mean) * rstd * ga + be;
+            if (ks >= KS - 2 && cc >= l.D) z = (cc == l.ones_col) ? 1.f : 0.f;
+            zh[e] = (bf16_t)z;
+            afrag[ks][e] = aux_plane(z, zh[e], 1);
+        }
+        if (rok) *(bf16x8*)(l.z + (size_t)row * DP + c0) = zh;
+    }
+
+    // ---- all column tiles of the weight against the resident A fragments
+    const int m0p = m0 + 128 * (wave >> 2), wv = wave & 3;  // the epilogue helpers think in 128-row tiles of 4 waves
+    bf16_t* st = stg[wave];
+    auto staged_store = [&](f32x16 (&acc)[NBLK], bf16_t* dst, int ld, int n0, auto conv) {
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[acc_row(r, lane) * CS + 32 * nb + r31] = conv(acc[nb][r]);
+        constexpr int CPR = BN / 8;
+#pragma unroll
+        for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
+            const int c = c0 + lane, crow = c / CPR, ch = c % CPR;
+            const int grow = m0 + 32 * wave + crow;
+            if (grow < g.M) *(u32x4*)(dst + (size_t)grow * ld + n0 + 8 * ch) = *(const u32x4*)(st + crow * CS + 8 * ch);
+        }
+    };
+    swrite(0);
+    __syncthreads();
+    const int boff = r31 * LS + 8 * h2;
+    for (int tn = 0; tn < ntn; ++tn) {
+        const int buf = tn & 1, n0 = tn * BN;
+        if (tn + 1 < ntn) gload(tn + 1);
+        f32x16 acc[NBLK];
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) {
+                const bf16x8 b = *(const bf16x8*)(&sB[buf][32 * nb * LS + boff + 16 * ks]);
+                acc[nb] = mfma32h(afrag[ks], b, acc[nb]);
+            }
+        if (m0p >= g.M) {
+            // a 128-row tile wholly beyond M (second half of the last workgroup): nothing to store, and the gelu' fragment buffer
+            // is only allocated for ceil(M / 128) tiles
+        } else if constexpr (EPI == EPI_BF16) {
+            staged_store(acc, (bf16_t*)g.C, g.ldc, n0, [](float v) { return (bf16_t)v; });
+        } else {
+            f32x16 resv[NBLK];
+            gemm_epilogue<NBLK, EPI_BIAS_GELU, true>(g, acc, resv, m0p, n0, wv, lane);  // gelu' written (fragment order), activation left in acc
+            staged_store(acc, g.C2, g.ldc2, n0, [](float v) { return (bf16_t)v; });
+            if (g.C2_lo) staged_store(acc, g.C2_lo, g.ldc2, n0, [](float v) { return aux_plane(v, (bf16_t)v, 1); });
+        }
+        if (tn + 1 < ntn) swrite(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // gemm_tn: workgroup = 4 waves = 128 Y-columns (output rows) x 32*XBLK X-columns (output cols)
 // over one m_chunk of the contraction; m-tile 32 rows, both LDS images stored [m][col] and read
 // with ds_read_b64_tr_b16 (row strides are 64 B x odd so the 4 rows of a transposed read hit
@@ -685,6 +861,25 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTNArgs g, int gx, in
 
 }  // namespace
 
+
+int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t s) {
+    if (!g.f16 || g.A_lo || g.B_lo || g.K != l.DP || g.N % 128 != 0 || (g.ldb % 8) || l.D <= l.DP - 32 || l.D > l.DP) return V1T_ERR_UNSUPPORTED;
+    if (epi == EPI_BF16 ? (g.ldc % 8) != 0 : (epi != EPI_BIAS_GELU || (g.ldc2 % 8) != 0)) return V1T_ERR_UNSUPPORTED;
+    if (g.M != l.rows || (l.inject && !l.xout)) return V1T_ERR_ARG;
+    if (l.rows <= 0) return V1T_OK;
+    const dim3 grid((l.rows + 255) / 256), blk(512);
+#define LNG_CASE(DPV)                                                                                              \
+    case DPV:                                                                                                      \
+        if (epi == EPI_BF16) hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BF16>), grid, blk, 0, s, l, g);           \
+        else hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BIAS_GELU>), grid, blk, 0, s, l, g);                      \
+        break;
+    switch (l.DP) {
+        LNG_CASE(32) LNG_CASE(64) LNG_CASE(96) LNG_CASE(128) LNG_CASE(160)
+        default: return V1T_ERR_UNSUPPORTED;
+    }
+#undef LNG_CASE
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
 
 int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 != 0 || a.N % 32 != 0 || (a.lda % 8) || (a.ldb % 8)) return V1T_ERR_ARG;
