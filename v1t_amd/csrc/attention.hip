@@ -295,6 +295,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     dmaK.init(lane, wave, a.ldqkv);
     dmaV.init(lane, wave, a.ldqkv);
 
+    // the first K / V stage goes out BEFORE the Q fragments: the fragment loads (16 B per lane, two lanes per row) keep the
+    // workgroup's memory path busy for thousands of cycles and everything issued behind them waits (dK/dV kernel, same finding)
+    dmaK.issue(kbase, 0, a.T, sK[0]);
+    dmaV.issue(vbase, 0, a.T, sV[0]);
     bf16x8 qf[G::KS];
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) {
@@ -405,8 +409,6 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
 #endif
     };
 
-    dmaK.issue(kbase, 0, a.T, sK[0]);
-    dmaV.issue(vbase, 0, a.T, sV[0]);
     touch(qf);
     touch(c);
     dma_wait_and_barrier();

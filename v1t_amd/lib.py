@@ -13,7 +13,7 @@ import typing as t
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libv1t_amd.so")
+LIB_PATH = os.path.join(HERE, "lib", os.environ.get("V1T_LIB", "libv1t_amd.so"))  # V1T_LIB (dev): an experiment build next to it
 
 c_void_p, c_int, c_ll, c_float, c_u64, c_u32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint64, C.c_uint32
 
