@@ -152,13 +152,14 @@ def run_rollout(a, dev):
     lib = L.load()
     with torch.no_grad():
         images, _ = model.image_cropper(b["image"], "A", b["behavior"], b["pupil_center"])
+        full = a.rollout == "full"
         for _ in range(max(a.warmup, 1)):
-            heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], "A")
+            heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], "A", full_chain=full)
         torch.cuda.synchronize()
-        L.check(lib.v1t_profile_enable(0, a.steps * args.num_blocks + 8))
+        L.check(lib.v1t_profile_enable(7 if full else 0, a.steps * args.num_blocks + 8))
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], "A")
+            heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], "A", full_chain=full)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     launches, total_ms = C.c_int(), C.c_double()
@@ -166,6 +167,25 @@ def run_rollout(a, dev):
     L.check(lib.v1t_profile_enable(-1, 0))
     fl = algorithmic_flops(args, a.neurons)
     avg_ms = total_ms.value / max(launches.value, 1)
+    if full:
+        # the reference's algorithm: L products of (T x T) matrices per image (attention_rollout.py:113-117; the first one is with
+        # the identity and is executed like the others), 2 T^3 flops each; split-bf16 executes 3 MFMA products per algorithmic one
+        T = fl["T"]
+        per_launch = 2.0 * T ** 3 * B
+        achieved = per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        return {
+            "metric": "eval forward + attention rollout images/sec at batch 256 (BASELINE configs[4])", "value": round(B * a.steps / dt, 2), "unit": "images/s",
+            "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16+fp16 forward, split-bf16 (bf16x3) rollout products", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: default V1T eval forward at batch 256 + attention rollout, FULL MATRIX CHAIN as the reference multiplies "
+                                   f"it (head-max of the recomputed P per block, then {args.num_blocks} (T x T).(T x T) products per image on the MFMAs, "
+                                   f"{2.0 * T ** 3 * args.num_blocks / 1e9:.1f} GFLOP / image), heat-maps {tuple(heat.shape)} included", "global_batch": B},
+            "model_tflops_per_s": round((fl["fwd_per_image"] + 2.0 * T ** 3 * args.num_blocks) * B * a.steps / dt / 1e12, 2),
+            "roofline": {"kernel": "rollout_matmul (X <- X . A_hat^T, fp32 in / out, 3 bf16 MFMA products per algorithmic product)", "bound": "mfma",
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS / 3.0, "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS / 3.0), 4),
+                         "traffic": None, "launches": launches.value, "avg_ms": round(avg_ms, 4), "flops_per_launch": per_launch,
+                         "note": "peak = dense bf16 MFMA peak / 3 (split-bf16: three products per algorithmic one)"},
+        }
     per_launch = fl["attn_fwd_per_image_block"] * B
     achieved = per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     return {
@@ -189,6 +209,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--neurons", type=int, default=None)
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c4", "c5"])
+    ap.add_argument("--rollout", default="row", choices=["row", "full"], help="c5: row-vector chain (default) or the reference's full (T x T) matrix chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="roofline.traffic = null instead of reading the tracked PMC summary (used while collecting it)")
     ap.add_argument("--profile-class", type=int, default=2, help="kernel class timed with hipEvents (see include/v1t_amd.h)")

@@ -268,10 +268,17 @@ int v1t_rollout_headmax(const void* qkv, const float* lse2, int B, int H, int T,
  * u = v . ((A + I) / rowsum); v == NULL means v = e_0 (first step = row 0 of the last block). */
 int v1t_rollout_vecmat(const float* A, const float* rowsum, const float* v, float* u, int B, int T,
                        int TP, void* stream);
+/* One step of the FULL matrix chain the reference multiplies out, result = A_hat @ result with A_hat = (A + I) / rowsum
+ * (attention_rollout.py:107-117), carried transposed (X = result^T, (B, T, TP) fp32 like A) so that the output is the next
+ * step's input:  Xout[n][i] = sum_j Xin[n][j] * A_hat[i][j];  Xin == NULL is the identity (first block). Blocks in the
+ * reference's order, first to last; the heat vector J[-1][0, 1:] (:118) is column 0 of the last X: Xout[1:, 0]. Split-bf16
+ * MFMA products (~2^-17 relative), fp32 accumulate; 2 T^3 flops per image and step. Xout must not alias Xin. */
+int v1t_rollout_matmul(const float* A, const float* rowsum, const float* Xin, float* Xout, int B, int T,
+                       int TP, void* stream);
 
 /* Live kernel timing (bench.py roofline): when enabled, every launch of the selected kernel class is
  * bracketed by hipEvents on its own stream. class ids: 0 attention fwd, 1 attention bwd dQ,
- * 2 attention bwd dK/dV, 3 gemm_nt, 4 gemm_tn, 5 readout fwd, 6 readout bwd. */
+ * 2 attention bwd dK/dV, 3 gemm_nt, 4 gemm_tn, 5 readout fwd, 6 readout bwd, 7 rollout matmul. */
 int v1t_profile_enable(int kernel_class, int max_launches);   /* kernel_class < 0 disables */
 int v1t_profile_read(int* launches, double* total_ms);        /* synchronises the recorded events */
 

@@ -394,3 +394,39 @@ torch.save({"u": u.detach().cpu(), "g": model.core._arena.grad.cpu()}, sys.argv[
     # same arithmetic up to the summation order of the row statistics (a rounding flip of a 16-bit operand now and then)
     assert rel_to_max(b["u"], a["u"]) < 1e-3
     assert rel_to_max(b["g"], a["g"]) < 5e-3
+
+
+@pytest.mark.parametrize("B,T", [(2, 70), (1, 300), (3, 129)])
+def test_rollout_matmul_vs_fp64(B, T):
+    """v1t_rollout_matmul (one step of the full rollout chain, X <- X . A_hat^T, split-bf16 MFMA products) against fp64 torch:
+    ragged T (no multiple of the 128 x 128 tile or the 32-wide K tile), identity start (Xin = NULL), two chained steps."""
+    import ctypes as C
+
+    from v1t_amd import lib as L
+
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    TP = (T + 3) // 4 * 4
+    g = torch.Generator().manual_seed(T)
+    steps = []
+    for _ in range(2):
+        A = torch.rand(B, T, TP, generator=g) * (2.0 / T)
+        A[:, :, T:] = 7.0  # pad columns must be ignored
+        steps.append(A.to(dev))
+    ref = None
+    cur = None
+    bufs = [torch.full((B, T, TP), float("nan"), device=dev) for _ in range(2)]
+    for k, A in enumerate(steps):
+        a64 = A[:, :, :T].double().cpu() + torch.eye(T, dtype=torch.float64)
+        rowsum = a64.sum(-1)
+        ahat = a64 / rowsum[..., None]
+        ref = ahat if ref is None else ahat @ ref
+        rs = rowsum.float().to(dev)
+        out = bufs[k & 1]
+        L.check(lib.v1t_rollout_matmul(A.data_ptr(), rs.data_ptr(), L.ptr(cur), out.data_ptr(), B, T, TP, L.stream()), "rollout_matmul")
+        cur = out
+    got = cur[:, :, :T].transpose(1, 2).double().cpu()  # X = result^T
+    assert bool(torch.isfinite(cur).all())
+    assert float((cur[:, :, T:]).abs().max()) == 0.0 if TP > T else True
+    assert rel_to_max(got, ref) < 5e-5  # split-bf16: ~2^-16 of the largest entry
+    assert L.load().v1t_rollout_matmul(steps[0].data_ptr(), rs.data_ptr(), cur.data_ptr(), cur.data_ptr(), B, T, TP, L.stream()) != 0  # aliasing refused

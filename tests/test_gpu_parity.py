@@ -437,7 +437,11 @@ def test_attention_rollout_vs_reference_golden(golden, dev):
     ref_rows = golden["rollout/row"]
     # pre-normalisation heat vector: entries ~1/T; bf16 q/k rounding -> <= 2e-3 relative to the row's max
     assert rel_to_max(rows.cpu().numpy(), ref_rows) < 2e-3
+    full_rows = rollout_rows(model.core, b["image"], b["behavior"], b["pupil_center"], "A", full_chain=True)  # the (T x T) matrix chain
+    assert rel_to_max(full_rows.cpu().numpy(), ref_rows) < 2e-3 and rel_to_max(full_rows.cpu().numpy(), rows.cpu().numpy()) < 1e-4
+    heat_full = attention_rollouts(model.core, b["image"], b["behavior"], b["pupil_center"], "A", full_chain=True)
     heat = attention_rollouts(model.core, b["image"], b["behavior"], b["pupil_center"], "A")
+    assert float((heat_full - heat).abs().max()) < 1e-3
     ref = golden["rollout/heatmap"]
     assert heat.shape == ref.shape
     assert float(np.abs(heat.cpu().numpy() - ref).max()) < 2e-2  # min-max normalisation amplifies the error
@@ -478,6 +482,13 @@ def test_attention_rollout_vs_oracle_default_size(dev):
     for i in range(2):
         ref = O.attention_rollout_row(attn[i])
         assert rel_to_max(rows[i].cpu().numpy(), ref.numpy()) < 3e-3
+    # the reference's own algorithm, the (T x T) matrix chain, on the MFMAs (v1t_rollout_matmul, split-bf16 products): the same
+    # head-max matrices, so it must agree with the row chain far below the tolerance against the oracle (bf16 q / k rounding)
+    full = rollout_rows(model.core, b["image"], b["behavior"], b["pupil_center"], "A", full_chain=True)
+    assert full.shape == rows.shape
+    assert rel_to_max(full.cpu().numpy(), rows.cpu().numpy()) < 1e-4
+    for i in range(2):
+        assert rel_to_max(full[i].cpu().numpy(), O.attention_rollout_row(attn[i]).numpy()) < 3e-3
 
 
 @pytest.mark.parametrize("variant", [{}, {"use_lsa": True}, {"patch_mode": 3}, {"behavior_mode": 0, "shift_mode": 0}, {"patch_stride": 2, "disable_bias": True},

@@ -1053,6 +1053,10 @@ int v1t_rollout_headmax(const void* qkv, const float* lse2, int B, int H, int T,
     a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
     return launch_rollout_headmax(a, DP, A, TP, rowsum, (hipStream_t)stream);
 }
+int v1t_rollout_matmul(const float* A, const float* rowsum, const float* Xin, float* Xout, int B, int T, int TP, void* stream) {
+    if (!A || !rowsum || !Xout || Xout == Xin || B <= 0 || T <= 0) return V1T_ERR_ARG;
+    return launch_rollout_matmul(A, rowsum, Xin, Xout, B, T, TP, (hipStream_t)stream);
+}
 int v1t_rollout_vecmat(const float* A, const float* rowsum, const float* v, float* u, int B, int T, int TP, void* stream) {
     if (!A || !rowsum || !u || TP < T || TP % 4) return V1T_ERR_ARG;
     return launch_rollout_vecmat(A, rowsum, v, u, B, T, TP, (hipStream_t)stream);

@@ -43,3 +43,4 @@ int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s);  // dq + dkv kern
 // attention rollout building blocks (reference utils/attention_rollout.py:92-122)
 int launch_rollout_headmax(const AttnArgs& a, int DP, float* A, int TP, float* rowsum, hipStream_t s);
 int launch_rollout_vecmat(const float* A, const float* rowsum, const float* v, float* u, int B, int T, int TP, hipStream_t s);
+int launch_rollout_matmul(const float* A, const float* rowsum, const float* Xin, float* Xout, int B, int T, int TP, hipStream_t s);

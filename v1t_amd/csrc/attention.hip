@@ -2011,6 +2011,109 @@ __global__ __launch_bounds__(256) void rollout_vecmat_kernel(const float* A, con
         if (j0 + j < T) u[(size_t)b * T + j0 + j] = acc[j] + sw[j0 + j];
 }
 
+// One step of the FULL rollout chain, result <- A_hat . result with A_hat = (A + I) / rowsum (attention_rollout.py:107-117),
+// carried as X = result^T so that both operands are K-contiguous and the output is the next step's left operand without a
+// transpose:  Xout[n][i] = sum_j Xin[n][j] * (A[i][j] + [i == j]) / rowsum[i];  Xin == nullptr is the identity (first block).
+// fp32 in, fp32 out, on the MFMAs in split-bf16 (x = hi + lo, hi.hi + lo.hi + hi.lo: ~2^-17 relative per product - the reference
+// multiplies in fp32): operands are converted while they are staged (no bf16 planes in HBM). Workgroup = 4 waves = 128 x 128 of
+// one image, K tiles of 32, double-buffered LDS, next tile's global loads in flight during the MFMAs. 2 T^3 flops per image and
+// step (9 GFLOP at T = 1654), three MFMA products each; only row 0 of the final product is used downstream, which is why
+// v1t_rollout_vecmat (2 T^2) is the default - this entry exists because the reference's algorithm is the matrix chain.
+constexpr int RM_BK = 32, RM_LS = RM_BK + 8;
+__global__ __launch_bounds__(256, 2) void rollout_matmul_kernel(const float* A, const float* rowsum, const float* Xin, float* Xout, int T, int TP) {
+    constexpr int BM = 128, BN = 128, NBLK = 4;
+    __shared__ __attribute__((aligned(16))) bf16_t sm[2][4][BM * RM_LS];  // [buffer][X hi, X lo, A hi, A lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, n0 = blockIdx.y * BM, i0 = blockIdx.x * BN;
+    const float* Ab = A + (size_t)b * T * TP;
+    const float* Xb = Xin ? Xin + (size_t)b * T * TP : nullptr;
+    const float* rs = rowsum + (size_t)b * T;
+    const int nk = (T + RM_BK - 1) / RM_BK;
+
+    f32x4 rx[4], ra[4];
+    float rinv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (tid + 256 * i) >> 3;
+        rinv[i] = (i0 + r < T) ? 1.0f / rs[i0 + r] : 0.f;
+    }
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, r = c >> 3, k = kt * RM_BK + 4 * (c & 7);
+            const int n = n0 + r, ii = i0 + r;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
+            if (Xb) {
+                if (n < T && k < TP) x = *(const f32x4*)(Xb + (size_t)n * TP + k);
+            }
+            if (ii < T && k < TP) y = *(const f32x4*)(Ab + (size_t)ii * TP + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool kin = k + e < T;
+                if (!Xb) x[e] = (n == k + e) ? 1.f : 0.f;
+                x[e] = (kin && n < T) ? x[e] : 0.f;
+                y[e] = (kin && ii < T) ? (y[e] + (ii == k + e ? 1.f : 0.f)) * rinv[i] : 0.f;
+            }
+            rx[i] = x;
+            ra[i] = y;
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, r = c >> 3, off = r * RM_LS + 4 * (c & 7);
+            bf16x4 xh, xl, ah, al;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[e] = (bf16_t)rx[i][e];
+                xl[e] = (bf16_t)(rx[i][e] - (float)xh[e]);
+                ah[e] = (bf16_t)ra[i][e];
+                al[e] = (bf16_t)(ra[i][e] - (float)ah[e]);
+            }
+            *(bf16x4*)&sm[buf][0][off] = xh;
+            *(bf16x4*)&sm[buf][1][off] = xl;
+            *(bf16x4*)&sm[buf][2][off] = ah;
+            *(bf16x4*)&sm[buf][3][off] = al;
+        }
+    };
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) zero16(acc[nb]);
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int foff = (lane & 31) * RM_LS + 8 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < RM_BK / 16; ++ks) {
+            const bf16x8 xh = *(const bf16x8*)&sm[buf][0][32 * wave * RM_LS + foff + 16 * ks];
+            const bf16x8 xl = *(const bf16x8*)&sm[buf][1][32 * wave * RM_LS + foff + 16 * ks];
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) {
+                const bf16x8 ah = *(const bf16x8*)&sm[buf][2][32 * nb * RM_LS + foff + 16 * ks];
+                const bf16x8 al = *(const bf16x8*)&sm[buf][3][32 * nb * RM_LS + foff + 16 * ks];
+                acc[nb] = mfma32(xl, ah, acc[nb]);
+                acc[nb] = mfma32(xh, al, acc[nb]);
+                acc[nb] = mfma32(xh, ah, acc[nb]);
+            }
+        }
+        if (kt + 1 < nk) swrite(buf ^ 1);
+        __syncthreads();
+    }
+    float* Ob = Xout + (size_t)b * T * TP;
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+        const int col = i0 + 32 * nb + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = n0 + 32 * wave + acc_row(r, lane);
+            if (row < T && col < TP) Ob[(size_t)row * TP + col] = col < T ? acc[nb][r] : 0.f;
+        }
+    }
+}
+
 template <int DP>
 int launch_headmax_t(const AttnArgs& a, float* A, int TP, float* rowsum, hipStream_t s) {
     dim3 grid((a.T + 127) / 128, a.B);
@@ -2043,6 +2146,14 @@ int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s) { DP_DISPATCH(bwd_
 int launch_rollout_headmax(const AttnArgs& a, int DP, float* A, int TP, float* rowsum, hipStream_t s) {
     if (a.H * (DP > 96 ? 4 : 2) > 16) return V1T_ERR_UNSUPPORTED;  // Q fragments of all heads must fit the register file
     DP_DISPATCH(launch_headmax_t, a, A, TP, rowsum, s)
+}
+int launch_rollout_matmul(const float* A, const float* rowsum, const float* Xin, float* Xout, int B, int T, int TP, hipStream_t s) {
+    if (TP % 4 != 0 || TP < T || B > 65535) return V1T_ERR_ARG;
+    dim3 grid((T + 127) / 128, (T + 127) / 128, B);
+    prof_begin(PROF_ROLLOUT_MM, s);
+    hipLaunchKernelGGL(rollout_matmul_kernel, grid, dim3(256), 0, s, A, rowsum, Xin, Xout, T, TP);
+    prof_end(PROF_ROLLOUT_MM, s);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 int launch_rollout_vecmat(const float* A, const float* rowsum, const float* v, float* u, int B, int T, int TP, hipStream_t s) {
     dim3 grid((TP / 4 + 255) / 256, B);

@@ -214,6 +214,6 @@ DEVFN int xcd_remap(int bid, int nwg) {
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // ---- optional per-launch hipEvent timing of one kernel class (see v1t_profile_enable) ----
-enum ProfClass { PROF_ATTN_FWD = 0, PROF_ATTN_DQ = 1, PROF_ATTN_DKV = 2, PROF_GEMM_NT = 3, PROF_GEMM_TN = 4, PROF_READOUT_FWD = 5, PROF_READOUT_BWD = 6 };
+enum ProfClass { PROF_ATTN_FWD = 0, PROF_ATTN_DQ = 1, PROF_ATTN_DKV = 2, PROF_GEMM_NT = 3, PROF_GEMM_TN = 4, PROF_READOUT_FWD = 5, PROF_READOUT_BWD = 6, PROF_ROLLOUT_MM = 7 };
 void prof_begin(int cls, hipStream_t s);
 void prof_end(int cls, hipStream_t s);

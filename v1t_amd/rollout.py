@@ -25,9 +25,14 @@ from .core import ViTCore, find_shape
 
 @torch.no_grad()
 def rollout_rows(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, pupil_centers: torch.Tensor, mouse_id: str,
-                 return_headmax: bool = False):
+                 return_headmax: bool = False, full_chain: bool = False):
     """images: CORE input (B, C, H, W) (post image-cropper). Returns the pre-normalisation heat vector
-    J_last[0, 1:] (B, T-1) of attention_rollout.py:118 (and optionally the list of head-max matrices)."""
+    J_last[0, 1:] (B, T-1) of attention_rollout.py:118 (and optionally the list of head-max matrices).
+    `full_chain`: multiply the (T x T) matrices out as the reference does (attention_rollout.py:113-117, `v1t_rollout_matmul`,
+    2 T^3 flops per image and block on the MFMAs) instead of the row-vector chain (2 T^2): same result up to fp32
+    re-association, ~1000x the arithmetic - there for parity with the reference's algorithm and as a benchmark (config C5)."""
+    if full_chain:
+        return _rollout_rows_full(core, images, behaviors, pupil_centers, mouse_id, return_headmax)
     was_training = core.training
     core.train(False)
     try:
@@ -61,6 +66,48 @@ def rollout_rows(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, p
     return (rows, maps[::-1]) if return_headmax else rows
 
 
+def _rollout_rows_full(core: ViTCore, images, behaviors, pupil_centers, mouse_id: str, return_headmax: bool):
+    was_training = core.training
+    core.train(False)
+    try:
+        tokens = core.forward_tokens(images, mouse_id, behaviors, pupil_centers, keep_workspace=True)
+        core._last_tokens = tokens
+    finally:
+        core.train(was_training)
+    lib = L.load()
+    B, T = tokens.shape[0], core.num_tokens
+    TP = (T + 3) // 4 * 4
+    cfg = core._cfg
+    H, DP = cfg.num_heads, core.padded_dim
+    dev = tokens.device
+    # A and the two ping-pong result^T buffers are (B, T, TP) fp32 each - 2.8 GB at batch 256: kept on the core between calls
+    # (a fresh 8.5 GB request per call makes the caching allocator release and re-map segments, 10x the time of the chain itself);
+    # Recorder.clear() drops them
+    key = (B, T, TP, str(dev))
+    scratch = getattr(core, "_rollout_scratch", None)
+    if scratch is None or scratch[0] != key:
+        scratch = (key, torch.empty((B, T, TP), dtype=torch.float32, device=dev), torch.empty((B, T), dtype=torch.float32, device=dev),
+                   [torch.empty((B, T, TP), dtype=torch.float32, device=dev) for _ in range(2)])
+        core._rollout_scratch = scratch
+    _, A, rowsum, X = scratch
+    cur: t.Optional[torch.Tensor] = None
+    maps = []
+    nqkv, nlse = B * T * 3 * H * DP * 2, B * H * T * 4
+    for k in range(cfg.num_blocks):  # the reference's order: result = a_k @ result, first block first
+        qkv = core.workspace_tensor("qkv", k)[:nqkv]
+        lse2 = core.workspace_tensor("lse2", k)[:nlse]
+        scale = core.transformer.blocks[k]["mha"].scale
+        L.check(lib.v1t_rollout_headmax(qkv.data_ptr(), lse2.data_ptr(), B, H, T, DP, scale.data_ptr(), int(cfg.use_lsa), int(cfg.use_lsa),
+                                        A.data_ptr(), TP, rowsum.data_ptr(), L.stream()), "rollout_headmax")
+        out = X[k & 1]
+        L.check(lib.v1t_rollout_matmul(A.data_ptr(), rowsum.data_ptr(), L.ptr(cur), out.data_ptr(), B, T, TP, L.stream()), "rollout_matmul")
+        cur = out
+        if return_headmax:
+            maps.append(A[:, :, :T].clone())
+    rows = cur[:, 1:T, 0].contiguous()  # result[0, 1:] = column 0 of result^T
+    return (rows, maps) if return_headmax else rows
+
+
 class Recorder(torch.nn.Module):
     """Counterpart of the reference `Recorder` (attention_rollout.py:15-77) for the native core. The reference hooks every
     block's `Attention.attend` (nn.Softmax) module; the fused attention has no such module - P is never materialised - so the
@@ -81,6 +128,7 @@ class Recorder(torch.nn.Module):
         return self.core
 
     def clear(self):
+        self.core._rollout_scratch = None
         torch.cuda.empty_cache()
 
     @torch.no_grad()
@@ -93,10 +141,11 @@ class Recorder(torch.nn.Module):
 
 
 @torch.no_grad()
-def attention_rollouts(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, pupil_centers: torch.Tensor, mouse_id: str) -> torch.Tensor:
+def attention_rollouts(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, pupil_centers: torch.Tensor, mouse_id: str,
+                       full_chain: bool = False) -> torch.Tensor:
     """Heat-maps (B, H, W) like reference `attention_rollouts` (attention_rollout.py:125-133) applied to the
     recorder output of `core` on `images`."""
-    rows = rollout_rows(core, images, behaviors, pupil_centers, mouse_id)
+    rows = rollout_rows(core, images, behaviors, pupil_centers, mouse_id, full_chain=full_chain)
     B = rows.shape[0]
     h, w = find_shape(rows.shape[1])
     heat = rows.reshape(B, h, w)
