@@ -431,7 +431,7 @@ int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
 // latency), i.e. the old kernel was bound by its re-reads; here a workgroup fetches 160 KB of x and 614 KB of W.
 // Epilogues: EPI_BF16 (QKV) and EPI_BIAS_GELU (FC1; gelu' in the fragment order of 128-row tiles, as gemm_nt writes it).
 template <int DP, int EPI>
-__global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs g) {
+__global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs g, int nsplit) {
     constexpr int KS = DP / 16, NBLK = 4, BN = 128, LS = DP + 8, NTH = 512, KC = DP / 8;
     constexpr int B_CHUNKS = BN * KC, B_ITERS = (B_CHUNKS + NTH - 1) / NTH;
     constexpr int CS = BN + 8;
@@ -440,9 +440,12 @@ __global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs
     __shared__ __attribute__((aligned(16))) float sgb[2][DP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r31 = lane & 31, h2 = lane >> 5;
-    const int m0 = blockIdx.x * 256;
+    // nsplit > 1 (launches with few row tiles: a rank's share of a multi-GPU step): the column tiles of a row tile are dealt
+    // over nsplit workgroups; each normalises the rows for itself, the first one writes the LayerNorm outputs
+    const int sp = blockIdx.x % nsplit;
+    const int m0 = (blockIdx.x / nsplit) * 256;
     const int row = m0 + 32 * wave + r31;
-    const bool rok = row < l.rows;
+    const bool rok = row < l.rows, wln = rok && sp == 0;
     const int rr = rok ? row : l.rows - 1;
     const int ntn = g.N / BN;
 
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs
             if (c < B_CHUNKS) *(u32x4*)(&sB[buf][brow * LS + 8 * kc]) = rb[i];
         }
     };
-    gload(0);  // in flight during the LayerNorm
+    gload(sp);  // in flight during the LayerNorm
     if (tid < DP) {
         sgb[0][tid] = tid < l.D ? l.gamma[tid] : 0.f;
         sgb[1][tid] = tid < l.D ? l.beta[tid] : 0.f;
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs
                     oa[e] = xv[ks][e] += a[e];
                     ob[e] = xv[ks][4 + e] += b[e];
                 }
-                if (rok) {
+                if (wln) {
                     *(f32x4*)(op + 16 * ks) = oa;
                     *(f32x4*)(op + 16 * ks + 4) = ob;
                 }
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs
         }
     q += __shfl_xor(q, 32);
     const float rstd = rsqrtf(q / l.D + l.eps);
-    if (rok && h2 == 0) {
+    if (wln && h2 == 0) {
         l.mean[row] = mean;
         l.rstd[row] = rstd;
     }
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs
             zh[e] = (bf16_t)z;
             afrag[ks][e] = aux_plane(z, zh[e], 1);
         }
-        if (rok) *(bf16x8*)(l.z + (size_t)row * DP + c0) = zh;
+        if (wln) *(bf16x8*)(l.z + (size_t)row * DP + c0) = zh;
     }
 
     // ---- all column tiles of the weight against the resident A fragments
@@ -568,9 +571,9 @@ __global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs
     swrite(0);
     __syncthreads();
     const int boff = r31 * LS + 8 * h2;
-    for (int tn = 0; tn < ntn; ++tn) {
-        const int buf = tn & 1, n0 = tn * BN;
-        if (tn + 1 < ntn) gload(tn + 1);
+    for (int tn = sp, it = 0; tn < ntn; tn += nsplit, ++it) {
+        const int buf = it & 1, n0 = tn * BN;
+        if (tn + nsplit < ntn) gload(tn + nsplit);
         f32x16 acc[NBLK];
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb)
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs
             staged_store(acc, g.C2, g.ldc2, n0, [](float v) { return (bf16_t)v; });
             if (g.C2_lo) staged_store(acc, g.C2_lo, g.ldc2, n0, [](float v) { return aux_plane(v, (bf16_t)v, 1); });
         }
-        if (tn + 1 < ntn) swrite(buf ^ 1);
+        if (tn + nsplit < ntn) swrite(buf ^ 1);
         __syncthreads();
     }
 }
@@ -877,11 +880,23 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
     if (epi == EPI_BF16 ? (g.ldc % 8) != 0 : (epi != EPI_BIAS_GELU || (g.ldc2 % 8) != 0)) return V1T_ERR_UNSUPPORTED;
     if (g.M != l.rows || (l.inject && !l.xout)) return V1T_ERR_ARG;
     if (l.rows <= 0) return V1T_OK;
-    const dim3 grid((l.rows + 255) / 256), blk(512);
+    // workgroups: row tiles x nsplit, one workgroup per CU (a rank of an 8-GPU step has 91 row tiles, the single-GPU batch 724)
+    const int rt = (l.rows + 255) / 256, ntn = g.N / 128;
+    static const int force_split = std::getenv("V1T_LNG_SPLIT") ? atoi(std::getenv("V1T_LNG_SPLIT")) : 0;  // dev switch
+    // cost model in column-tile units: rounds of 256 workgroups x (LayerNorm prologue ~1.5 tiles + the workgroup's tiles); measured
+    // on one rank's share of 2- / 4- / 8-GPU steps (362 / 181 / 91 row tiles -> 2 / 1 / 2)
+    int nsplit = 1;
+    float best = 1e30f;
+    for (int ns = 1; ns <= ntn; ++ns) {
+        const float cost = (float)((rt * ns + 255) / 256) * (1.5f + (float)((ntn + ns - 1) / ns));
+        if (cost < best - 1e-3f) { best = cost; nsplit = ns; }
+    }
+    if (force_split > 0) nsplit = std::min(force_split, ntn);
+    const dim3 grid(rt * nsplit), blk(512);
 #define LNG_CASE(DPV)                                                                                              \
     case DPV:                                                                                                      \
-        if (epi == EPI_BF16) hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BF16>), grid, blk, 0, s, l, g);           \
-        else hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BIAS_GELU>), grid, blk, 0, s, l, g);                      \
+        if (epi == EPI_BF16) hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BF16>), grid, blk, 0, s, l, g, nsplit);   \
+        else hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BIAS_GELU>), grid, blk, 0, s, l, g, nsplit);              \
         break;
     switch (l.DP) {
         LNG_CASE(32) LNG_CASE(64) LNG_CASE(96) LNG_CASE(128) LNG_CASE(160)
