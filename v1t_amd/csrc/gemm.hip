@@ -430,20 +430,20 @@ int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
 // tiles + 614 KB of weights x 1448 row tiles through L2 - per CU that is its ~11.7 B / cycle fetch limit (outstanding misses x
 // latency), i.e. the old kernel was bound by its re-reads; here a workgroup fetches 160 KB of x and 614 KB of W.
 // Epilogues: EPI_BF16 (QKV) and EPI_BIAS_GELU (FC1; gelu' in the fragment order of 128-row tiles, as gemm_nt writes it).
-template <int DP, int EPI>
-__global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs g, int nsplit) {
-    constexpr int KS = DP / 16, NBLK = 4, BN = 128, LS = DP + 8, NTH = 512, KC = DP / 8;
+template <int DP, int EPI, int NW, int NBLK>
+__global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs g, int nsplit) {
+    constexpr int KS = DP / 16, BN = 32 * NBLK, LS = DP + 8, NTH = 64 * NW, KC = DP / 8, BM = 32 * NW;
     constexpr int B_CHUNKS = BN * KC, B_ITERS = (B_CHUNKS + NTH - 1) / NTH;
     constexpr int CS = BN + 8;
     __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LS];
-    __shared__ __attribute__((aligned(16))) bf16_t stg[8][32 * CS];
+    __shared__ __attribute__((aligned(16))) bf16_t stg[NW][32 * CS];
     __shared__ __attribute__((aligned(16))) float sgb[2][DP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r31 = lane & 31, h2 = lane >> 5;
     // nsplit > 1 (launches with few row tiles: a rank's share of a multi-GPU step): the column tiles of a row tile are dealt
     // over nsplit workgroups; each normalises the rows for itself, the first one writes the LayerNorm outputs
     const int sp = blockIdx.x % nsplit;
-    const int m0 = (blockIdx.x / nsplit) * 256;
+    const int m0 = (blockIdx.x / nsplit) * BM;
     const int row = m0 + 32 * wave + r31;
     const bool rok = row < l.rows, wln = rok && sp == 0;
     const int rr = rok ? row : l.rows - 1;
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs
     }
 
     // ---- all column tiles of the weight against the resident A fragments
-    const int m0p = m0 + 128 * (wave >> 2), wv = wave & 3;  // the epilogue helpers think in 128-row tiles of 4 waves
+    const int m0p = m0 + 128 * (wave >> 2), wv = wave & 3;  // the epilogue helpers think in 128-row tiles of 4 waves (NW = 4 or 8)
     bf16_t* st = stg[wave];
     auto staged_store = [&](f32x16 (&acc)[NBLK], bf16_t* dst, int ld, int n0, auto conv) {
 #pragma unroll
@@ -876,27 +876,38 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTNArgs g, int gx, in
 
 
 int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t s) {
-    if (!g.f16 || g.A_lo || g.B_lo || g.K != l.DP || g.N % 128 != 0 || (g.ldb % 8) || l.D <= l.DP - 32 || l.D > l.DP) return V1T_ERR_UNSUPPORTED;
+    if (!g.f16 || g.A_lo || g.B_lo || g.K != l.DP || g.N % 64 != 0 || (g.ldb % 8) || l.D <= l.DP - 32 || l.D > l.DP) return V1T_ERR_UNSUPPORTED;
     if (epi == EPI_BF16 ? (g.ldc % 8) != 0 : (epi != EPI_BIAS_GELU || (g.ldc2 % 8) != 0)) return V1T_ERR_UNSUPPORTED;
     if (g.M != l.rows || (l.inject && !l.xout)) return V1T_ERR_ARG;
     if (l.rows <= 0) return V1T_OK;
     // workgroups: row tiles x nsplit, one workgroup per CU (a rank of an 8-GPU step has 91 row tiles, the single-GPU batch 724)
-    const int rt = (l.rows + 255) / 256, ntn = g.N / 128;
+    // two shapes: 8 waves x 256 rows x 128-column tiles, one workgroup per CU (LDS 157 KB), or 4 waves x 128 rows x 64-column
+    // tiles, two independent workgroups per CU (62 KB each) whose MFMA / epilogue / store phases drift apart and overlap
+    static const int shape = std::getenv("V1T_LNG_SHAPE") ? atoi(std::getenv("V1T_LNG_SHAPE")) : 1;  // dev switch: 0 = 8 waves
+    const int BMr = shape ? 128 : 256, BNr = shape ? 64 : 128;
+    if (g.N % BNr != 0) return V1T_ERR_UNSUPPORTED;
+    const int rt = (l.rows + BMr - 1) / BMr, ntn = g.N / BNr;
     static const int force_split = std::getenv("V1T_LNG_SPLIT") ? atoi(std::getenv("V1T_LNG_SPLIT")) : 0;  // dev switch
     // cost model in column-tile units: rounds of 256 workgroups x (LayerNorm prologue ~1.5 tiles + the workgroup's tiles); measured
     // on one rank's share of 2- / 4- / 8-GPU steps (362 / 181 / 91 row tiles -> 2 / 1 / 2)
     int nsplit = 1;
     float best = 1e30f;
     for (int ns = 1; ns <= ntn; ++ns) {
-        const float cost = (float)((rt * ns + 255) / 256) * (1.5f + (float)((ntn + ns - 1) / ns));
+        const int slots = shape ? 512 : 256;  // resident workgroups
+        const float cost = (float)((rt * ns + slots - 1) / slots) * ((shape ? 3.0f : 1.5f) + (float)((ntn + ns - 1) / ns));
         if (cost < best - 1e-3f) { best = cost; nsplit = ns; }
     }
     if (force_split > 0) nsplit = std::min(force_split, ntn);
-    const dim3 grid(rt * nsplit), blk(512);
-#define LNG_CASE(DPV)                                                                                              \
-    case DPV:                                                                                                      \
-        if (epi == EPI_BF16) hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BF16>), grid, blk, 0, s, l, g, nsplit);   \
-        else hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BIAS_GELU>), grid, blk, 0, s, l, g, nsplit);              \
+    const dim3 grid(rt * nsplit), blk(shape ? 256 : 512);
+#define LNG_CASE(DPV)                                                                                                       \
+    case DPV:                                                                                                               \
+        if (shape) {                                                                                                        \
+            if (epi == EPI_BF16) hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BF16, 4, 2>), grid, blk, 0, s, l, g, nsplit);   \
+            else hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BIAS_GELU, 4, 2>), grid, blk, 0, s, l, g, nsplit);              \
+        } else {                                                                                                            \
+            if (epi == EPI_BF16) hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BF16, 8, 4>), grid, blk, 0, s, l, g, nsplit);   \
+            else hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BIAS_GELU, 8, 4>), grid, blk, 0, s, l, g, nsplit);              \
+        }                                                                                                                   \
         break;
     switch (l.DP) {
         LNG_CASE(32) LNG_CASE(64) LNG_CASE(96) LNG_CASE(128) LNG_CASE(160)
