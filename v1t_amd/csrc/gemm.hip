@@ -559,13 +559,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
         for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
             const int c = c0 + lane, crow = c / CPR, ch = c % CPR;
             const int grow = m0 + 32 * wave + crow;
-#if defined(V1T_EXP_NOSTORE)
-            if (grow < g.M && g.M < 0) *(u32x4*)(dst + (size_t)grow * ld + n0 + 8 * ch) = *(const u32x4*)(st + crow * CS + 8 * ch);
-#elif defined(V1T_EXP_TILEMAJOR)
-            if (grow < g.M) *(u32x4*)(dst + ((size_t)(n0 / BN) * g.M + grow) * BN + 8 * ch) = *(const u32x4*)(st + crow * CS + 8 * ch);
-#else
             if (grow < g.M) *(u32x4*)(dst + (size_t)grow * ld + n0 + 8 * ch) = *(const u32x4*)(st + crow * CS + 8 * ch);
-#endif
         }
     };
     swrite(0);
@@ -584,11 +578,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
 #pragma unroll
             for (int nb = 0; nb < NBLK; ++nb) {
                 const bf16x8 b = *(const bf16x8*)(&sB[buf][32 * nb * LS + boff + 16 * ks]);
-#ifdef V1T_EXP_NOMFMA
-                acc[nb][ks & 15] += (float)b[0] * (float)afrag[ks][1];
-#else
                 acc[nb] = mfma32h(afrag[ks], b, acc[nb]);
-#endif
             }
         if (m0p >= g.M) {
             // a 128-row tile wholly beyond M (second half of the last workgroup): nothing to store, and the gelu' fragment buffer
