@@ -246,6 +246,28 @@ DEVFN bf16x8 tr_frag(const bf16_t* p, int k0, int m0) {
     return r;
 }
 
+// Row-permuted tile images (dK/dV kernel): a 32-row tile whose rows are read BOTH as 16-B row chunks (ds_read_b128: wants a row
+// stride of 16 B x odd, RSTR) and transposed (ds_read_b64_tr_b16, a 16-lane group takes 4 consecutive rows x 32 B: with RSTR's
+// 84-bank stride rows 0 and 3 of a group share 4 banks - a quarter of all LDS cycles of that kernel were bank conflicts). No row
+// stride serves both, but the 4 x 4 index transpose inside each 16-row block does: logical row 4 a + b sits at position a + 4 b,
+// so the 4 rows of a transposed read are 4 positions apart (bank starts 0 / 16 / 32 / 48) and the 8 / 16 consecutive rows of a
+// row read still land on 16 distinct residues.
+DEVFN int perm_row(int r) { return (r & 16) | ((r & 3) << 2) | ((r >> 2) & 3); }
+// transposed-fragment lane offset / fragment read for such an image (rows k0 + 8 e + 4 h + q -> positions k0 + 2 e + h + 4 q)
+DEVFN int tr_lane_off_perm(int lane, int stride) {
+    const int g = lane >> 4, i = lane & 15;
+    return ((g >> 1) + 4 * (i >> 2)) * stride + 16 * (g & 1) + 4 * (i & 3);
+}
+template <int STR>
+DEVFN bf16x8 tr_frag_perm(const bf16_t* p, int k0, int m0) {
+    const bf16x4 lo = lds_tr_read(p + k0 * STR + m0);
+    const bf16x4 hi = lds_tr_read(p + (k0 + 2) * STR + m0);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
 // keep-bits of the 4 consecutive elements (r&3 = 0..3) of one accumulator group: the lane's varying
 // coordinate runs over 2 consecutive 2x2 blocks (words w0: elements 0,1; w1: elements 2,3); sh_even /
 // sh_odd select the byte for an even / odd value of the varying coordinate (they encode the parity of
@@ -1310,7 +1332,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     const bool last = pw == 3;  // wave-uniform
     auto lane_off = [&](int i, int ld, int max_row) {  // byte offset of this lane's 16 B of piece i inside the tile's rows
         const int p = 64 * (pw * Dma::PW + i) + lane;
-        const int r = min(p / Dma::CPR, max_row), cc = min(p % Dma::CPR, DP / 8 - 1);
+        const int r = min(perm_row(min(p / Dma::CPR, 31)), max_row), cc = min(p % Dma::CPR, DP / 8 - 1);  // LDS position -> the row it holds
         return (unsigned)((r * ld + 8 * cc) * 2);
     };
     auto dma16 = [&](const void* gbase, unsigned voff, const void* lds_dst) {  // scalar base + lane offset, 16 B per lane
@@ -1408,11 +1430,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         KSP_MARK(1);
         lds_barrier();  // K / V images written
         KSP_MARK(2);
-        const int roff = (lane & 31) * G::RSTR + 8 * h2;
+        const int roff_lin = (lane & 31) * G::RSTR + 8 * h2;            // K / V images: rows in order
+        const int roff = perm_row(lane & 31) * G::RSTR + 8 * h2;        // Q / dO tiles: rows permuted (perm_row)
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            kf[ks] = *(const bf16x8*)(kv_image(false) + roff + 16 * ks);
-            vf[ks] = *(const bf16x8*)(kv_image(true) + roff + 16 * ks);
+            kf[ks] = *(const bf16x8*)(kv_image(false) + roff_lin + 16 * ks);
+            vf[ks] = *(const bf16x8*)(kv_image(true) + roff_lin + 16 * ks);
         }
         // K is pre-multiplied by c = scale log2(e) (one bf16 rounding of c k: 2^-9 relative per term, i.e. ~1e-3 absolute on
         // the exponent c S, a quarter of the bf16 rounding P gets anyway), so that P = exp2(S') costs no multiply per element
@@ -1579,7 +1602,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         zero16(dk[d]);
         zero16(dv[d]);
     }
-    const int toff = tr_lane_off(lane, G::RSTR);
+    const int toff = tr_lane_off_perm(lane, G::RSTR);
     const int nkb = a.ldds / 32;  // 32-key blocks per query block
     bf16_t* ds_wave = a.ds + ((bh * nq) * nkb + (size_t)(rb * 4 + pw)) * 1024 + lane * 8;
     const unsigned kmask = kok ? 0xFFFFFFFFu : 0u;  // keys beyond T: zeros (the dQ GEMM multiplies them with clamped K rows)
@@ -1637,7 +1660,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         asm volatile("" : "+v"(ta), "+v"(qa));
         auto frag = [&](int m) {
             const bf16_t* p = (const bf16_t*)(const __attribute__((address_space(3))) bf16_t*)(uintptr_t)(m < 2 * G::DB ? ta : qa);
-            return tr_frag<G::RSTR>(p, 16 * (m & 1), 32 * ((m % (2 * G::DB)) >> 1));
+            return tr_frag_perm<G::RSTR>(p, 16 * (m & 1), 32 * ((m % (2 * G::DB)) >> 1));
         };
         bf16x8 fr[NSLOT];
 #pragma unroll
@@ -1750,7 +1773,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
     // instead of 7 (at 256 queries K re-reads from L2 were 40 % of the bytes the LDS-DMA path moved, and that path - ~24 GB/s per
     // CU - is what bounds this kernel)
     constexpr int KT = 32, NBUF = 3, QPW = 2;  // 3 x 43 KB of LDS: two stages in flight while one is consumed
-    using DmaK = TileDma<DP, G::RSTR, KT, 8>;
+    using DmaK = TileDma<DP, G::TSTR, KT, 8>;  // read transposed only: the 64 B x odd row stride (RSTR's 336 B: 2-way conflicts on a quarter of the banks)
     __shared__ __attribute__((aligned(16))) bf16_t sS[NBUF][8][QPW][1024];
     __shared__ __attribute__((aligned(16))) bf16_t sK[NBUF][DmaK::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1771,7 +1794,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
         if (qb[u] < nq) nact = u + 1;  // wave-uniform; blocks are active in order of u
         sbase[u] = (const char*)(a.ds + ((bh * nq + min(qb[u], nq - 1)) * nkb) * 1024);
     }
-    const unsigned svoff = (unsigned)(lane * 16);  // a block is 2 KB contiguous: the instruction offset advances source and LDS alike
+    // a block is 2 KB contiguous ([k-step 2][half 2][key 32][8]): the instruction offset advances source and LDS alike. The LDS image
+    // keeps the upper half of each k-step ROTATED by 4 keys (slot j <- key (j + 4) & 31, by the lane's source offset): a transposed
+    // read takes 4 keys x 16 B from both halves, which sit 512 B = a whole number of bank rounds apart - 2-way conflicts on every
+    // A read; after the rotation the two 64-B groups are 16 banks apart
+    const unsigned svoff = (unsigned)((lane < 32 ? lane : 32 + ((lane + 4) & 31)) * 16);
     f32x16 dq[QPW][G::DB];
 #pragma unroll
     for (int u = 0; u < QPW; ++u)
@@ -1782,7 +1809,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
     // s = gi & 1 (A rows m = 16 s + i) and keys 8 (gi >> 1) + {0..3} (second read: + 4); lane 4 q' + p of the group supplies
     // the address of key row q', columns 4 p .. 4 p + 3 = elements 4 (p & 1) .. of half p >> 1; lane i receives column i.
     const int gi = lane >> 4, li = lane & 15;
-    const int aoff = (gi & 1) * 512 + ((li & 3) >> 1) * 256 + (8 * (gi >> 1) + (li >> 2)) * 8 + (li & 1) * 4;  // elements
+    const int ahalf = (li & 3) >> 1, akey = 8 * (gi >> 1) + (li >> 2);
+    int aoffs[4];  // element offsets for key offsets 0, 4, 16, 20 (k-step kk, first / second read)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        aoffs[c] = (gi & 1) * 512 + ahalf * 256 + ((akey + 16 * (c >> 1) + 4 * (c & 1) - 4 * ahalf) & 31) * 8 + (li & 1) * 4;
     const int nst = nkb;  // 32-key stages
     // vector-memory operations this wave issues per stage: its own dS' blocks (2 pieces each) + its share of the K tile
     const int nops = 2 * nact + min(DmaK::PW, max(0, DmaK::NINST - wave * DmaK::PW));
@@ -1809,12 +1840,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 kfr[G::DB];
 #pragma unroll
-            for (int d = 0; d < G::DB; ++d) kfr[d] = lds_tr_frag_nat(sK[buf], G::RSTR, 16 * kk, 32 * d, lane);
+            for (int d = 0; d < G::DB; ++d) kfr[d] = lds_tr_frag_nat(sK[buf], G::TSTR, 16 * kk, 32 * d, lane);
 #pragma unroll
             for (int u = 0; u < QPW; ++u)
                 if (u < nact) {
-                    const bf16_t* ap = &sS[buf][wave][u][aoff + 16 * kk * 8];
-                    const bf16x4 lo = lds_tr_read(ap), hi = lds_tr_read(ap + 4 * 8);
+                    const bf16_t* ab = &sS[buf][wave][u][0];
+                    const bf16x4 lo = lds_tr_read(ab + aoffs[2 * kk]), hi = lds_tr_read(ab + aoffs[2 * kk + 1]);
                     bf16x8 afr;
                     afr[0] = lo[0]; afr[1] = lo[1]; afr[2] = lo[2]; afr[3] = lo[3];
                     afr[4] = hi[0]; afr[5] = hi[1]; afr[6] = hi[2]; afr[7] = hi[3];
