@@ -110,7 +110,8 @@ int v1t_dropout_mask(uint64_t seed, uint32_t stream_id, float p, long long rows,
                      uint8_t* out, void* stream);
 /* The attention-P dropout (vit.py:263) is evaluated B*H*T*T times inside three MFMA kernels; its mask uses
  * one hash per 2x2 (query,key) block with 8-bit thresholds, so its rate is quantised to round(256 p)/256
- * (0.2544 -> 0.25390625) and 1/(1-rate) uses the quantised rate. This returns the effective rate. */
+ * (0.2544 -> 0.25390625; p < 1/512 -> 0 = no dropout at this site, p > 255/256 -> 255/256) and 1/(1-rate) uses the quantised
+ * rate. This returns the effective rate. */
 float v1t_attention_dropout_rate(float p);
 
 /* ------------------------------------------------ Gaussian2d readout (readout/gaussian2d.py:237-278) */

@@ -430,3 +430,15 @@ def test_rollout_matmul_vs_fp64(B, T):
     assert float((cur[:, :, T:]).abs().max()) == 0.0 if TP > T else True
     assert rel_to_max(got, ref) < 5e-5  # split-bf16: ~2^-16 of the largest entry
     assert L.load().v1t_rollout_matmul(steps[0].data_ptr(), rs.data_ptr(), cur.data_ptr(), cur.data_ptr(), B, T, TP, L.stream()) != 0  # aliasing refused
+
+
+def test_attention_dropout_rate_quantisation():
+    """The attention-P dropout runs at round(256 p) / 256: tiny rates round to OFF (not up to 1 / 256), the top is 255 / 256."""
+    from v1t_amd import lib as L
+
+    lib = L.load()
+    assert float(lib.v1t_attention_dropout_rate(0.0)) == 0.0
+    assert float(lib.v1t_attention_dropout_rate(0.001)) == 0.0          # < 1 / 512
+    assert float(lib.v1t_attention_dropout_rate(0.003)) == 1.0 / 256.0  # rounds to 1
+    assert abs(float(lib.v1t_attention_dropout_rate(0.2544)) - 65.0 / 256.0) < 1e-7
+    assert float(lib.v1t_attention_dropout_rate(0.9999)) == 255.0 / 256.0

@@ -246,6 +246,13 @@ class ViTCore(Core):
         self._block_events = None  # set by the data-parallel trainer (dist.MouseSharding.reduce_core_overlapped)
         self._path_scale_override = None  # tests: (num_blocks, 2, B) factors to replay instead of drawing them
         self.num_blocks = int(args.num_blocks)
+        # the attention-probability dropout (vit.py:263) runs at round(256 p) / 256 (include/v1t_amd.h): say so when that is not p
+        self.attention_dropout_rate = float(lib.v1t_attention_dropout_rate(float(args.t_dropout))) if float(args.t_dropout) > 0 else 0.0
+        if float(args.t_dropout) > 0 and abs(self.attention_dropout_rate - float(args.t_dropout)) > 0.02 * float(args.t_dropout):
+            import warnings
+
+            warnings.warn(f"v1t_amd: attention-probability dropout runs at {self.attention_dropout_rate:.5f} (t_dropout = {float(args.t_dropout):.5f} "
+                          f"quantised to 1/256); the proj / MLP dropouts use the exact rate", stacklevel=2)
 
     def __del__(self):
         try:

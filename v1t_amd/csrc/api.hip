@@ -244,11 +244,14 @@ static const bool g_debug_sync = std::getenv("V1T_DEBUG_SYNC") != nullptr;
     d.inv_keep = 1.f;
     d.keep_prob = 1.f;
     if (training && p > 0.f) {
-        int t = (int)std::floor((double)p * 256.0 + 0.5);
-        t = std::min(std::max(t, 1), 255);
-        d.thresh8 = (uint32_t)t;
-        d.inv_keep = 256.0f / (float)(256 - t);
-        d.keep_prob = (float)(256 - t) / 256.0f;
+        // rate quantised to t / 256; a rate below 1 / 512 rounds to "no dropout at this site" (0 is closer to it than 1 / 256:
+        // a sweep over t_dropout near 0 would otherwise train at 2-4x the requested rate), above 255.5 / 256 to 255 / 256
+        const int t = std::min((int)std::floor((double)p * 256.0 + 0.5), 255);
+        if (t > 0) {
+            d.thresh8 = (uint32_t)t;
+            d.inv_keep = 256.0f / (float)(256 - t);
+            d.keep_prob = (float)(256 - t) / 256.0f;
+        }
     }
     return d;
 }
