@@ -442,3 +442,30 @@ def test_attention_dropout_rate_quantisation():
     assert float(lib.v1t_attention_dropout_rate(0.003)) == 1.0 / 256.0  # rounds to 1
     assert abs(float(lib.v1t_attention_dropout_rate(0.2544)) - 65.0 / 256.0) < 1e-7
     assert float(lib.v1t_attention_dropout_rate(0.9999)) == 255.0 / 256.0
+
+
+def test_attention_forward_extreme_scores(ctx):
+    """Online softmax of the forward kernel with its deferred rescale (the running maximum moves only when a score exceeds it by
+    2^6): queries whose scores are all huge of either sign, whose FIRST key tile is huge against a moderate rest, and a huge score
+    late in the row - against fp32 torch, forward output and log-sum-exp."""
+    lib, L, dev = ctx
+    B, H, T, DP = 1, 2, 200, 160
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B * T, 3, H, DP, generator=g) * 0.7
+    x[3, 0] *= 40.0                     # query 3: huge scores of either sign
+    x[7, 0, 0] = -25.0 * x[:, 1, 0].mean(0).sign() * 1.0   # query 7 (head 0): strongly anti-aligned with the mean key
+    x[:32, 1, 1] *= 25.0                # head 1: the first 32 keys are huge -> first-tile scores dominate or vanish
+    x[150, 1, 0] *= 50.0                # head 0: one huge key late in the row
+    qkv = x.reshape(B * T, 3 * H * DP).to(dev).bfloat16()
+    scale = torch.tensor([DP ** -0.5], device=dev)
+    o = torch.empty(B * T, H * DP, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, T, device=dev)
+    L.check(lib.v1t_attention_forward(qkv.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, 0.0, 1, 8, o.data_ptr(), lse.data_ptr(), L.stream()))
+    assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
+    q, k, v = (qkv.float().view(B, T, 3, H, DP)[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # (B, H, T, DP)
+    s = (q @ k.transpose(-1, -2)) * float(scale)
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * T, H * DP)
+    ref_lse2 = torch.logsumexp(s, -1) * 1.4426950408889634
+    assert rel_to_max(o.float().cpu(), ref.cpu()) < 1.5e-2
+    # scores of ~1e3 in log2 units
+    assert float(((lse - ref_lse2).abs() / (1.0 + 4e-3 * ref_lse2.abs())).max()) < 1.0
