@@ -2046,32 +2046,51 @@ __global__ __launch_bounds__(256) void rollout_vecmat_kernel(const float* A, con
 // carried as X = result^T so that both operands are K-contiguous and the output is the next step's left operand without a
 // transpose:  Xout[n][i] = sum_j Xin[n][j] * (A[i][j] + [i == j]) / rowsum[i];  Xin == nullptr is the identity (first block).
 // fp32 in, fp32 out, on the MFMAs in split-bf16 (x = hi + lo, hi.hi + lo.hi + hi.lo: ~2^-17 relative per product - the reference
-// multiplies in fp32): operands are converted while they are staged (no bf16 planes in HBM). Workgroup = 4 waves = 128 x 128 of
-// one image, K tiles of 32, double-buffered LDS, next tile's global loads in flight during the MFMAs. 2 T^3 flops per image and
+// multiplies in fp32): operands are converted while they are staged (no bf16 planes in HBM); tiling below. 2 T^3 flops per image and
 // step (9 GFLOP at T = 1654), three MFMA products each; only row 0 of the final product is used downstream, which is why
 // v1t_rollout_vecmat (2 T^2) is the default - this entry exists because the reference's algorithm is the matrix chain.
 constexpr int RM_BK = 32, RM_LS = RM_BK + 8;
-__global__ __launch_bounds__(256, 2) void rollout_matmul_kernel(const float* A, const float* rowsum, const float* Xin, float* Xout, int T, int TP) {
-    constexpr int BM = 128, BN = 128, NBLK = 4;
-    __shared__ __attribute__((aligned(16))) bf16_t sm[2][4][BM * RM_LS];  // [buffer][X hi, X lo, A hi, A lo]
+// Workgroup = 8 waves = a 256 x 256 tile of one image's X . A_hat^T, waves 4 (rows) x 2 (columns), each 64 x 128 = 2 x 4 MFMA blocks:
+// an LDS fragment feeds 4 (X) or 2 (A_hat) blocks x 3 split products, 12 fragment reads per 24 MFMAs. (The first version, 128 x 128
+// tiles of 4 waves, fetched 287 MB per image and step through L2 for 22 MB of operands and ran at the ~6.4 TB/s that moves; this tile
+// halves the traffic.) K tiles of 32: fp32 operands loaded to registers one tile ahead, split into bf16 hi + lo planes while they are
+// written to LDS (single buffer: 80 KB, two barriers per K tile).
+__global__ __launch_bounds__(512, 2) void rollout_matmul_kernel(const float* A, const float* rowsum, const float* Xin, float* Xout, int T, int TP) {
+    constexpr int BM = 256, BN = 256;
+    __shared__ __attribute__((aligned(16))) bf16_t sm[4][BM * RM_LS];  // X hi, X lo, A hi, A lo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;  // this wave: rows 64 wr .., columns 128 wc ..
     const int b = blockIdx.z, n0 = blockIdx.y * BM, i0 = blockIdx.x * BN;
     const float* Ab = A + (size_t)b * T * TP;
     const float* Xb = Xin ? Xin + (size_t)b * T * TP : nullptr;
     const float* rs = rowsum + (size_t)b * T;
     const int nk = (T + RM_BK - 1) / RM_BK;
 
-    f32x4 rx[4], ra[4];
+    f32x4 rx[4], ra[4];  // 256 rows x 32 k = 2048 chunks of 4 floats per operand, 4 per thread
     float rinv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int r = (tid + 256 * i) >> 3;
+        const int r = (tid + 512 * i) >> 3;
         rinv[i] = (i0 + r < T) ? 1.0f / rs[i0 + r] : 0.f;
     }
+    // interior: the workgroup's rows are all < T (both operands); then a K tile that ends inside T and does not meet the
+    // diagonal of the A_hat rows needs no per-element masks (they were ~2/3 of the staging instructions)
+    const bool rows_in = n0 + BM <= T && i0 + BN <= T && Xb != nullptr;
     auto gload = [&](int kt) {
+        const int k0 = kt * RM_BK;
+        if (rows_in && k0 + RM_BK <= T && (k0 + RM_BK <= i0 || k0 >= i0 + BN)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + 512 * i, r = c >> 3, k = k0 + 4 * (c & 7);
+                rx[i] = *(const f32x4*)(Xb + (size_t)(n0 + r) * TP + k);
+                const f32x4 y = *(const f32x4*)(Ab + (size_t)(i0 + r) * TP + k);
+                ra[i] = f32x4{y[0] * rinv[i], y[1] * rinv[i], y[2] * rinv[i], y[3] * rinv[i]};
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, r = c >> 3, k = kt * RM_BK + 4 * (c & 7);
+            const int c = tid + 512 * i, r = c >> 3, k = kt * RM_BK + 4 * (c & 7);
             const int n = n0 + r, ii = i0 + r;
             f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
             if (Xb) {
@@ -2089,10 +2108,10 @@ __global__ __launch_bounds__(256, 2) void rollout_matmul_kernel(const float* A, 
             ra[i] = y;
         }
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, r = c >> 3, off = r * RM_LS + 4 * (c & 7);
+            const int c = tid + 512 * i, r = c >> 3, off = r * RM_LS + 4 * (c & 7);
             bf16x4 xh, xl, ah, al;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -2101,48 +2120,57 @@ __global__ __launch_bounds__(256, 2) void rollout_matmul_kernel(const float* A, 
                 ah[e] = (bf16_t)ra[i][e];
                 al[e] = (bf16_t)(ra[i][e] - (float)ah[e]);
             }
-            *(bf16x4*)&sm[buf][0][off] = xh;
-            *(bf16x4*)&sm[buf][1][off] = xl;
-            *(bf16x4*)&sm[buf][2][off] = ah;
-            *(bf16x4*)&sm[buf][3][off] = al;
+            *(bf16x4*)&sm[0][off] = xh;
+            *(bf16x4*)&sm[1][off] = xl;
+            *(bf16x4*)&sm[2][off] = ah;
+            *(bf16x4*)&sm[3][off] = al;
         }
     };
-    f32x16 acc[NBLK];
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int nb = 0; nb < NBLK; ++nb) zero16(acc[nb]);
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) zero16(acc[rb][nb]);
     gload(0);
-    swrite(0);
-    __syncthreads();
     const int foff = (lane & 31) * RM_LS + 8 * (lane >> 5);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        swrite();
+        __syncthreads();
         if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < RM_BK / 16; ++ks) {
-            const bf16x8 xh = *(const bf16x8*)&sm[buf][0][32 * wave * RM_LS + foff + 16 * ks];
-            const bf16x8 xl = *(const bf16x8*)&sm[buf][1][32 * wave * RM_LS + foff + 16 * ks];
+            bf16x8 xh[2], xl[2];
 #pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) {
-                const bf16x8 ah = *(const bf16x8*)&sm[buf][2][32 * nb * RM_LS + foff + 16 * ks];
-                const bf16x8 al = *(const bf16x8*)&sm[buf][3][32 * nb * RM_LS + foff + 16 * ks];
-                acc[nb] = mfma32(xl, ah, acc[nb]);
-                acc[nb] = mfma32(xh, al, acc[nb]);
-                acc[nb] = mfma32(xh, ah, acc[nb]);
+            for (int rb = 0; rb < 2; ++rb) {
+                xh[rb] = *(const bf16x8*)&sm[0][(64 * wr + 32 * rb) * RM_LS + foff + 16 * ks];
+                xl[rb] = *(const bf16x8*)&sm[1][(64 * wr + 32 * rb) * RM_LS + foff + 16 * ks];
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const bf16x8 ah = *(const bf16x8*)&sm[2][(128 * wc + 32 * nb) * RM_LS + foff + 16 * ks];
+                const bf16x8 al = *(const bf16x8*)&sm[3][(128 * wc + 32 * nb) * RM_LS + foff + 16 * ks];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    acc[rb][nb] = mfma32(xl[rb], ah, acc[rb][nb]);
+                    acc[rb][nb] = mfma32(xh[rb], al, acc[rb][nb]);
+                    acc[rb][nb] = mfma32(xh[rb], ah, acc[rb][nb]);
+                }
             }
         }
-        if (kt + 1 < nk) swrite(buf ^ 1);
-        __syncthreads();
+        __syncthreads();  // every wave is done with this K tile's planes
     }
     float* Ob = Xout + (size_t)b * T * TP;
 #pragma unroll
-    for (int nb = 0; nb < NBLK; ++nb) {
-        const int col = i0 + 32 * nb + (lane & 31);
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = n0 + 32 * wave + acc_row(r, lane);
-            if (row < T && col < TP) Ob[(size_t)row * TP + col] = col < T ? acc[nb][r] : 0.f;
+        for (int nb = 0; nb < 4; ++nb) {
+            const int col = i0 + 128 * wc + 32 * nb + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + 64 * wr + 32 * rb + acc_row(r, lane);
+                if (row < T && col < TP) Ob[(size_t)row * TP + col] = col < T ? acc[rb][nb][r] : 0.f;
+            }
         }
-    }
 }
 
 template <int DP>
@@ -2180,9 +2208,9 @@ int launch_rollout_headmax(const AttnArgs& a, int DP, float* A, int TP, float* r
 }
 int launch_rollout_matmul(const float* A, const float* rowsum, const float* Xin, float* Xout, int B, int T, int TP, hipStream_t s) {
     if (TP % 4 != 0 || TP < T || B > 65535) return V1T_ERR_ARG;
-    dim3 grid((T + 127) / 128, (T + 127) / 128, B);
+    dim3 grid((T + 255) / 256, (T + 255) / 256, B);
     prof_begin(PROF_ROLLOUT_MM, s);
-    hipLaunchKernelGGL(rollout_matmul_kernel, grid, dim3(256), 0, s, A, rowsum, Xin, Xout, T, TP);
+    hipLaunchKernelGGL(rollout_matmul_kernel, grid, dim3(512), 0, s, A, rowsum, Xin, Xout, T, TP);
     prof_end(PROF_ROLLOUT_MM, s);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
