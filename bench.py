@@ -202,6 +202,55 @@ def run_rollout(a, dev):
     }
 
 
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` without torchrun: N child processes, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    torch.distributed.run sets them, rendezvous on 127.0.0.1), rank 0's stdout relayed (its ONE JSON line), the other ranks'
+    output to stderr. The parent never initialises the GPU: torch.cuda.device_count() does not (it reads the driver's list).
+    Exit code: the first non-zero child code; 2 when the node has fewer than N GPUs (never a silent single-GPU line)."""
+    import socket
+    import subprocess
+
+    if not a.dry_run:
+        n_dev = torch.cuda.device_count()
+        if n_dev < a.gpus:
+            print(f"bench.py: --gpus {a.gpus} but this node has {n_dev} GPU(s)", file=sys.stderr, flush=True)
+            return 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else sys.stderr, stderr=sys.stderr))
+    code = 0
+    for p_ in procs:
+        rc = p_.wait()
+        code = code or rc
+    return code
+
+
+def dry_run(a) -> int:
+    """Rendezvous check on the CPU (tests/test_bench_launch.py): gloo group over the launcher's environment, one all-reduce."""
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != a.gpus:
+        print(f"--gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    seen = torch.ones(1)
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_in_group": int(seen.item())}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,7 +262,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="roofline.traffic = null instead of reading the tracked PMC summary (used while collecting it)")
     ap.add_argument("--profile-class", type=int, default=2, help="kernel class timed with hipEvents (see include/v1t_amd.h)")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous check only (gloo, no GPU): every rank joins the process group, "
+                    "rank 0 prints how many ranks the group's all-reduce saw")
     a = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # started without torchrun: become the launcher BEFORE anything touches the GPU (a process that has initialised HIP is
+        # never re-executed; the ranks are fresh children)
+        raise SystemExit(spawn_ranks(a))
+    if a.dry_run:
+        raise SystemExit(dry_run(a))
 
     import torch.distributed as dist
     import v1t_amd
@@ -223,8 +281,10 @@ def main():
     from v1t_amd.trainer import Trainer
 
     rank, local, world = init_from_env()
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.is_available() and world > torch.cuda.device_count() and os.environ.get("V1T_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"--gpus {a.gpus} but this node has {torch.cuda.device_count()} GPU(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     local = local % torch.cuda.device_count()  # one rank per GPU under the driver; more ranks than GPUs share (dev runs)
@@ -275,7 +335,11 @@ def main():
     batches = {m: make_batch(args, m, neurons[m], args.batch_size, dev, seed=i) for i, m in enumerate(args.mouse_ids) if m in sharding.local_mice()}
 
     lib = L.load()
+    ranks_seen, backend = 1, "none"
     if world > 1:
+        cnt = torch.ones(1, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)  # how many ranks the collective library really joined (goes into the JSON line)
+        ranks_seen, backend = int(cnt.item()), str(dist.get_backend())
         # self-check of the exchange before anything is timed: the overlapped, bucketed all-reduce the trainer uses must give
         # the sums of one blocking all-reduce over the same buffer; otherwise fall back to the blocking form (and say so)
         core = model.core
@@ -354,7 +418,7 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16+fp16",
             "data": "synthetic",
-            "config": {"workload": workload, "global_batch": sharding.images_per_step(), "parallelism": f"mouse-dp{world}",
+            "config": {"workload": workload, "global_batch": sharding.images_per_step(), "parallelism": f"mouse-dp{world}", "ranks_in_group": ranks_seen, "backend": backend,
                        "exchange": ("bucketed async all-reduce behind per-block events" if trainer.overlap else "blocking all-reduce") if world > 1 else "none"},
             "loss": loss,
             "model_tflops_per_s": round(fl["train_per_image"] * images / dt / 1e12, 2),
