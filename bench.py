@@ -154,12 +154,12 @@ def run_rollout(a, dev):
         images, _ = model.image_cropper(b["image"], "A", b["behavior"], b["pupil_center"])
         full = a.rollout == "full"
         for _ in range(max(a.warmup, 1)):
-            heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], "A", full_chain=full)
+            heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], "A", full_chain=full, keep_scratch=full)
         torch.cuda.synchronize()
         L.check(lib.v1t_profile_enable(7 if full else 0, a.steps * args.num_blocks + 8))
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], "A", full_chain=full)
+            heat = attention_rollouts(model.core, images, b["behavior"], b["pupil_center"], "A", full_chain=full, keep_scratch=full)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     launches, total_ms = C.c_int(), C.c_double()
@@ -197,7 +197,8 @@ def run_rollout(a, dev):
                                f"image, is not executed - only its row 0 is used downstream), heat-maps {tuple(heat.shape)} included", "global_batch": B},
         "model_tflops_per_s": round(fl["fwd_per_image"] * B * a.steps / dt / 1e12, 2),
         "roofline": {"kernel": KERNELS[0][1] + ", eval (no dropout)", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic("attn_fwd_eval", B, args.num_heads, fl["T"], 160),
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None if a.no_pmc else pmc_traffic("attn_fwd_eval", B, args.num_heads, fl["T"], model.core.padded_dim),
+                     "traffic_source": None if a.no_pmc else "measured offline: " + os.path.relpath(PMC_FILE, ROOT),
                      "launches": launches.value, "avg_ms": round(avg_ms, 4), "flops_per_launch": per_launch},
     }
 

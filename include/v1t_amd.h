@@ -265,6 +265,13 @@ int v1t_attention_backward_ws(const void* qkv, const void* o, const void* dO, co
 int v1t_rollout_headmax(const void* qkv, const float* lse2, int B, int H, int T, int DP,
                         const float* scale, int scale_per_head, int mask_diag, float* A, int TP,
                         float* rowsum, void* stream);
+/* Per-head softmax probabilities of one block, P (B, H, T, TP) fp32 (pad columns zero): what the reference's Recorder hooks
+ * capture from every block's `attend` module (attention_rollout.py:31-36, stacked to (B, L, H, T, T) at :76), recomputed from
+ * the saved qkv and log2-sum-exp like v1t_rollout_headmax. 43.8 MB per image and block at the default size: for a bounded
+ * number of images (the "emit_probs" switch of SURVEY.md 8b next to "emit_headmax"). */
+int v1t_attention_probs(const void* qkv, const float* lse2, int B, int H, int T, int DP,
+                        const float* scale, int scale_per_head, int mask_diag, float* P, int TP,
+                        void* stream);
 /* One step of the rollout chain restricted to row 0 (only J[-1, 0, 1:] is used, :118):
  * u = v . ((A + I) / rowsum); v == NULL means v = e_0 (first step = row 0 of the last block). */
 int v1t_rollout_vecmat(const float* A, const float* rowsum, const float* v, float* u, int B, int T,

@@ -5,6 +5,13 @@ import numpy as np
 import torch
 
 MAX_SAMPLE = 4096
+MARGINS: dict = {}  # name -> (achieved error, bound): printed by conftest.pytest_terminal_summary, worst first
+
+
+def record_margin(name: str, err: float, bound: float) -> None:
+    old = MARGINS.get(name)
+    if old is None or err / max(bound, 1e-300) > old[0] / max(old[1], 1e-300):
+        MARGINS[name] = (float(err), float(bound))
 
 
 def sample(x: torch.Tensor) -> np.ndarray:
@@ -27,6 +34,7 @@ def assert_close(name, got, ref, rtol, atol):
     err = np.abs(got - ref)
     bound = atol + rtol * np.abs(ref)
     worst = float((err / bound).max()) if err.size else 0.0
+    record_margin(name, worst, 1.0)
     assert np.isfinite(got).all() and worst <= 1.0, f"{name}: max err {err.max():.3e}, {worst:.2f}x the bound (rtol {rtol}, atol {atol})"
 
 
@@ -34,6 +42,14 @@ def rel_to_max(got, ref) -> float:
     got = _np(got)
     ref = _np(ref)
     return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def check_rel(name: str, got, ref, tol: float) -> float:
+    """rel_to_max(got, ref) < tol, with the achieved error / bound recorded for the end-of-run table."""
+    e = rel_to_max(got, ref)
+    record_margin(name, e, tol)
+    assert e < tol, f"{name}: {e:.3e} of the reference's max, bound {tol:.1e} ({e / tol:.2f}x)"
+    return e
 
 
 def build_native_model(cfg, sd, device, dropout=None):

@@ -4,7 +4,7 @@ vectors generated from the real reference and (ii) the CPU oracle on the same se
 Tolerance for predicted responses (BASELINE.json north_star): <= 1e-3 relative, with the absolute floor
 1e-6 that ELU1's fp32 quantisation near 0 needs:
     |y - y_ref| <= 1e-3 * |y_ref| + 1e-6     for every (image, neuron).
-Gradients are compared relative to each tensor's max (bf16 mixed-precision backward): <= 5e-2.
+Gradients are compared relative to each tensor's max (bf16 mixed-precision backward): <= 1.2e-2 (G_TOL below).
 """
 import numpy as np
 import pytest
@@ -12,11 +12,13 @@ import torch
 
 from oracle import v1t_oracle as O
 from oracle import weights as W
-from tests.helpers import assert_close, build_native_model, rel_to_max, sample
+from tests.helpers import assert_close, build_native_model, check_rel, record_margin, rel_to_max, sample
 
 pytestmark = pytest.mark.gpu
 Y_RTOL, Y_ATOL = 1e-3, 1e-6
-G_TOL = 5e-2
+G_TOL = 1.2e-2  # per-tensor max error of a gradient relative to the tensor's max: 2x the worst measured over every golden / oracle
+                # gradient check (5.9e-3, GPUTEST r03; the end-of-run table prints the achieved margins)
+GN_TOL = 5e-3   # relative error of a gradient tensor's norm (worst measured 1.5e-3)
 
 
 @pytest.fixture(scope="module")
@@ -62,9 +64,10 @@ def test_predictions_and_grads_vs_reference_golden(golden, dev, name, cfg_fn):
         if float(np.abs(refg).max()) == 0.0:
             assert float(g.abs().max()) == 0.0
         else:
-            assert rel_to_max(sample(g), refg) < G_TOL, k
+            check_rel(f"{name}.grad.{k}", sample(g), refg, G_TOL)
         nrm, rn = float(g.double().norm()), float(golden[f"{name}/gradnorm/{k}"])
-        assert abs(nrm - rn) <= G_TOL * rn + 1e-12, k
+        record_margin(f"{name}.gradnorm.{k}", abs(nrm - rn), GN_TOL * rn + 1e-12)
+        assert abs(nrm - rn) <= GN_TOL * rn + 1e-12, k
         n += 1
     assert n >= 20
 
@@ -152,7 +155,7 @@ def test_drop_path_vs_reference_golden(dev):
             continue
         ref = g[gk]
         if float(np.abs(ref).max()) > 0:
-            assert rel_to_max(sample(p.grad), ref) < G_TOL, k
+            check_rel(f"test_drop_path_vs_reference_golden:" + str(k), sample(p.grad), ref, G_TOL)
         n += 1
     assert n >= 20
 
@@ -195,7 +198,7 @@ def test_image_shifter_vs_reference_golden(dev, sm):
             assert p.grad is not None, k
             ref = g[gk]
             if float(np.abs(ref).max()) > 0:
-                assert rel_to_max(sample(p.grad), ref) < G_TOL, k
+                check_rel(f"test_image_shifter_vs_reference_golden:" + str(k), sample(p.grad), ref, G_TOL)
             n += 1
         assert n >= 20 and any("image_shifter" in k for k, _ in model.named_parameters())
 
@@ -294,7 +297,7 @@ def test_patch_modes_2_3_gradients_vs_oracle(dev, pm):
             continue
         ref = sdd[k].grad
         assert ref is not None and p.grad is not None, k
-        assert rel_to_max(p.grad.detach().cpu().reshape(ref.shape), ref) < G_TOL, k
+        check_rel(f"test_patch_modes_2_3_gradients_vs_oracle:" + str(k), p.grad.detach().cpu().reshape(ref.shape), ref, G_TOL)
         n += 1
     assert n >= (6 if pm == 2 else 8)
 
@@ -319,7 +322,7 @@ def test_train_mode_readout_sampling_vs_reference_golden(golden, dev):
     loss = PoissonLoss(type("A", (), {"ds_scale": 1})(), ds={"A": type("D", (), {"dataset": range(4500)})()})(y_true=bd["response"], y_pred=y, mouse_id="A", batch_size=2)
     (loss + model.regularizer("A")).backward()
     g = model.readouts["A"].sigma.grad
-    assert rel_to_max(sample(g), golden["g4/grad/readouts.A.sigma"]) < G_TOL
+    check_rel("test_train_mode_readout_sampling_vs_reference_golden:3", sample(g), golden["g4/grad/readouts.A.sigma"], G_TOL)
 
 
 def test_train_mode_dropout_replayed_in_oracle(dev):
@@ -368,30 +371,36 @@ def test_train_mode_dropout_replayed_in_oracle(dev):
         ref = sdd[k].grad
         if ref is None or p.grad is None:
             continue
-        assert rel_to_max(p.grad.cpu().numpy(), ref.numpy()) < G_TOL, k
+        check_rel(f"test_train_mode_dropout_replayed_in_oracle:" + str(k), p.grad.cpu().numpy(), ref.numpy(), G_TOL)
 
 
-def test_optimizer_step_vs_reference_golden(golden, dev):
-    """G6: one full step = 2 mice summed + AdamW (train.py:97-111, 216-223) through the fused trainer."""
+@pytest.mark.parametrize("native", [True, False])
+def test_optimizer_step_vs_reference_golden(golden, dev, native):
+    """G6: one full step = 2 mice summed + AdamW (train.py:97-111, 216-223) through the fused trainer: the native step bench.py
+    times (_NativeStep, the reference's eps draws replayed through `Trainer.eps_override`) and the autograd path."""
+    from v1t_amd.synthetic import make_ds
     from v1t_amd.trainer import Trainer
 
     cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 200, "B": 123}, p_dropout=0.0, t_dropout=0.0)
     sd = W.make_state_dict(cfg, 55)
     model, args = build_native_model(cfg, sd, dev)
     args.batch_size = 4
-    from v1t_amd.synthetic import make_ds
-
     tr = Trainer(args, model, make_ds(cfg.num_neurons))
+    tr.native = native
     batches = {m: {k: v.to(dev) for k, v in W.make_batch(cfg, m, 4, 55).items()} for m in cfg.mouse_ids}
     eps = {m: torch.from_numpy(golden[f"step/eps/{m}"]).to(dev) for m in cfg.mouse_ids}
-    # inject the reference's eps draws into the readouts for this step
-    for m in cfg.mouse_ids:
-        ro = model.readouts[m]
-        orig = ro.forward
-        ro.forward = (lambda inputs, sample=None, shifts=None, eps=None, _o=orig, _e=eps[m]: _o(inputs, sample=sample, shifts=shifts, eps=_e))
+    if native:
+        tr.eps_override = eps
+    else:  # inject the reference's eps draws into the readouts for this step
+        for m in cfg.mouse_ids:
+            ro = model.readouts[m]
+            orig = ro.forward
+            ro.forward = (lambda inputs, sample=None, shifts=None, eps=None, _o=orig, _e=eps[m]: _o(inputs, sample=sample, shifts=shifts, eps=_e))
     tr.train_step(batches)
+    went_native = len(tr._native_cache) == 1 and next(iter(tr._native_cache.values())) is not None
+    assert went_native == native, "the step must run on the path this case names"
     new = model.state_dict()
-    bad = []
+    bad, worst = [], 0.0
     for k in golden:
         if k.startswith("step/param/"):
             key = k[len("step/param/"):]
@@ -399,8 +408,10 @@ def test_optimizer_step_vs_reference_golden(golden, dev):
             upd_ref, upd = ref - before, sample(new[key]) - before
             # Adam's first step moves every element by ~lr*sign(g): compare the update, tolerate sign flips of ~zero grads
             frac_bad = float(np.mean(np.abs(upd - upd_ref) > 0.25 * 1.647e-3))
+            worst = max(worst, frac_bad)
             if frac_bad > 0.02:
                 bad.append((key, frac_bad))
+    record_margin(f"g6.step(native={native}) fraction of elements off by > lr/4", worst, 0.02)
     assert not bad, bad
 
 
@@ -436,7 +447,7 @@ def test_attention_rollout_vs_reference_golden(golden, dev):
     rows, maps = rollout_rows(model.core, b["image"], b["behavior"], b["pupil_center"], "A", return_headmax=True)
     ref_rows = golden["rollout/row"]
     # pre-normalisation heat vector: entries ~1/T; bf16 q/k rounding -> <= 2e-3 relative to the row's max
-    assert rel_to_max(rows.cpu().numpy(), ref_rows) < 2e-3
+    check_rel("test_attention_rollout_vs_reference_golden:5", rows.cpu().numpy(), ref_rows, 2e-3)
     full_rows = rollout_rows(model.core, b["image"], b["behavior"], b["pupil_center"], "A", full_chain=True)  # the (T x T) matrix chain
     assert rel_to_max(full_rows.cpu().numpy(), ref_rows) < 2e-3 and rel_to_max(full_rows.cpu().numpy(), rows.cpu().numpy()) < 1e-4
     heat_full = attention_rollouts(model.core, b["image"], b["behavior"], b["pupil_center"], "A", full_chain=True)
@@ -459,10 +470,22 @@ def test_attention_rollout_vs_reference_golden(golden, dev):
     assert attn.shape == (2, cfg.num_blocks, 1, T, T) and out.shape == (2, *model.core.output_shape)
     for i in range(2):
         r = O.attention_rollout_row(attn[i].cpu())
-        assert rel_to_max(r.numpy(), ref_rows[i]) < 2e-3
+        check_rel("test_attention_rollout_vs_reference_golden:6", r.numpy(), ref_rows[i], 2e-3)
     assert rec.eject() is model.core
     with pytest.raises(AssertionError):
         rec(b["image"], b["behavior"], b["pupil_center"], "A")
+    # per-head probabilities, the reference Recorder's own tensor (B, blocks, heads, T, T) (attention_rollout.py:31-36, 76):
+    # against the oracle's recorded softmax outputs; their head-max is the map above; rows sum to 1
+    out2, probs = Recorder(model.core, per_head=True)(b["image"], b["behavior"], b["pupil_center"], "A")
+    assert probs.shape == (2, cfg.num_blocks, cfg.num_heads, T, T) and torch.equal(out2, out)
+    recd = []
+    with torch.no_grad():
+        O.vit_tokens(cfg, sd, W.make_batch(cfg, "A", 2, 99)["image"], "A", W.make_batch(cfg, "A", 2, 99)["behavior"], W.make_batch(cfg, "A", 2, 99)["pupil_center"], record=recd)
+    ref_p = torch.stack(recd, dim=1)
+    assert ref_p.shape == probs.shape
+    check_rel("g5.per-head probabilities vs oracle", probs.cpu(), ref_p, 2e-2)  # bf16 q / k: ~1e-2 of the largest probability
+    assert float((probs.sum(-1) - 1).abs().max()) < 2e-3
+    assert float((probs.amax(dim=2) - attn[:, :, 0]).abs().max()) < 1e-6
 
 
 def test_attention_rollout_vs_oracle_default_size(dev):
@@ -481,14 +504,14 @@ def test_attention_rollout_vs_oracle_default_size(dev):
     attn = torch.stack(rec, dim=1)
     for i in range(2):
         ref = O.attention_rollout_row(attn[i])
-        assert rel_to_max(rows[i].cpu().numpy(), ref.numpy()) < 3e-3
+        check_rel("test_attention_rollout_vs_oracle_default_size:7", rows[i].cpu().numpy(), ref.numpy(), 3e-3)
     # the reference's own algorithm, the (T x T) matrix chain, on the MFMAs (v1t_rollout_matmul, split-bf16 products): the same
     # head-max matrices, so it must agree with the row chain far below the tolerance against the oracle (bf16 q / k rounding)
     full = rollout_rows(model.core, b["image"], b["behavior"], b["pupil_center"], "A", full_chain=True)
     assert full.shape == rows.shape
-    assert rel_to_max(full.cpu().numpy(), rows.cpu().numpy()) < 1e-4
+    check_rel("test_attention_rollout_vs_oracle_default_size:8", full.cpu().numpy(), rows.cpu().numpy(), 1e-4)
     for i in range(2):
-        assert rel_to_max(full[i].cpu().numpy(), O.attention_rollout_row(attn[i]).numpy()) < 3e-3
+        check_rel("test_attention_rollout_vs_oracle_default_size:9", full[i].cpu().numpy(), O.attention_rollout_row(attn[i]).numpy(), 3e-3)
 
 
 @pytest.mark.parametrize("variant", [{}, {"use_lsa": True}, {"patch_mode": 3}, {"behavior_mode": 0, "shift_mode": 0}, {"patch_stride": 2, "disable_bias": True},
@@ -541,7 +564,7 @@ def test_core_batched_over_mice_equals_per_mouse(dev, variant):
     for a, b_ in zip(ys, ys2):
         assert torch.equal(a, b_)  # eval mode: no dropout, rows independent of the rest of the batch
     for k in ref:
-        assert rel_to_max(got[k], ref[k]) < 2e-3, k
+        check_rel(f"test_core_batched_over_mice_equals_per_mouse:" + str(k), got[k], ref[k], 5e-6)
     model.core.behavior_mode = 4
     with pytest.raises(NotImplementedError):
         model.core.forward_many([b["image"] for _, b in pairs], [m for m, _ in pairs], [b["behavior"] for _, b in pairs], [b["pupil_center"] for _, b in pairs])
@@ -583,7 +606,7 @@ def test_native_step_equals_autograd_step(dev, variant):
     assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref)
     assert set(ref) == set(got) == {"core", "A", "B", "C"}
     for k in ref:
-        assert rel_to_max(got[k], ref[k]) < 2e-3, k  # float atomics in both paths: last bits
+        check_rel(f"test_native_step_equals_autograd_step:" + str(k), got[k], ref[k], 5e-6)  # float atomics in both paths: last bits
 
 
 def test_native_step_eps_statistics(dev):

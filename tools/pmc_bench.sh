@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcb_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc > /tmp/pmcb_$C.log 2>&1
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmce_$C -- python3 $GRAFT_REPO_ROOT/bench.py --config c5 --steps 1 --warmup 1 --no-cpu-baseline > /tmp/pmce_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmce_$C -- python3 $GRAFT_REPO_ROOT/bench.py --config c5 --steps 1 --warmup 1 --no-cpu-baseline --no-pmc > /tmp/pmce_$C.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, os, collections

@@ -1056,6 +1056,14 @@ int v1t_rollout_headmax(const void* qkv, const float* lse2, int B, int H, int T,
     a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
     return launch_rollout_headmax(a, DP, A, TP, rowsum, (hipStream_t)stream);
 }
+int v1t_attention_probs(const void* qkv, const float* lse2, int B, int H, int T, int DP, const float* scale, int scale_per_head,
+                        int mask_diag, float* P, int TP, void* stream) {
+    if (!qkv || !lse2 || !scale || !P || TP < T || TP % 4) return V1T_ERR_ARG;
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.lse2 = (float*)lse2; a.B = B; a.H = H; a.T = T;
+    a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
+    return launch_rollout_headmax(a, DP, P, TP, nullptr, (hipStream_t)stream);
+}
 int v1t_rollout_matmul(const float* A, const float* rowsum, const float* Xin, float* Xout, int B, int T, int TP, void* stream) {
     if (!A || !rowsum || !Xout || Xout == Xin || B <= 0 || T <= 0) return V1T_ERR_ARG;
     return launch_rollout_matmul(A, rowsum, Xin, Xout, B, T, TP, (hipStream_t)stream);

@@ -1939,7 +1939,9 @@ int bwd_flags(const AttnArgs& a, hipStream_t s) {
 // log2-sum-exp, never materialising the (B,H,T,T) tensor the reference's forward hooks stack), plus the row
 // sums rs[i] = sum_j A[i][j] + 1 of the identity-augmented matrix. One wave = 32 query rows, all heads' Q
 // fragments in registers (one wave per SIMD), K tiles of all heads staged by LDS-DMA.
-template <int DP, int HH>
+// PH (per head): instead of the head-max, every head's probabilities P[b][h][q][:] (B, H, T, TP) - the tensor the reference's
+// Recorder stacks (attention_rollout.py:31-36, 76); rowsum is not written.
+template <int DP, int HH, bool PH = false>
 __global__ __launch_bounds__(256, 1) void rollout_headmax_kernel(AttnArgs a, float* A, int TP, float* rowsum) {
     using G = Geo<DP>;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][HH][TileDma<DP, G::RSTR>::LDS_ELEMS];
@@ -1996,8 +1998,22 @@ __global__ __launch_bounds__(256, 1) void rollout_headmax_kernel(AttnArgs a, flo
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = fast_exp2(fmaf(s[r], cs[h], nl[h]));
-                amax[r] = (h == 0) ? p : fmaxf(amax[r], p);
+                amax[r] = (h == 0 || PH) ? p : fmaxf(amax[r], p);
             }
+            if constexpr (PH) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int key0 = 32 * kt + 8 * g + 4 * h2;
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (key0 + j >= a.T || (a.mask_diag && key0 + j == q)) ? 0.f : amax[4 * g + j];
+                    if (qok && key0 < TP) *(f32x4*)(A + (((size_t)b * HH + h) * a.T + q) * TP + key0) = o;
+                }
+            }
+        }
+        if constexpr (PH) {
+            dma_wait_and_barrier();
+            continue;
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -2015,7 +2031,7 @@ __global__ __launch_bounds__(256, 1) void rollout_headmax_kernel(AttnArgs a, flo
         dma_wait_and_barrier();
     }
     rs += __shfl_xor(rs, 32);
-    if (qok && h2 == 0) rowsum[(size_t)b * a.T + q] = rs + 1.0f;
+    if (!PH && qok && h2 == 0) rowsum[(size_t)b * a.T + q] = rs + 1.0f;
 }
 
 // u[b][j] = sum_i w_i * (A[b][i][j] + delta_ij),  w_i = v[b][i] / rs[b][i]   (v == nullptr: v = e_0)
@@ -2176,6 +2192,16 @@ __global__ __launch_bounds__(512, 2) void rollout_matmul_kernel(const float* A, 
 template <int DP>
 int launch_headmax_t(const AttnArgs& a, float* A, int TP, float* rowsum, hipStream_t s) {
     dim3 grid((a.T + 127) / 128, a.B);
+    if (!rowsum) {  // per-head probabilities
+        switch (a.H) {
+            case 1: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 1, true>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;
+            case 2: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 2, true>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;
+            case 3: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 3, true>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;
+            case 4: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 4, true>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;
+            default: return V1T_ERR_UNSUPPORTED;
+        }
+        return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    }
     switch (a.H) {
         case 1: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 1>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;
         case 2: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 2>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;

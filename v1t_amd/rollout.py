@@ -23,6 +23,44 @@ from . import lib as L
 from .core import ViTCore, find_shape
 
 
+def release_rollout_scratch(core: ViTCore) -> None:
+    """Drop the (B, T, TP) fp32 buffers a `full_chain` rollout keeps on the core (8.5 GB at batch 256) and hand the memory back
+    to the device."""
+    if getattr(core, "_rollout_scratch", None) is not None:
+        core._rollout_scratch = None
+        torch.cuda.empty_cache()
+
+
+@torch.no_grad()
+def attention_probabilities(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, pupil_centers: torch.Tensor, mouse_id: str) -> torch.Tensor:
+    """Per-head softmax probabilities of every block, (B, blocks, heads, T, T) fp32 - the tensor the reference's Recorder returns
+    (attention_rollout.py:31-36, 76) - recomputed block by block from the saved q / k and log-sum-exp (`v1t_attention_probs`).
+    175 MB per image at the default size, like the reference's: meant for a handful of images."""
+    was_training = core.training
+    core.train(False)
+    try:
+        tokens = core.forward_tokens(images, mouse_id, behaviors, pupil_centers, keep_workspace=True)
+        core._last_tokens = tokens
+    finally:
+        core.train(was_training)
+    lib = L.load()
+    B, T = tokens.shape[0], core.num_tokens
+    TP = (T + 3) // 4 * 4
+    cfg = core._cfg
+    H, DP = cfg.num_heads, core.padded_dim
+    out = torch.empty((B, cfg.num_blocks, H, T, T), dtype=torch.float32, device=tokens.device)
+    P = torch.empty((B, H, T, TP), dtype=torch.float32, device=tokens.device)
+    nqkv, nlse = B * T * 3 * H * DP * 2, B * H * T * 4
+    for k in range(cfg.num_blocks):
+        qkv = core.workspace_tensor("qkv", k)[:nqkv]
+        lse2 = core.workspace_tensor("lse2", k)[:nlse]
+        scale = core.transformer.blocks[k]["mha"].scale
+        L.check(lib.v1t_attention_probs(qkv.data_ptr(), lse2.data_ptr(), B, H, T, DP, scale.data_ptr(), int(cfg.use_lsa), int(cfg.use_lsa),
+                                        P.data_ptr(), TP, L.stream()), "attention_probs")
+        out[:, k] = P[..., :T]
+    return out
+
+
 @torch.no_grad()
 def rollout_rows(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, pupil_centers: torch.Tensor, mouse_id: str,
                  return_headmax: bool = False, full_chain: bool = False):
@@ -80,9 +118,10 @@ def _rollout_rows_full(core: ViTCore, images, behaviors, pupil_centers, mouse_id
     cfg = core._cfg
     H, DP = cfg.num_heads, core.padded_dim
     dev = tokens.device
-    # A and the two ping-pong result^T buffers are (B, T, TP) fp32 each - 2.8 GB at batch 256: kept on the core between calls
-    # (a fresh 8.5 GB request per call makes the caching allocator release and re-map segments, 10x the time of the chain itself);
-    # Recorder.clear() drops them
+    # A and the two ping-pong result^T buffers are (B, T, TP) fp32 each - 2.8 GB at batch 256: kept on the core while a caller
+    # loops over batches (a fresh 8.5 GB request per call makes the caching allocator release and re-map segments, 10x the time
+    # of the chain itself); `attention_rollouts(..., keep_scratch=False)` (the default), `release_rollout_scratch(core)` or
+    # `Recorder.clear()` drop them
     key = (B, T, TP, str(dev))
     scratch = getattr(core, "_rollout_scratch", None)
     if scratch is None or scratch[0] != key:
@@ -116,11 +155,13 @@ class Recorder(torch.nn.Module):
     the MAX OVER HEADS of the softmax probabilities (recomputed from the saved q/k and log-sum-exp by `v1t_rollout_headmax`).
     The reference's first step is exactly that maximum (`torch.max(attention, dim=1)`, :105), which over a singleton head axis
     is the identity, so its heat-maps come out the same while the tensor is `heads` times smaller (43.8 MB instead of 175 MB
-    per image at the default size). Per-head probabilities are not available from the native core."""
+    per image at the default size). `Recorder(core, per_head=True)` returns the reference's own tensor instead, per-head
+    probabilities (B, blocks, heads, T, T) (`attention_probabilities`), at the reference's memory cost."""
 
-    def __init__(self, core: ViTCore):
+    def __init__(self, core: ViTCore, per_head: bool = False):
         super().__init__()
         self.core = core
+        self.per_head = per_head
         self.ejected = False
 
     def eject(self):
@@ -128,13 +169,15 @@ class Recorder(torch.nn.Module):
         return self.core
 
     def clear(self):
-        self.core._rollout_scratch = None
-        torch.cuda.empty_cache()
+        release_rollout_scratch(self.core)
 
     @torch.no_grad()
     def forward(self, images: torch.Tensor, behaviors: torch.Tensor, pupil_centers: torch.Tensor, mouse_id: str):
         assert not self.ejected, "recorder has been ejected, cannot be used anymore"
         core = self.core
+        if self.per_head:
+            probs = attention_probabilities(core, images, behaviors, pupil_centers, mouse_id)
+            return core.tokens_to_output(core._last_tokens), probs
         _, maps = rollout_rows(core, images, behaviors, pupil_centers, mouse_id, return_headmax=True)
         tokens = core._last_tokens
         return core.tokens_to_output(tokens), torch.stack(maps, dim=1)[:, :, None]
@@ -142,10 +185,14 @@ class Recorder(torch.nn.Module):
 
 @torch.no_grad()
 def attention_rollouts(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, pupil_centers: torch.Tensor, mouse_id: str,
-                       full_chain: bool = False) -> torch.Tensor:
+                       full_chain: bool = False, keep_scratch: bool = False) -> torch.Tensor:
     """Heat-maps (B, H, W) like reference `attention_rollouts` (attention_rollout.py:125-133) applied to the
-    recorder output of `core` on `images`."""
+    recorder output of `core` on `images`. `keep_scratch`: a `full_chain` rollout leaves its (B, T, TP) buffers on the core for
+    the next call (loops over many batches, bench.py); by default they are released before returning."""
     rows = rollout_rows(core, images, behaviors, pupil_centers, mouse_id, full_chain=full_chain)
+    if full_chain and not keep_scratch:
+        rows = rows.clone()
+        release_rollout_scratch(core)
     B = rows.shape[0]
     h, w = find_shape(rows.shape[1])
     heat = rows.reshape(B, h, w)
