@@ -158,8 +158,9 @@ int v1t_readout_grid_backward_ws(int B, int N, int gd, const float* src, const f
                                  const float* eps, const float* dgrid, float* dW0, float* db0, float* dW2,
                                  float* db2, float* dmu_free, float* dsigma, float* dshift, void* ws,
                                  long long ws_bytes, void* stream);
-/* The readout's position noise (gaussian2d.py:219-221: `norm = mu.new(...).normal_()`): n standard normal deviates from the
- * counter hash of (seed, stream_id), Box-Muller pairs; stateless (a step's draw can be replayed), one launch. */
+/* The readout's position noise (gaussian2d.py:219-221: `norm = mu.new(...).normal_()`): n standard normal deviates from
+ * Philox-4x32-10 keyed by the full 64-bit seed with counter (index, stream_id): every (seed, stream_id) is its own stream of
+ * independent 128-bit blocks, Box-Muller pairs from different words; stateless (a step's draw can be replayed), one launch. */
 int v1t_normal_fill(float* out, long long n, uint64_t seed, uint32_t stream_id, void* stream);
 /* out[r][0..na) = a[r][:], out[r][na..na+nb) = b[r][:], out rows ldo floats apart: the BehaviorMLP input
  * torch.cat((behaviors, pupil_centers), dim=-1) (vit.py:431-432) written straight into a shared batch buffer. */

@@ -99,6 +99,23 @@ def test_optimizer_groups_follow_reference_order_and_load_by_name():
     unnamed = {"state": sd["state"], "param_groups": [{k: v for k, v in x.items() if k != "name"} for x in swapped["param_groups"]]}
     with pytest.raises(ValueError):
         opt.load_state_dict(unnamed)
+    # everything is validated BEFORE anything is copied - a file whose parameters of one arena carry different
+    # step counts is rejected and leaves moments, step counters and learning rates as they were
+    import copy
+
+    bad = copy.deepcopy(sd)
+    last = max(bad["state"])
+    bad["state"][last]["step"] = torch.tensor(7.0)
+    for st in bad["state"].values():
+        st["exp_avg"] = st["exp_avg"] + 1.0
+    bad["param_groups"][0]["lr"] = 123.0
+    before = {m: (model.mouse_arena(m).exp_avg.clone(), model.mouse_arena(m).step) for m in neurons}
+    core_before = (model.core._arena.exp_avg.clone(), model.core._arena.step, opt.group_lr("core"))
+    with pytest.raises(ValueError, match="step counts"):
+        opt.load_state_dict(bad)
+    for m in neurons:
+        assert torch.equal(model.mouse_arena(m).exp_avg, before[m][0]) and model.mouse_arena(m).step == before[m][1]
+    assert torch.equal(model.core._arena.exp_avg, core_before[0]) and model.core._arena.step == core_before[1] and opt.group_lr("core") == core_before[2]
 
 
 @pytest.mark.gpu

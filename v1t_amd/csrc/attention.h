@@ -26,8 +26,9 @@ struct AttnArgs {
     // one streaming GEMM instead of a second recomputation of S and dP (5 MFMA products instead of 7). Layout (attention.hip,
     // "producer / consumer backward"): [B*H][32-query block][32-key block][k-step 2][lane 64][8] bf16 - a 32 x 32 block is the
     // 2 KB the consumer wave holds as its two B-operand fragments (key on the lane), stored with two 16-B-per-lane instructions.
-    // Behind it: the padded per-row constants [B*H][TPq] fp32 each, nlse = -lse2 / (scale log2 e) and ndelta = -keep_prob *
-    // rowsum(dO * O) (pad rows: nlse = -1e30, so P = 0 there), written by the delta kernel.
+    // Behind it: the padded per-row constants [B*H][TPq] fp32 each, nlse = -lse2 (log2 domain: the dK/dV producers pre-multiply K by
+    // scale log2 e, so S' = (c K) Q^T + nlse is the exponent itself) and ndelta = -keep_prob * rowsum(dO * O) (pad rows:
+    // nlse = -1e30, so P = 0 there), written by attn_delta2_kernel.
     bf16_t* ds; int ldds;
 };
 __host__ __device__ inline int attn_ds_ld(int T) { return (T + 127) / 128 * 128; }             // key columns covered (128-key workgroups)

@@ -468,7 +468,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// Forward, software-pipelined (default path: DP >= 128, no LSA diagonal). Same geometry and products as attn_fwd_kernel
+// Forward, software-pipelined - OPT-IN (V1T_ATTN_FWD_V2=1, DP >= 128, no LSA diagonal; attn_fwd_kernel above is the default: this
+// one ties with it). Same geometry and products as attn_fwd_kernel
 // (8 waves x 32 queries share 64-key K/V stages; S^T = K Q^T with the query on the lane, O^T += V^T P^T with P^T straight
 // from the accumulator), but a wave keeps THREE key tiles in flight: iteration t issues, one MFMA per "slot",
 //     O^T += V^T P^T of tile t - 1   (KS MFMAs)   and   S'^T = K Q^T of tile t + 1   (KS MFMAs),

@@ -378,25 +378,47 @@ int launch_shifter_bwd(const ShifterArgs& a, hipStream_t s) {
     return ok();
 }
 
-// ---- standard normal deviates from the counter hash (the readout's position noise eps ~ N(0, I), gaussian2d.py:219-221):
-// element pair (2 i, 2 i + 1) = Box-Muller of two 24-bit uniforms hashed from (key, i). Stateless, so the draw of a step is a
-// function of (seed, stream id) and can be replayed; replaces a torch normal_() launch on torch's Philox stream.
-__global__ __launch_bounds__(256) void normal_fill_kernel(float* out, long long n, uint32_t key) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // pair index
-    if (2 * i >= n) return;
-    const uint32_t h1 = mix32(key + (uint32_t)i * 0x9E3779B1u), h2 = mix32(h1 ^ 0x85EBCA77u ^ (uint32_t)(i >> 32));
-    const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
-    const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);            // [0, 1)
-    const float r = sqrtf(-2.0f * __logf(u1));
-    float sn, cs;
-    __sincosf(6.283185307179586f * u2, &sn, &cs);
-    out[2 * i] = r * cs;
-    if (2 * i + 1 < n) out[2 * i + 1] = r * sn;
+// ---- standard normal deviates (the readout's position noise eps ~ N(0, I), gaussian2d.py:219-221) from Philox-4x32-10
+// (Salmon et al. 2011, the generator family torch's normal_() draws from): key = the full 64-bit seed, counter = (quad index lo,
+// quad index hi, stream id, 0), so every (seed, stream) pair is its own 2^64-long stream of independent 128-bit blocks - no
+// 32-bit key collapse, no overlapping windows between mice / steps / ranks. One block = 4 uniform words = 2 Box-Muller pairs
+// (u1, u2 from DIFFERENT words) = out[4 i .. 4 i + 3]. Stateless: the draw of a step is a function of (seed, stream id) and can
+// be replayed.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__global__ __launch_bounds__(256) void normal_fill_kernel(float* out, long long n, uint32_t k0, uint32_t k1, uint32_t stream_id) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // quad index
+    if (4 * i >= n) return;
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)((unsigned long long)i >> 32), stream_id, 0u};
+    philox4x32_10(c, k0, k1);
+    float z[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)(c[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+        const float u2 = (float)(c[2 * p + 1] >> 8) * (1.0f / 16777216.0f);        // [0, 1)
+        const float r = sqrtf(-2.0f * __logf(u1));
+        float sn, cs;
+        __sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[2 * p] = r * cs;
+        z[2 * p + 1] = r * sn;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (4 * i + e < n) out[4 * i + e] = z[e];
 }
 int launch_normal_fill(float* out, long long n, uint64_t seed, uint32_t stream_id, hipStream_t s) {
     if (n <= 0) return V1T_OK;
-    const long long pairs = (n + 1) / 2;
-    hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, out, n, drop_key(seed, stream_id));
+    const long long quads = (n + 3) / 4;
+    hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, out, n, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id);
     return ok();
 }
 // out[r][0 .. na) = a[r][:], out[r][na .. na + nb) = b[r][:]  (the BehaviorMLP input cat(behaviors, pupil_centers), vit.py:431-432,

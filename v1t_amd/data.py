@@ -7,8 +7,8 @@ Host-side mirror of src/v1t/data.py with the same names, arguments and batch dic
 The reference reads 4 `.npy` files per trial per epoch through torch DataLoader workers. Here a mouse's recording is read
 ONCE (`MouseStore`) into packed `[trials][...]` arrays in HBM, and `DeviceLoader` builds every batch with one gather +
 standardise launch per field (`v1t_gather_transform`), so nothing but a few hundred index bytes crosses PCIe per step.
-`MiceDataset.__getitem__` keeps the reference's per-trial host path (numpy, same arithmetic) for code that indexes the
-dataset directly.
+The standardisation lives in ONE table (`FieldTransform` per field) read by the device gather, by the host `__getitem__`
+(for code that indexes the dataset directly) and by the inverse transforms.
 """
 from __future__ import annotations
 
@@ -120,32 +120,68 @@ class MouseStore:
         return cls._cache[key]
 
 
+class FieldTransform(t.NamedTuple):
+    """y = (x - sub) / div * mul for one field of a trial (None = identity for that step); `v1t_gather_transform` applies it on
+    the device, `apply` / `invert` on the host. Statistics are scalars or arrays of the field's own shape."""
+    sub: t.Optional[np.ndarray] = None
+    div: t.Optional[np.ndarray] = None
+    mul: t.Optional[np.ndarray] = None
+
+    def apply(self, x):
+        if self.sub is not None:
+            x = x - self.sub
+        if self.div is not None:
+            x = x / self.div
+        return x if self.mul is None else x * self.mul
+
+    def invert(self, y):
+        if self.mul is not None:
+            y = y / self.mul
+        if self.div is not None:
+            y = y * self.div
+        return y if self.sub is None else y + self.sub
+
+
+def _standardisation(stats: t.Dict[str, t.Dict[str, np.ndarray]]) -> t.Dict[str, FieldTransform]:
+    """The dataset's standardisation as ONE table (what data.py:357-410 does field by field): images and pupil centres are
+    z-scored, behaviour is divided by its std, responses are multiplied by the per-neuron precision 1 / std, where neurons whose
+    std is below 1 % of the mean std get 1 / (that threshold) instead (data.py:387-397)."""
+    std = stats["response"]["std"]
+    floor = 0.01 * np.mean(std)
+    precision = 1.0 / np.where(std > floor, std, floor).astype(std.dtype)
+    return {"image": FieldTransform(sub=stats["image"]["mean"], div=stats["image"]["std"]),
+            "response": FieldTransform(mul=precision),
+            "behavior": FieldTransform(div=stats["behavior"]["std"]),
+            "pupil_center": FieldTransform(sub=stats["pupil_center"]["mean"], div=stats["pupil_center"]["std"])}
+
+
 class MiceDataset:
-    """reference data.py:275-434"""
+    """One tier of one mouse's recording (the reference's `MiceDataset`, data.py:275-434: same constructor, attributes the
+    readouts and metrics read - `coordinates`, `neuron_ids`, `*_stats`, `image_ids`, `trial_ids`, `image_shape`, `hashed` - and
+    per-field `transform_* / i_transform_*` methods). Built around the packed `MouseStore`: the standardisation is one
+    `FieldTransform` table that the device gather, the host `__getitem__` and the inverse transforms all read."""
 
     def __init__(self, args, tier: str, data_dir: str, mouse_id: str):
-        assert tier in ("train", "validation", "test", "final_test")
-        self.tier, self.mouse_id, self.ds_name = tier, mouse_id, args.ds_name
-        assert self.ds_name in ("sensorium", "franke2022")
-        mouse_dir = os.path.join(data_dir, get_mouse2path(self.ds_name)[mouse_id])
-        md = load_mouse_metadata(self.ds_name, mouse_dir=mouse_dir)
-        self.behavior_mode = args.behavior_mode
+        if tier not in ("train", "validation", "test", "final_test"):
+            raise AssertionError(f"unknown tier {tier}")
+        self.tier, self.mouse_id, self.ds_name, self.behavior_mode = tier, mouse_id, args.ds_name, args.behavior_mode
+        self.mouse_dir = os.path.join(data_dir, get_mouse2path(self.ds_name)[mouse_id])
         if self.behavior_mode and mouse_id == "S0":
-            raise ValueError("Mouse S0 does not have behaviour data.")
-        self.mouse_dir, self.neuron_ids, self.coordinates, self.stats = md["mouse_dir"], md["neuron_ids"], md["coordinates"], md["stats"]
-        indexes = np.where(md["tiers"] == tier)[0].astype(np.int32)
-        if tier == "train" and getattr(args, "limit_data", None) and len(indexes) > args.limit_data:
-            indexes = np.random.default_rng(seed=args.seed).choice(indexes, size=args.limit_data, replace=False)
-        self.indexes = indexes
-        self.image_ids = md["image_ids"][self.indexes]
-        self.trial_ids = md["trial_ids"][self.indexes]
-        self.compute_response_precision()
-        self.hashed = self.ds_name == "sensorium" and mouse_id in ("S0", "S1")
-        self.image_shape = tuple(np.load(os.path.join(mouse_dir, "data", "images", "0.npy")).shape)
-        self.gray_scale = False
-        if getattr(args, "gray_scale", False) and self.ds_name == "franke2022":
-            self.gray_scale = True
-            self.image_shape = (1,) + self.image_shape[1:]
+            raise ValueError("Mouse S0 does not have behaviour data.")  # the reference's message (data.py:296)
+        md = load_mouse_metadata(self.ds_name, mouse_dir=self.mouse_dir)
+        self.neuron_ids, self.coordinates, self.stats = md["neuron_ids"], md["coordinates"], md["stats"]
+        self.transforms = _standardisation(self.stats)
+        self._response_precision = self.transforms["response"].mul
+        # the trials of this tier; --limit_data keeps a seeded random subset of the training tier (data.py:310-321)
+        rows = np.flatnonzero(md["tiers"] == tier).astype(np.int32)
+        limit = getattr(args, "limit_data", None)
+        if tier == "train" and limit and len(rows) > limit:
+            rows = np.random.default_rng(seed=args.seed).choice(rows, size=limit, replace=False)
+        self.indexes, self.image_ids, self.trial_ids = rows, md["image_ids"][rows], md["trial_ids"][rows]
+        self.hashed = (self.ds_name, mouse_id) in (("sensorium", "S0"), ("sensorium", "S1"))  # live-test mice: hashed labels
+        c, *hw = np.load(os.path.join(self.mouse_dir, "data", FIELDS["image"], "0.npy")).shape
+        self.gray_scale = bool(getattr(args, "gray_scale", False)) and self.ds_name == "franke2022"
+        self.image_shape = (1 if self.gray_scale else c, *hw)
         self._dev: t.Optional[t.Dict[str, t.Any]] = None
 
     def __len__(self):
@@ -157,67 +193,40 @@ class MiceDataset:
     pupil_stats = property(lambda self: self.stats["pupil_center"])
     num_neurons = property(lambda self: len(self.neuron_ids))
 
-    def compute_response_precision(self):
-        """1 / std per neuron where std > 1 % of the mean std, else 1 / threshold (data.py:387-397)"""
-        std = self.response_stats["std"]
-        threshold = 0.01 * np.mean(std)
-        idx = std > threshold
-        precision = np.ones_like(std) / threshold
-        precision[idx] = 1 / std[idx]
-        self._response_precision = precision
-
-    # ---- host transforms (per trial, numpy), as the reference applies them in __getitem__
+    # ---- host side: the reference's per-field method names over the table
     def transform_image(self, image):
-        image = (image - self.image_stats["mean"]) / self.image_stats["std"]
-        return np.mean(image, axis=0, keepdims=True) if self.gray_scale else image
+        z = self.transforms["image"].apply(image)
+        return z.mean(axis=0, keepdims=True) if self.gray_scale else z
 
     def i_transform_image(self, image):
-        if self.behavior_mode == 1:
-            image = torch.unsqueeze(image[0], dim=0) if len(image.shape) == 3 else torch.unsqueeze(image[:, 0, :, :], dim=1)
-        return (image * self.image_stats["std"]) + self.image_stats["mean"]
-
-    def transform_pupil_center(self, x):
-        return (x - self.pupil_stats["mean"]) / self.pupil_stats["std"]
-
-    def i_transform_pupil_center(self, x):
-        return (x * self.pupil_stats["std"]) + self.pupil_stats["mean"]
-
-    def transform_behavior(self, x):
-        return x / self.behavior_stats["std"]
-
-    def i_transform_behavior(self, x):
-        return x * self.behavior_stats["std"]
-
-    def transform_response(self, x):
-        return x * self._response_precision
-
-    def i_transform_response(self, x):
-        return x / self._response_precision
+        if self.behavior_mode == 1:  # behaviour planes were appended as channels: keep the stimulus channel (data.py:364-372)
+            image = image[:1] if image.ndim == 3 else image[:, :1]
+        return self.transforms["image"].invert(image)
 
     def __getitem__(self, idx):
+        """One standardised trial from the .npy files (for code that indexes the dataset; the training path is `device_batch`)."""
         trial = self.indexes[idx]
-        load = lambda d: np.load(os.path.join(self.mouse_dir, "data", d, f"{trial}.npy")).astype(np.float32)
-        return {
-            "image": self.transform_image(load("images")), "response": self.transform_response(load("responses")),
-            "behavior": self.transform_behavior(load("behavior")), "pupil_center": self.transform_pupil_center(load("pupil_center")),
-            "image_id": self.image_ids[idx], "trial_id": self.trial_ids[idx], "mouse_id": self.mouse_id,
-        }
+        item = {f: self.transforms[f].apply(np.load(os.path.join(self.mouse_dir, "data", d, f"{trial}.npy")).astype(np.float32)) for f, d in FIELDS.items()}
+        if self.gray_scale:
+            item["image"] = item["image"].mean(axis=0, keepdims=True)
+        item.update(image_id=self.image_ids[idx], trial_id=self.trial_ids[idx], mouse_id=self.mouse_id)
+        return item
 
     # ---- device path
     def _device_state(self, device: torch.device):
         if self._dev is None or self._dev["device"] != torch.device(device):
             store = MouseStore.get(self.mouse_dir, device)
-            f32 = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1))).to(device)
-            # (sub, div, mul) per field; statistics are scalars or arrays of the field's shape (broadcast by period)
-            tf = {"image": (f32(self.image_stats["mean"]), f32(self.image_stats["std"]), None),
-                  "response": (None, None, f32(self._response_precision)),
-                  "behavior": (None, f32(self.behavior_stats["std"]), None),
-                  "pupil_center": (f32(self.pupil_stats["mean"]), f32(self.pupil_stats["std"]), None)}
-            for field, (s_, d_, m_) in tf.items():
+            tf = {}
+            for field, ft in self.transforms.items():
                 e = store.data[field].shape[1]
-                for a in (s_, d_, m_):
-                    if a is not None and a.numel() not in (1, e):
-                        raise RuntimeError(f"{field} statistics of {a.numel()} elements do not broadcast over {store.shapes[field]}")
+                dev_ft = []
+                for a in ft:  # statistics broadcast over the flattened field by period: scalar or the field's own size
+                    if a is not None:
+                        a = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1))).to(device)
+                        if a.numel() not in (1, e):
+                            raise RuntimeError(f"{field} statistics of {a.numel()} elements do not broadcast over {store.shapes[field]}")
+                    dev_ft.append(a)
+                tf[field] = tuple(dev_ft)
             self._dev = {"device": torch.device(device), "store": store, "tf": tf,
                          "indexes": torch.from_numpy(self.indexes.astype(np.int32)).to(device)}
         return self._dev
@@ -248,6 +257,16 @@ class MiceDataset:
         out["trial_id"] = torch.from_numpy(np.asarray(tid)) if np.issubdtype(np.asarray(tid).dtype, np.number) else list(tid)
         out["mouse_id"] = [self.mouse_id] * b
         return out
+
+
+def _field_methods():
+    # transform_<field> / i_transform_<field> for the remaining fields (the names evaluate.py / user code call): table look-ups
+    for field, stem in (("pupil_center", "pupil_center"), ("behavior", "behavior"), ("response", "response")):
+        setattr(MiceDataset, f"transform_{stem}", lambda self, x, _f=field: self.transforms[_f].apply(x))
+        setattr(MiceDataset, f"i_transform_{stem}", lambda self, x, _f=field: self.transforms[_f].invert(x))
+
+
+_field_methods()
 
 
 class DeviceLoader:

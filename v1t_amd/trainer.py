@@ -90,6 +90,7 @@ class FusedAdamW:
             pairs = list(zip(self.param_groups, saved_groups))
         slots = self._slots()
         todo = []
+        steps: t.Dict[int, int] = {}
         for g, saved in pairs:
             if len(saved["params"]) != len(g["params"]):
                 raise ValueError(f"group {g['name']}: loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
@@ -100,16 +101,17 @@ class FusedAdamW:
                 for k in ("exp_avg", "exp_avg_sq"):
                     if tuple(st[k].shape) != tuple(p.shape):
                         raise ValueError(f"group {g['name']}: {k} of saved parameter {j} has shape {tuple(st[k].shape)}, the parameter {tuple(p.shape)}")
-                todo.append((slots[id(p)], st))
-        steps: t.Dict[int, int] = {}
+                a_, s_ = slots[id(p)]
+                n = int(float(st["step"]))
+                if steps.setdefault(id(a_), n) != n:  # one fused launch per arena shares one bias-correction step
+                    raise ValueError(f"group {g['name']}: parameters of one arena carry different step counts ({steps[id(a_)]} and {n})")
+                todo.append(((a_, s_), st))
+        # nothing has been written up to here: a rejected file leaves the optimizer untouched
         for (a, s), st in todo:
             m_, v_ = a.moments()
             s.view(m_[s.offset:s.offset + s.numel]).copy_(st["exp_avg"].to(m_.device))
             s.view(v_[s.offset:s.offset + s.numel]).copy_(st["exp_avg_sq"].to(v_.device))
-            n = int(float(st["step"]))
-            if steps.setdefault(id(a), n) != n:
-                raise ValueError("parameters of one arena carry different step counts")
-            a.step = n
+            a.step = steps[id(a)]
         for g, saved in pairs:
             g["lr"] = float(saved["lr"])
 
@@ -281,7 +283,7 @@ class _NativeStep:
                 if ov is not None:
                     t_["eps"].copy_(ov.reshape(n, N, 2))
                 else:
-                    L.check(lib.v1t_normal_fill(t_["eps"].data_ptr(), n * N * 2, trainer._eps_state, 0x10000 + 256 * trainer.mouse_ids.index(m) + trainer.sharding.rank, s_),
+                    L.check(lib.v1t_normal_fill(t_["eps"].data_ptr(), n * N * 2, trainer._eps_state, ((1 + trainer.mouse_ids.index(m)) << 16) | (trainer.sharding.rank & 0xFFFF), s_),
                             "normal_fill")
                 if t_["mu"] is not None:
                     with torch.no_grad():
