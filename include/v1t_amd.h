@@ -135,6 +135,13 @@ int v1t_gaussian2d_backward_ws(const float* z, long long zsb, long long zsc, int
                                int N, const float* grid, const float* feat, int FS, const float* gout,
                                float* dz, long long dzsb, long long dzsc, float* dgrid, float* dfeat,
                                float* dbias, void* ws, long long ws_bytes, void* stream);
+/* The three kernels of the form above one by one, `parts` = bit mask: 1 sort the taps (needs grid only - the training step runs
+ * it while the core is still in its forward), 2 parameter gradients (dgrid, dfeat, dbias), 4 gather dz from the sorted taps
+ * (needs part 1's scratch and gout; z / dz addressing as above). 7 == v1t_gaussian2d_backward_ws. */
+int v1t_gaussian2d_backward_parts(const float* z, long long zsb, long long zsc, int B, int C, int H, int W,
+                                  int N, const float* grid, const float* feat, int FS, const float* gout,
+                                  float* dz, long long dzsb, long long dzsc, float* dgrid, float* dfeat,
+                                  float* dbias, void* ws, long long ws_bytes, int parts, void* stream);
 
 /* Readout sample positions (gaussian2d.py:188-235, 265-268): mu from the grid predictor
  * (Linear(gd,30) -> ELU -> Linear(30,2) -> tanh on the normalised cortical coordinates src (N,gd); gd == 0:

@@ -909,6 +909,16 @@ int v1t_gaussian2d_backward_ws(const float* z, long long zsb, long long zsc, int
     a.gout = gout; a.dz = dz; a.dzsb = dzsb; a.dzsc = dzsc; a.dgrid = dgrid; a.dfeat = dfeat; a.dbias = dbias;
     return launch_readout_bwd(a, ws, (size_t)ws_bytes, (hipStream_t)stream);
 }
+int v1t_gaussian2d_backward_parts(const float* z, long long zsb, long long zsc, int B, int C, int H, int W, int N, const float* grid,
+                                  const float* feat, int FS, const float* gout, float* dz, long long dzsb, long long dzsc,
+                                  float* dgrid, float* dfeat, float* dbias, void* ws, long long ws_bytes, int parts, void* stream) {
+    if (!grid || !ws || ws_bytes <= 0 || parts <= 0 || parts > READOUT_BWD_ALL) return V1T_ERR_ARG;
+    if ((parts & (READOUT_BWD_PARAMS | READOUT_BWD_DZ)) && (!z || !feat || !gout)) return V1T_ERR_ARG;
+    ReadoutArgs a{};
+    a.z = z; a.zsb = zsb; a.zsc = zsc; a.B = B; a.C = C; a.H = H; a.W = W; a.N = N; a.grid = grid; a.feat = feat; a.FS = FS;
+    a.gout = gout; a.dz = dz; a.dzsb = dzsb; a.dzsc = dzsc; a.dgrid = dgrid; a.dfeat = dfeat; a.dbias = dbias;
+    return launch_readout_bwd_parts(a, ws, (size_t)ws_bytes, parts, (hipStream_t)stream);
+}
 int v1t_gaussian2d_backward(const float* z, long long zsb, long long zsc, int B, int C, int H, int W, int N, const float* grid,
                             const float* feat, int FS, const float* gout, float* dz, long long dzsb, long long dzsc,
                             float* dgrid, float* dfeat, float* dbias, void* stream) {

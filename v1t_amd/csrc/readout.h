@@ -24,3 +24,6 @@ int launch_readout_fwd(const ReadoutArgs& a, hipStream_t s);
 // ws: optional scratch of readout_bwd_ws_bytes() bytes; with it dz is gathered through per-cell lists (no float atomics)
 size_t readout_bwd_ws_bytes(int B, int H, int W, int N);
 int launch_readout_bwd(const ReadoutArgs& a, void* ws, size_t ws_bytes, hipStream_t s);
+// the sorted form's kernels one by one: parts = bit mask of the values below (SORT needs grid only; DZ needs SORT's scratch and gout)
+enum { READOUT_BWD_SORT = 1, READOUT_BWD_PARAMS = 2, READOUT_BWD_DZ = 4, READOUT_BWD_ALL = 7 };
+int launch_readout_bwd_parts(const ReadoutArgs& a, void* ws, size_t ws_bytes, int parts, hipStream_t s);

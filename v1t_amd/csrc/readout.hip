@@ -277,31 +277,40 @@ DzSort sort_plan(void* ws, int B, int N) {
 }
 
 template <int NE>
-int launch_t(const ReadoutArgs& a, bool bwd, void* ws, size_t ws_bytes, hipStream_t s) {
+int launch_t(const ReadoutArgs& a, bool bwd, void* ws, size_t ws_bytes, hipStream_t s, int parts = READOUT_BWD_ALL) {
     const dim3 grid((a.N + 3) / 4);
     if (!bwd) {
         hipLaunchKernelGGL(readout_fwd_kernel<NE>, grid, dim3(256), 0, s, a);
-    } else if (a.dz && ws && a.H * a.W <= DZ_MAX_CELLS && ws_bytes >= readout_bwd_ws_bytes(a.B, a.H, a.W, a.N)) {
+    } else if (ws && a.H * a.W <= DZ_MAX_CELLS && ws_bytes >= readout_bwd_ws_bytes(a.B, a.H, a.W, a.N) && (a.dz || parts != READOUT_BWD_ALL)) {
+        // the three kernels of the sorted form, individually selectable (the training step sorts the taps while the core is still
+        // in its forward - the sort needs the sample positions only - and gathers dz before the parameter gradients, so that the
+        // core's backward can start as early as possible)
         const DzSort ix = sort_plan(ws, a.B, a.N);
-        ReadoutArgs a2 = a;
-        a2.dz = nullptr;
-        hipLaunchKernelGGL(readout_sort_kernel, dim3(DZ_SLICES, a.B), dim3(1024), 0, s, a, ix);
-        hipLaunchKernelGGL(readout_bwd_kernel<NE>, grid, dim3(256), 0, s, a2);
-        const size_t chunks = (size_t)a.B * DZ_SLICES * ix.R / 64;
-        hipLaunchKernelGGL(readout_dz_gather_kernel<NE>, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, a, ix);
+        if (parts & READOUT_BWD_SORT) hipLaunchKernelGGL(readout_sort_kernel, dim3(DZ_SLICES, a.B), dim3(1024), 0, s, a, ix);
+        if (parts & READOUT_BWD_PARAMS) {
+            ReadoutArgs a2 = a;
+            a2.dz = nullptr;
+            hipLaunchKernelGGL(readout_bwd_kernel<NE>, grid, dim3(256), 0, s, a2);
+        }
+        if ((parts & READOUT_BWD_DZ) && a.dz) {
+            const size_t chunks = (size_t)a.B * DZ_SLICES * ix.R / 64;
+            hipLaunchKernelGGL(readout_dz_gather_kernel<NE>, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, a, ix);
+        }
+    } else if (parts != READOUT_BWD_ALL) {
+        return V1T_ERR_WORKSPACE;  // the split form exists with the sorted workspace only
     } else {
         hipLaunchKernelGGL(readout_bwd_kernel<NE>, grid, dim3(256), 0, s, a);
     }
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 
-int dispatch(const ReadoutArgs& a, bool bwd, void* ws, size_t ws_bytes, hipStream_t s) {
+int dispatch(const ReadoutArgs& a, bool bwd, void* ws, size_t ws_bytes, hipStream_t s, int parts = READOUT_BWD_ALL) {
     if (a.C > 256 || a.N <= 0) return a.N <= 0 ? V1T_OK : V1T_ERR_UNSUPPORTED;
     switch ((a.C + 63) / 64) {
-        case 1: return launch_t<1>(a, bwd, ws, ws_bytes, s);
-        case 2: return launch_t<2>(a, bwd, ws, ws_bytes, s);
-        case 3: return launch_t<3>(a, bwd, ws, ws_bytes, s);
-        default: return launch_t<4>(a, bwd, ws, ws_bytes, s);
+        case 1: return launch_t<1>(a, bwd, ws, ws_bytes, s, parts);
+        case 2: return launch_t<2>(a, bwd, ws, ws_bytes, s, parts);
+        case 3: return launch_t<3>(a, bwd, ws, ws_bytes, s, parts);
+        default: return launch_t<4>(a, bwd, ws, ws_bytes, s, parts);
     }
 }
 
@@ -314,3 +323,4 @@ size_t readout_bwd_ws_bytes(int B, int H, int W, int N) {
 }
 int launch_readout_fwd(const ReadoutArgs& a, hipStream_t s) { return dispatch(a, false, nullptr, 0, s); }
 int launch_readout_bwd(const ReadoutArgs& a, void* ws, size_t ws_bytes, hipStream_t s) { return dispatch(a, true, ws, ws_bytes, s); }
+int launch_readout_bwd_parts(const ReadoutArgs& a, void* ws, size_t ws_bytes, int parts, hipStream_t s) { return dispatch(a, true, ws, ws_bytes, s, parts); }

@@ -63,6 +63,7 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_resize_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "v1t_gaussian2d_backward_ws_bytes": (c_ll, [c_int, c_int, c_int, c_int]),
     "v1t_gaussian2d_backward_ws": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
+    "v1t_gaussian2d_backward_parts": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     "v1t_readout_grid_forward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 11),
     "v1t_readout_grid_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 17),
     "v1t_normal_fill": (c_int, [c_void_p, c_ll, c_u64, c_u32, c_void_p]),

@@ -183,6 +183,8 @@ class _NativeStep:
         self.zeros = torch.zeros(nz, **f32)
         self.tails = []
         zo = len(units)
+        self._dz_events = None
+        self.mice_stepped = False
         C_, gh, gw = core.output_shape
         for i, (m, n) in enumerate(self.sig):
             ro = model.readouts[m]
@@ -234,6 +236,14 @@ class _NativeStep:
         self.generation = gen
 
     def run(self, trainer: "Trainer", units) -> torch.Tensor:
+        """One step's forward + backward. Stream plan (kernel trace of round 2: the per-mouse tails were a 0.8 ms hole between the
+        core's forward and backward - chains of ~11 small dependent kernels, four chains at a time (hardware queues)):
+          side stream of mouse m, BEFORE the core forward is enqueued: everything that does not need the core's output - shifter
+              forward, position noise, sample positions, and the counting sort of the taps the dz gather reads;
+          main: resize / concat -> v1t_vit_forward;
+          side stream, behind the forward: readout forward -> ELU1 + Poisson -> dz gather -> [event: dz of mouse m complete] ->
+              parameter gradients of the readout, sample positions and shifter -> (single-GPU: this mouse's AdamW);
+          main: waits for the seven dz events only -> v1t_vit_backward -> ... The rest of the tails overlaps the core backward."""
         model = trainer.model
         core, crop = model.core, model.image_cropper
         lib = L.load()
@@ -241,8 +251,47 @@ class _NativeStep:
         C_, gh, gw, T, DP = self.geom
         main = torch.cuda.current_stream()
         st = main.cuda_stream
-        self.zeros.zero_()
+        streams = None
+        if model.readout_streams and len(units) > 1:
+            # V1T_TAIL_STREAMS side streams, the mice dealt over them round-robin (default 3: with the main stream that is the four
+            # hardware queues HIP multiplexes streams onto - a fifth stream would share the main stream's in-order queue)
+            pool = model._side_streams(max(1, min(len(units), trainer.tail_streams)))
+            streams = [pool[i % len(pool)] for i in range(len(units))]
+        if self._dz_events is None:
+            self._dz_events = [torch.cuda.Event() for _ in units]
+        # the shared buffers of this step (previous step's readers are behind us on this stream or were awaited at its end)
+        self.zeros.zero_()  # per-unit loss scalars, d shift accumulators
         self.gout.zero_()
+        start = torch.cuda.Event()
+        start.record(main)
+        trainer._eps_state = (trainer._eps_state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        side = lambda i: (torch.cuda.stream(streams[i]) if streams else contextlib.nullcontext())  # noqa: E731
+        # ---- per mouse, core-independent part
+        pups, ys = [], []
+        for i, ((m, b, full), t_) in enumerate(zip(units, self.tails)):
+            n, N, ro = t_["n"], t_["N"], t_["ro"]
+            pup = b["pupil_center"].to(torch.float32).contiguous()
+            pups.append(pup)
+            ys.append(b["response"].to(torch.float32).contiguous())
+            if streams:
+                streams[i].wait_event(start)  # parameters of the previous optimizer step, inputs
+            with side(i):
+                s_ = torch.cuda.current_stream().cuda_stream
+                if t_["shift"] is not None:
+                    L.check(lib.v1t_core_shifter_forward(n, pup.data_ptr(), *t_["sp"], t_["shift"].data_ptr(), s_), "core_shifter_forward")
+                ov = trainer.eps_override.get(m) if trainer.eps_override else None
+                if ov is not None:
+                    t_["eps"].copy_(ov.reshape(n, N, 2))
+                else:
+                    L.check(lib.v1t_normal_fill(t_["eps"].data_ptr(), n * N * 2, trainer._eps_state, ((1 + trainer.mouse_ids.index(m)) << 16) | (trainer.sharding.rank & 0xFFFF), s_),
+                            "normal_fill")
+                if t_["mu"] is not None:
+                    with torch.no_grad():
+                        ro._mu.clamp_(min=-1, max=1)  # gaussian2d.py:212-215 (acts on the free parameter only)
+                L.check(lib.v1t_readout_grid_forward(n, N, t_["gd"], t_["src"], *t_["gp"], t_["mu"], t_["sigma"], t_["eps"].data_ptr(), L.ptr(t_["shift"]),
+                                                     t_["grid"].data_ptr(), s_), "readout_grid_forward")
+                L.check(lib.v1t_gaussian2d_backward_parts(None, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), None, t_["FS"], None, None, T * DP, DP,
+                                                          None, None, None, t_["rws"].data_ptr(), t_["rws"].numel(), 1, s_), "gaussian2d_sort")
         # ---- inputs straight into the shared batch buffers
         off = 0
         for (m, b, _), (_, n) in zip(units, self.sig):
@@ -265,49 +314,33 @@ class _NativeStep:
         L.check(lib.v1t_vit_forward(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), self.img.data_ptr(), L.ptr(self.beh), 0, self.B,
                                     self.ws.data_ptr(), self.ws_bytes, 1, 1, seed, None, self.tokens.data_ptr(), st), "vit_forward")
         core._last_ws = (self.ws, self.B, True)
-        # ---- per-mouse tails (shifter, sample positions, readout, loss and all their backward) on side streams
-        streams = model._side_streams(len(units)) if (model.readout_streams and len(units) > 1) else None
-        trainer._eps_state = (trainer._eps_state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        fwd_done = torch.cuda.Event()
+        fwd_done.record(main)
+        # ---- per mouse, behind the core: readout, loss, dz (-> event), then the parameter gradients (and this mouse's optimizer)
+        own_opt = trainer.sharding.world == 1 and streams is not None
         off = 0
         for i, ((m, b, full), t_) in enumerate(zip(units, self.tails)):
-            n, N, ro = t_["n"], t_["N"], t_["ro"]
+            n, N = t_["n"], t_["N"]
             if streams:
-                streams[i].wait_stream(main)
-            with (torch.cuda.stream(streams[i]) if streams else contextlib.nullcontext()):
+                streams[i].wait_event(fwd_done)
+            with side(i):
                 s_ = torch.cuda.current_stream().cuda_stream
-                pup = b["pupil_center"].to(torch.float32).contiguous()
-                y = b["response"].to(torch.float32).contiguous()
-                if t_["shift"] is not None:
-                    L.check(lib.v1t_core_shifter_forward(n, pup.data_ptr(), *t_["sp"], t_["shift"].data_ptr(), s_), "core_shifter_forward")
-                ov = trainer.eps_override.get(m) if trainer.eps_override else None
-                if ov is not None:
-                    t_["eps"].copy_(ov.reshape(n, N, 2))
-                else:
-                    L.check(lib.v1t_normal_fill(t_["eps"].data_ptr(), n * N * 2, trainer._eps_state, ((1 + trainer.mouse_ids.index(m)) << 16) | (trainer.sharding.rank & 0xFFFF), s_),
-                            "normal_fill")
-                if t_["mu"] is not None:
-                    with torch.no_grad():
-                        ro._mu.clamp_(min=-1, max=1)  # gaussian2d.py:212-215 (acts on the free parameter only)
-                L.check(lib.v1t_readout_grid_forward(n, N, t_["gd"], t_["src"], *t_["gp"], t_["mu"], t_["sigma"], t_["eps"].data_ptr(), L.ptr(t_["shift"]),
-                                                     t_["grid"].data_ptr(), s_), "readout_grid_forward")
                 zptr = self.tokens.data_ptr() + 4 * (off * T * DP + DP)  # this unit's images, CLS row skipped
                 gptr = self.gout.data_ptr() + 4 * (off * T * DP + DP)
                 L.check(lib.v1t_gaussian2d_forward(zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["bias"], t_["u"].data_ptr(), s_),
                         "gaussian2d_forward")
                 scale = math.sqrt(trainer.ds_sizes[m] / full)
-                L.check(lib.v1t_elu1_poisson(t_["u"].data_ptr(), y.data_ptr(), n * N, scale, 1.0, t_["yhat"].data_ptr(), t_["du"].data_ptr(), t_["loss"].data_ptr(), s_),
+                L.check(lib.v1t_elu1_poisson(t_["u"].data_ptr(), ys[i].data_ptr(), n * N, scale, 1.0, t_["yhat"].data_ptr(), t_["du"].data_ptr(), t_["loss"].data_ptr(), s_),
                         "elu1_poisson")
-                L.check(lib.v1t_gaussian2d_backward_ws(zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["du"].data_ptr(), gptr, T * DP, DP,
-                                                       t_["dgrid"].data_ptr(), t_["dfeat"], t_["dbias"], t_["rws"].data_ptr(), t_["rws"].numel(), s_), "gaussian2d_backward")
-                L.check(lib.v1t_readout_grid_backward_ws(n, N, t_["gd"], t_["src"], *t_["gp"], t_["mu"], t_["sigma"], t_["eps"].data_ptr(), t_["dgrid"].data_ptr(),
-                                                         *t_["dgp"], t_["dmu"], t_["dsigma"], t_["dshift"].data_ptr() if t_["shift"] is not None else None,
-                                                         t_["gws"].data_ptr(), t_["gws"].numel(), s_), "readout_grid_backward")
-                if t_["shift"] is not None:
-                    L.check(lib.v1t_core_shifter_backward(n, pup.data_ptr(), *t_["sp"], t_["dshift"].data_ptr(), *t_["dsp"], s_), "core_shifter_backward")
+                bw = lambda parts: L.check(lib.v1t_gaussian2d_backward_parts(  # noqa: E731
+                    zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["du"].data_ptr(), gptr, T * DP, DP, t_["dgrid"].data_ptr(),
+                    t_["dfeat"], t_["dbias"], t_["rws"].data_ptr(), t_["rws"].numel(), parts, s_), "gaussian2d_backward")
+                bw(4)  # dz of this mouse's images, from the taps sorted before the forward
+                self._dz_events[i].record(torch.cuda.current_stream())
             off += n
         if streams:
-            for s_i in streams:
-                main.wait_stream(s_i)
+            for ev in self._dz_events:
+                main.wait_event(ev)
         # ---- shared core backward (gradients accumulate into the core arena; per-block events for the data-parallel exchange)
         core._arena.attach_grads()
         evs = core._block_events
@@ -315,6 +348,31 @@ class _NativeStep:
         L.check(lib.v1t_vit_backward_events(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), self.img.data_ptr(), L.ptr(self.beh), 0, self.B,
                                             self.ws.data_ptr(), self.scratch.data_ptr(), self.sb, 1, seed, None, self.gout.data_ptr(), core._arena.grad.data_ptr(),
                                             ev_arr, st), "vit_backward")
+        # second pass over the mice: what the core's backward does not wait for. Issued AFTER every mouse's dz chain and after
+        # the core's backward (V1T_TAIL_ORDER=0: before it) because the streams share four in-order hardware queues: work enqueued
+        # earlier would sit in front of another mouse's dz chain, or of the backward itself
+        off = 0
+        for i, ((m, b, full), t_) in enumerate(zip(units, self.tails)):
+            n, N = t_["n"], t_["N"]
+            with side(i):
+                s_ = torch.cuda.current_stream().cuda_stream
+                zptr = self.tokens.data_ptr() + 4 * (off * T * DP + DP)
+                gptr = self.gout.data_ptr() + 4 * (off * T * DP + DP)
+                L.check(lib.v1t_gaussian2d_backward_parts(zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["du"].data_ptr(), gptr, T * DP, DP,
+                                                          t_["dgrid"].data_ptr(), t_["dfeat"], t_["dbias"], t_["rws"].data_ptr(), t_["rws"].numel(), 2, s_),
+                        "gaussian2d_backward")  # d grid, d features, d bias
+                L.check(lib.v1t_readout_grid_backward_ws(n, N, t_["gd"], t_["src"], *t_["gp"], t_["mu"], t_["sigma"], t_["eps"].data_ptr(), t_["dgrid"].data_ptr(),
+                                                         *t_["dgp"], t_["dmu"], t_["dsigma"], t_["dshift"].data_ptr() if t_["shift"] is not None else None,
+                                                         t_["gws"].data_ptr(), t_["gws"].numel(), s_), "readout_grid_backward")
+                if t_["shift"] is not None:
+                    L.check(lib.v1t_core_shifter_backward(n, pups[i].data_ptr(), *t_["sp"], t_["dshift"].data_ptr(), *t_["dsp"], s_), "core_shifter_backward")
+                if own_opt:
+                    trainer.step_mouse(m)  # this mouse's arena is complete: its AdamW runs here, beside the core's backward
+            off += n
+        if streams:
+            for s_i in dict.fromkeys(streams):
+                main.wait_stream(s_i)  # the tails' parameter gradients (and optimizer steps); long done by now
+        self.mice_stepped = own_opt
         return self.zeros[:len(units)]
 
 
@@ -344,6 +402,7 @@ class Trainer:
             model.core.fold_rank(self.sharding.rank)
         # V1T_NATIVE_STEP=0 (dev): forward / backward through the nn.Module + autograd path instead of the direct C-ABI sequence
         self.native = os.environ.get("V1T_NATIVE_STEP", "1") != "0"
+        self.tail_streams = int(os.environ.get("V1T_TAIL_STREAMS", "3"))
         self._native_cache: t.Dict[t.Any, t.Optional[_NativeStep]] = {}
         self._eps_state = (int(getattr(args, "seed", 1234)) * 2654435761 + 97) & 0xFFFFFFFFFFFFFFFF
         self.eps_override: t.Optional[t.Dict[str, torch.Tensor]] = None  # tests: mouse -> (n, N, 2) position noise to replay
@@ -421,13 +480,18 @@ class Trainer:
                 self._core_l1 = float(core.reg_scale) * len(self.mouse_ids)
             self.opt.step_arena(ca, [(0, ca.param_floats, self._core_l1, self.opt.group_lr("core"))])
             core.mark_updated()
-        for mouse_id in self.sharding.local_mice():
-            a = model.mouse_arena(mouse_id)
-            # one launch per (L1 coefficient, optimizer group) run: readouts / image_cropper / core_shifter keep their own lr
-            self.opt.step_arena(a, [(o, n, c, self.opt.group_lr(g)) for o, n, c, g in model.mouse_step_ranges(mouse_id)])
+        if not (native is not None and native.mice_stepped):  # (the native single-GPU step ran them on the mice's own streams)
+            for mouse_id in self.sharding.local_mice():
+                self.step_mouse(mouse_id)
         if native is not None:
             return {"loss": losses[0].sum()}
         return {"loss": torch.stack(losses).sum() if losses else torch.zeros((), device=core._arena.data.device)}
+
+    def step_mouse(self, mouse_id: str) -> None:
+        """AdamW (+ L1) over one mouse's arena on the CURRENT stream: one launch per (L1 coefficient, optimizer group) run -
+        readouts / image_cropper / core_shifter keep their own learning rates."""
+        a = self.model.mouse_arena(mouse_id)
+        self.opt.step_arena(a, [(o, n, c, self.opt.group_lr(g)) for o, n, c, g in self.model.mouse_step_ranges(mouse_id)])
 
     @torch.no_grad()
     def predict(self, batch: t.Dict[str, torch.Tensor], mouse_id: str) -> torch.Tensor:
