@@ -161,7 +161,11 @@ struct TileDma {
     }
     // img: element (row 0, col 0) of this (image, head) slice; t0: first row of the tile; lds: tile base (LDS_ELEMS elements)
     DEVFN void issue(const bf16_t* img, int t0, int T, bf16_t* lds) const {
-        const char* base = (const char*)(img + (size_t)t0 * ld) - BIAS;
+        // (wave-uniform by construction; the explicit readfirstlanes keep the "s" asm operands in SGPRs where hipcc's uniformity
+        // analysis gives up - a tile index that comes out of a loop rotated per wave half)
+        const unsigned long long bb = (unsigned long long)(uintptr_t)((const char*)(img + (size_t)t0 * ld) - BIAS);
+        const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)), b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bb);
+        const char* base = (const char*)(uintptr_t)(((unsigned long long)b_hi << 32) | (unsigned long long)b_lo);
         const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds);
         const bool ragged = t0 + ROWS > T;  // wave-uniform
         unsigned v[PW];
@@ -176,7 +180,7 @@ struct TileDma {
         for (int g = 0; g < NG; ++g) {
             const int n0 = wave * PW + 4 * g;                       // wave-uniform
             const int cnt = min(min(4, PW - 4 * g), NINST - n0);    // pieces of this group that exist
-            const unsigned m0v = l0 + 1024u * (unsigned)n0;
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(l0 + 1024u * (unsigned)n0);
             auto at = [&](int k) { return v[4 * g + k < PW ? 4 * g + k : PW - 1]; };
             if (cnt >= 4) group<4>(base, m0v, at(0), at(1), at(2), at(3));
             else if (cnt == 3) group<3>(base, m0v, at(0), at(1), at(2), 0);
@@ -293,7 +297,7 @@ DEVFN void decode_block(const AttnArgs& a, int bid, int nblk, int& rb, int& h, i
 
 // ------------------------------------------------------------------------------------------
 constexpr int FWD_WAVES = 8;  // 256 queries per workgroup share each K/V tile: half the LDS-DMA pieces per wave of a 4-wave workgroup
-template <int DP, bool DROP, bool DIAG>
+template <int DP, bool DROP, bool DIAG, bool STAGGER = false>
 __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a) {
     using G = Geo<DP>;
     // K/V are staged 64 keys at a time (one barrier and one burst of LDS-DMA pieces per 64 keys) and consumed as two
@@ -341,17 +345,22 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     const int voff = tr_lane_off(lane, G::TSTR);
     const int nt = (a.T + 31) / 32;
 
+    // A wave whose 32 queries all lie beyond T (T = 1654: waves 4-7 of every (image, head)'s 7th workgroup) only stages its share of
+    // K / V and keeps the barriers: its SIMD partner then has the matrix pipe and the issue port to itself, the ragged workgroup
+    // finishes in ~2/3 of the time and the grid (12.25 rounds of equal workgroups = 13) desynchronises into ~12.
+    const bool dead_wave = rb * (32 * FWD_WAVES) + 32 * wave >= a.T;  // wave-uniform
     KP_DECL;
-    auto tile = [&](auto tail_tag, int kt, int buf, bool issue_next) {
+    // A 32-key tile in two parts. part_a: S^T = K Q^T (all K fragments in flight, then the chain) and the transposed V fragments,
+    // issued behind the chain's MFMAs so that they land while the softmax runs; everything it reads from LDS is in registers when
+    // it returns. part_b: softmax, dropout, O^T += V^T P^T from those registers (no LDS access), and - for one part_b per stage -
+    // the LDS-DMA of stage `next_stage` (-1: none) in its VALU-only stretch.
+    auto part_a = [&](auto tail_tag, int kt, int buf, f32x16& s, bf16x8 (&vfr)[2 * G::DB]) __attribute__((always_inline)) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         KP_STAMP(0);
-        f32x16 s;
         zero16(s);
         const bf16_t* kp = &sK[buf][32 * (kt & 1) * G::RSTR + koff];
         const bf16_t* vp = &sV[buf][32 * (kt & 1) * G::TSTR + voff];
-        // all K fragments in flight, then the S chain; the V fragments (transposed reads) are issued right
-        // behind it so they land while the softmax runs on the VALU
-        bf16x8 kfr[G::KS], vfr[2 * G::DB];
+        bf16x8 kfr[G::KS];
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) kfr[ks] = *(const bf16x8*)(kp + 16 * ks);
 #pragma unroll
@@ -381,6 +390,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
                 s[r] = dead ? NEG_BIG : s[r];
             }
         }
+    };
+    auto part_b = [&](int kt, int next_stage, f32x16& s, const bf16x8 (&vfr)[2 * G::DB]) __attribute__((always_inline)) {
         mfma_result_fence();
         float pmax = vmax3(s[0], s[1], s[2]);
 #pragma unroll
@@ -398,11 +409,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
             m2 = mn;
         }
         const float negm = -m2;
-        // next tile's LDS-DMA is issued HERE, in the VALU-only stretch: a piece costs its wave 100-185 cycles of
+        // the next stage's LDS-DMA is issued HERE, in the VALU-only stretch: a piece costs its wave 100-185 cycles of
         // issue while ds_reads are in flight (tile start) but 25-60 when the LDS is quiet (kprof timeline)
-        if (issue_next) {  // wave-uniform: first tile of a stage that has a successor
-            dmaK.issue(kbase, 32 * (kt + 2), a.T, sK[buf ^ 1]);
-            dmaV.issue(vbase, 32 * (kt + 2), a.T, sV[buf ^ 1]);
+        if (next_stage >= 0) {  // wave-uniform
+            dmaK.issue(kbase, 64 * next_stage, a.T, sK[next_stage & 1]);
+            dmaV.issue(vbase, 64 * next_stage, a.T, sV[next_stage & 1]);
         }
         KP_STAMP(3);
 #pragma unroll
@@ -430,20 +441,55 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
         KP_FLUSH(kt, wave, lane);
 #endif
     };
+    auto tile = [&](auto tail_tag, int kt, int buf, int next_stage) __attribute__((always_inline)) {
+        f32x16 s;
+        bf16x8 vfr[2 * G::DB];
+        part_a(tail_tag, kt, buf, s, vfr);
+        part_b(kt, next_stage, s, vfr);
+    };
 
     touch(qf);
     touch(c);
     dma_wait_and_barrier();
     const int ns = (nt + 1) / 2;  // 64-key stages
-    for (int st = 0; st < ns - 1; ++st) {
-        const int buf = st & 1;
-        tile(std::false_type{}, 2 * st, buf, true);
-        tile(std::false_type{}, 2 * st + 1, buf, false);
-        dma_wait_and_barrier();
-        KP_STAMP(7);
+    if (dead_wave) {  // its own loop (a branch inside the tile costs the live path 55 spilled registers): same stages, same barriers
+        for (int st = 0; st < ns - 1; ++st) {
+            dmaK.issue(kbase, 64 * (st + 1), a.T, sK[(st & 1) ^ 1]);
+            dmaV.issue(vbase, 64 * (st + 1), a.T, sV[(st & 1) ^ 1]);
+            dma_wait_and_barrier();
+        }
+        return;
     }
-    tile(std::true_type{}, 2 * (ns - 1), (ns - 1) & 1, false);
-    if (2 * (ns - 1) + 1 < nt) tile(std::true_type{}, 2 * (ns - 1) + 1, (ns - 1) & 1, false);
+    if (STAGGER && wave >= FWD_WAVES / 2 && ns > 1) {
+        // The SIMD partners (waves w and w + 4) run the same program between the same barriers: left alone they do their MFMA chains
+        // at the same time and their softmax at the same time, so the matrix pipe idles while both are in the VALU stretch. The
+        // second-dispatched half therefore runs its stages ROTATED: the barrier falls behind part_a of the stage's second tile
+        // (every LDS read of the stage done, S and the V fragments in registers), part_b of that tile runs after the barrier.
+        // Same work per stage, same barriers, same two buffers - only the phase differs, by the length of a softmax + P.V.
+        f32x16 sc;
+        bf16x8 vc[2 * G::DB];
+        tile(std::false_type{}, 0, 0, 1);
+        part_a(std::false_type{}, 1, 0, sc, vc);
+        dma_wait_and_barrier();
+        for (int st = 1; st < ns - 1; ++st) {
+            const int buf = st & 1;
+            part_b(2 * st - 1, st + 1, sc, vc);
+            tile(std::false_type{}, 2 * st, buf, -1);
+            part_a(std::false_type{}, 2 * st + 1, buf, sc, vc);
+            dma_wait_and_barrier();
+        }
+        part_b(2 * (ns - 1) - 1, -1, sc, vc);
+    } else {
+        for (int st = 0; st < ns - 1; ++st) {
+            const int buf = st & 1;
+            tile(std::false_type{}, 2 * st, buf, st + 1);
+            tile(std::false_type{}, 2 * st + 1, buf, -1);
+            dma_wait_and_barrier();
+            KP_STAMP(7);
+        }
+    }
+    tile(std::true_type{}, 2 * (ns - 1), (ns - 1) & 1, -1);
+    if (2 * (ns - 1) + 1 < nt) tile(std::true_type{}, 2 * (ns - 1) + 1, (ns - 1) & 1, -1);
 
     const float ltot = lsum + __shfl_xor(lsum, 32);
     const float inv = (DROP ? a.adrop.inv_keep : 1.0f) / ltot;
@@ -1179,6 +1225,14 @@ int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
     if constexpr (DP >= 128 && !DIAG) {
         if (v2) {
             hipLaunchKernelGGL((attn_fwd2_kernel<DP, DROP>), grid, dim3(64 * FWD_WAVES), 0, s, a);
+            prof_end(PROF_ATTN_FWD, s);
+            return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+        }
+    }
+    static const bool stagger = std::getenv("V1T_ATTN_FWD_STAGGER") != nullptr;  // dev: A/B of the rotated second half
+    if constexpr (DP >= 128 && !DIAG) {
+        if (stagger) {
+            hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG, true>), grid, dim3(64 * FWD_WAVES), 0, s, a);
             prof_end(PROF_ATTN_FWD, s);
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
