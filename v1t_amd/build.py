@@ -42,9 +42,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     hipcc = _hipcc()
     objs, jobs = [], []
+    # dev: V1T_BUILD_LIB=libv1t_amd_x.so builds a second library next to the product one (its own objects; V1T_HIPCC_EXTRA flags),
+    # loaded with V1T_LIB=libv1t_amd_x.so - A/B experiments and the in-kernel probe builds
+    alt = os.environ.get("V1T_BUILD_LIB", "")
+    lib_path = os.path.join(LIBDIR, alt) if alt else LIB
+    objdir = os.path.join(LIBDIR, alt + ".objs") if alt else LIBDIR
+    os.makedirs(objdir, exist_ok=True)
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [sp] + hdrs):
             jobs.append([hipcc, *FLAGS, *PER_FILE.get(src, []), *EXTRA, "-c", sp, "-o", obj])
@@ -60,9 +66,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if jobs or force or _stale(lib_path, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs])
+    return lib_path
 
 
 if __name__ == "__main__":

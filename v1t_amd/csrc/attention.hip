@@ -436,8 +436,6 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
         }
 #ifdef V1T_KPROF
         KP_STAMP(5);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        KP_STAMP(6);
         KP_FLUSH(kt, wave, lane);
 #endif
     };
