@@ -40,6 +40,13 @@ typedef struct v1t_vit_config {
     int use_lsa, use_bias;            /* vit.py:235-251; --disable_bias => use_bias = 0 */
     float p_dropout, t_dropout;       /* vit.py:390,398 */
     float ln_eps;                     /* nn.LayerNorm default 1e-5 */
+    /* core_kind 1 = the CCT core (core/cct.py:247-317) on the same plan: conv tokenizer Conv2d(k = patch_size, stride, padding =
+     * conv_pad, no bias) -> ReLU -> MaxPool2d(3, 2, 1) -> tokens (no class token) + fixed position table (pos_mode 1: the "sine"
+     * buffer, cct.py:17-27; 0: none) -> dropout (cct.py:30-104); attention with qkv width 3 * emb_dim / num_heads and head dim
+     * emb_dim / num_heads^2 (cct.py:107-143; the scale buffer holds (emb_dim / num_heads)^-0.5); biases always on; state-dict
+     * names of cct.py ("tokenizer.conv2d.weight", "transformer.blocks.<k>.mha.qkv.weight", "...mlp.1.weight", "...b_mlp...").
+     * patch_mode / use_lsa / use_bias are ignored. 0 = the ViT core above. */
+    int core_kind, conv_pad, pos_mode;
 } v1t_vit_config;
 
 typedef struct v1t_vit v1t_vit;       /* opaque plan: dims, arena/shadow/workspace layout, pack table */
@@ -57,9 +64,10 @@ long long v1t_vit_param_floats(const v1t_vit* h);
 int v1t_vit_num_tensors(const v1t_vit* h);
 int v1t_vit_tensor_info(const v1t_vit* h, int idx, char* name, int name_cap, long long* offset,
                         int* ndim, long long* shape4, int* is_param);
-int v1t_vit_tokens(const v1t_vit* h);      /* T = patches + 1 */
+int v1t_vit_tokens(const v1t_vit* h);      /* T = patches + class tokens */
+int v1t_vit_cls_tokens(const v1t_vit* h);  /* 1 (ViT: token 0 is the class token) or 0 (CCT) */
 int v1t_vit_padded_dim(const v1t_vit* h);  /* DP: row stride of the token-major output */
-int v1t_vit_grid_h(const v1t_vit* h);      /* latent (h, w) = find_shape(T-1), vit.py:411-417 */
+int v1t_vit_grid_h(const v1t_vit* h);      /* latent (h, w) = find_shape(patches), vit.py:411-417 / cct.py:293-299 */
 int v1t_vit_grid_w(const v1t_vit* h);
 
 long long v1t_vit_shadow_bytes(const v1t_vit* h);                 /* bf16 padded/transposed weight shadow */

@@ -99,7 +99,7 @@ class FakeDS:
 
 def ref_args(cfg: O.Config, ds_name="sensorium"):
     return SimpleNamespace(
-        core="vit", readout="gaussian2d", behavior_mode=cfg.behavior_mode, shift_mode=cfg.shift_mode,
+        core=cfg.core, pos_emb=cfg.pos_emb, readout="gaussian2d", behavior_mode=cfg.behavior_mode, shift_mode=cfg.shift_mode,
         center_crop=cfg.center_crop, resize_image=0, ds_name=ds_name, patch_size=cfg.patch_size, patch_mode=cfg.patch_mode,
         patch_stride=cfg.patch_stride, num_blocks=cfg.num_blocks, num_heads=cfg.num_heads, emb_dim=cfg.emb_dim,
         mlp_dim=cfg.mlp_dim, p_dropout=cfg.p_dropout, t_dropout=cfg.t_dropout, drop_path=cfg.drop_path, use_lsa=cfg.use_lsa,
@@ -155,7 +155,8 @@ def ref_forward_backward(model, cfg, batch, mouse_id, ds_size, train_eps_seed=No
     taps = {}
     hooks = []
     core = model.core
-    hooks.append(core.patch_embedding.register_forward_hook(lambda m, i, o: taps.__setitem__("patch_embed", o.detach().clone())))
+    tokenizer = core.tokenizer if cfg.core == "cct" else core.patch_embedding
+    hooks.append(tokenizer.register_forward_hook(lambda m, i, o: taps.__setitem__("patch_embed", o.detach().clone())))
     if train_eps_seed is not None:
         torch.manual_seed(train_eps_seed)
     y, _, _ = model(inputs=batch["image"], mouse_id=mouse_id, behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
@@ -174,8 +175,9 @@ def ref_core_taps(model, batch, mouse_id):
     taps = {}
     hs = []
     for k, blk in enumerate(model.core.transformer.blocks):
-        hs.append(blk["mha"].register_forward_hook(lambda m, i, o, k=k: taps.__setitem__(f"mha{k}", (o + i[0]).detach().clone())))
-        hs.append(blk["mlp"].register_forward_hook(lambda m, i, o, k=k: taps.__setitem__(f"mlp{k}", (o + i[0]).detach().clone())))
+        mha, mlp = (blk.mha, blk.mlp) if hasattr(blk, "mha") else (blk["mha"], blk["mlp"])  # cct.py's block is a Module, vit.py's a ModuleDict
+        hs.append(mha.register_forward_hook(lambda m, i, o, k=k: taps.__setitem__(f"mha{k}", (o + i[0]).detach().clone())))
+        hs.append(mlp.register_forward_hook(lambda m, i, o, k=k: taps.__setitem__(f"mlp{k}", (o + i[0]).detach().clone())))
     with torch.no_grad():
         z = model.core(inputs=batch["image"], mouse_id=mouse_id, behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
     for h in hs:
@@ -682,6 +684,19 @@ def main():
     gen_image_shift(d)
     save("g8_image_shift.npz", d)
     if "--only-g8" in sys.argv:
+        return
+
+    d = {}
+    print("G13 CCT core (core/cct.py) at the reference's default CCT arguments, mouse A x 500 neurons, B=2, eval; + a 2-block variant without behaviour")
+    gen_train_fixture("g13", W.config_cct(), 2, 1234, d)
+    c13 = W.config_cct({"A": 200})
+    c13.num_blocks, c13.behavior_mode, c13.pos_emb, c13.emb_dim, c13.mlp_dim, c13.num_heads = 2, 0, "none", 64, 128, 2
+    gen_train_fixture("g13b", c13, 2, 77, d)
+    c13 = W.config_cct({"A": 200, "B": 123})
+    c13.num_blocks, c13.behavior_mode, c13.emb_dim, c13.mlp_dim, c13.mouse_ids, c13.input_shape = 1, 4, 144, 96, ("A", "B"), (2, 36, 64)
+    gen_train_fixture("g13c", c13, 2, 78, d)
+    save("g13_cct.npz", d)
+    if "--only-g13" in sys.argv:
         return
 
     d = {}

@@ -65,10 +65,16 @@ class Config:
     bias_mode: int = 0
     mouse_ids: t.Tuple[str, ...] = ("A",)
     num_neurons: t.Dict[str, int] = field(default_factory=lambda: {"A": 256})
+    core: str = "vit"      # "vit" (core/vit.py) or "cct" (core/cct.py: conv tokenizer, no class token, head dim emb_dim / heads^2)
+    pos_emb: str = "sine"  # cct only (train.py:603-605): "sine" | "none"
 
     @property
     def grid_hw(self) -> t.Tuple[int, int]:
         c, h, w = self.input_shape
+        if self.core == "cct":  # Conv2d(kernel patch_size, stride, padding 3) then MaxPool2d(3, 2, 1): cct.py:46-56
+            ch = (h + 6 - self.patch_size) // self.patch_stride + 1
+            cw = (w + 6 - self.patch_size) // self.patch_stride + 1
+            return (ch + 2 - 3) // 2 + 1, (cw + 2 - 3) // 2 + 1
         nh = (h - self.patch_size) // self.patch_stride + 1
         nw = (w - self.patch_size) // self.patch_stride + 1
         return nh, nw
@@ -290,6 +296,84 @@ def vit_core(cfg: Config, sd: SD, x: Tensor, mouse_id: str, behaviors: Tensor, p
     return tok[:, 1:, :].reshape(b, h, w, d).permute(0, 3, 1, 2)
 
 
+# --------------------------------------------------------------------------------------
+# CCT core (core/cct.py)
+# --------------------------------------------------------------------------------------
+def cct_tokenizer(cfg: Config, sd: SD, x: Tensor, mask: t.Optional[Tensor] = None, pfx: str = "core.") -> Tensor:
+    """Tokenizer.forward cct.py:87-103: conv (no bias, padding 3) -> ReLU -> MaxPool2d(3, 2, 1) -> `b c h w -> b (h w) c`
+    -> + pos_embedding (a buffer for "sine") -> Dropout(p_dropout)."""
+    y = torch.nn.functional.conv2d(x, sd[pfx + "tokenizer.conv2d.weight"], None, stride=cfg.patch_stride, padding=3)
+    y = torch.nn.functional.max_pool2d(torch.relu(y), kernel_size=3, stride=2, padding=1)
+    b, d, h, w = y.shape
+    y = y.permute(0, 2, 3, 1).reshape(b, h * w, d)
+    if cfg.pos_emb != "none":
+        y = y + sd[pfx + "tokenizer.pos_embedding"].to(y.dtype)
+    return apply_mask(y, mask, cfg.p_dropout)
+
+
+def cct_attention(cfg: Config, sd: SD, k: int, x: Tensor, masks: t.Optional[t.Dict[str, Tensor]] = None, pfx: str = "core.") -> Tensor:
+    """Attention.forward cct.py:128-143: inner = emb_dim // heads is the width of each of q, k, v; `b n (h d) -> b h n d` then cuts
+    it into `heads` heads of inner // heads columns; q * scale (the buffer inner^-0.5) before the product."""
+    p = f"{pfx}transformer.blocks.{k}.mha."
+    masks = masks or {}
+    b, n, _ = x.shape
+    h = cfg.num_heads
+    z = layer_norm(x, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])
+    q, kk, v = linear(z, sd[p + "qkv.weight"], None).chunk(3, dim=-1)
+    d = q.shape[-1] // h
+    q = q.reshape(b, n, h, d).permute(0, 2, 1, 3) * sd[p + "scale"]
+    kk = kk.reshape(b, n, h, d).permute(0, 2, 1, 3)
+    v = v.reshape(b, n, h, d).permute(0, 2, 1, 3)
+    attn = softmax_lastdim(q @ kk.transpose(-1, -2))
+    attn = apply_mask(attn, masks.get(f"attn{k}"), masks.get("attn_p", cfg.t_dropout))
+    o = (attn @ v).permute(0, 2, 1, 3).reshape(b, n, h * d)
+    o = linear(o, sd[p + "projection.0.weight"], sd.get(p + "projection.0.bias"))
+    return apply_mask(o, masks.get(f"proj{k}"), cfg.t_dropout)
+
+
+def cct_tokens(cfg: Config, sd: SD, x: Tensor, mouse_id: str, behaviors: Tensor, pupil_centers: Tensor,
+               masks: t.Optional[t.Dict[str, Tensor]] = None, taps: t.Optional[t.Dict[str, Tensor]] = None, pfx: str = "core.") -> Tensor:
+    """CCTCore.forward cct.py:305-316 + TransformerBlock.forward cct.py:189-197. DropPath: block k has its own rate
+    linspace(0, drop_path, blocks)[k] (cct.py:219); draws are passed as masks["drop_path"] like vit_tokens."""
+    masks = masks or {}
+    dpm = masks.get("drop_path") or {}
+    rates = [cfg.drop_path * k / max(cfg.num_blocks - 1, 1) for k in range(cfg.num_blocks)] if cfg.num_blocks > 1 else [0.0]
+
+    def drop_path(y: Tensor, key) -> Tensor:
+        m = dpm.get(key)
+        return y if m is None else (y / (1.0 - rates[key[0]])) * m.to(y.dtype)[:, None, None]
+
+    out = cct_tokenizer(cfg, sd, x, masks.get("patch"), pfx=pfx)
+    if taps is not None:
+        taps["patch_embed"] = out
+    v = torch.cat([behaviors, pupil_centers], dim=-1) if cfg.behavior_mode in (3, 4) else behaviors
+    for k in range(cfg.num_blocks):
+        if cfg.behavior_mode in (3, 4):
+            key = mouse_id if cfg.behavior_mode == 4 else "share"
+            p = f"{pfx}transformer.blocks.{k}.b_mlp.models.{key}."
+            hdn = torch.tanh(linear(v, sd[p + "0.weight"], sd.get(p + "0.bias")))
+            out = out + torch.tanh(linear(hdn, sd[p + "3.weight"], sd.get(p + "3.bias")))[:, None, :]
+        out = drop_path(cct_attention(cfg, sd, k, out, masks, pfx=pfx), (k, "mha")) + out
+        if taps is not None:
+            taps[f"mha{k}"] = out
+        p = f"{pfx}transformer.blocks.{k}.mlp."
+        z = layer_norm(out, sd[p + "0.weight"], sd[p + "0.bias"])
+        hdn = apply_mask(gelu_erf(linear(z, sd[p + "1.weight"], sd.get(p + "1.bias"))), masks.get(f"fc1{k}"), cfg.t_dropout)
+        y = apply_mask(linear(hdn, sd[p + "4.weight"], sd.get(p + "4.bias")), masks.get(f"fc2{k}"), cfg.t_dropout)
+        out = drop_path(y, (k, "mlp")) + out
+        if taps is not None:
+            taps[f"mlp{k}"] = out
+    return out
+
+
+def cct_core(cfg: Config, sd: SD, x: Tensor, mouse_id: str, behaviors: Tensor, pupil_centers: Tensor, **kw) -> Tensor:
+    """cct.py:316: every token, `b (h w) c -> b c h w`."""
+    tok = cct_tokens(cfg, sd, x, mouse_id, behaviors, pupil_centers, **kw)
+    h, w = cfg.latent_hw
+    b, _, d = tok.shape
+    return tok.reshape(b, h, w, d).permute(0, 3, 1, 2)
+
+
 def core_regularizer(cfg: Config, sd: SD, param_keys: t.Iterable[str]) -> Tensor:
     """ViTCore.regularizer vit.py:419-421: reg_scale * sum |p| over all core parameters."""
     return cfg.core_reg_scale * sum(sd[k].abs().sum() for k in param_keys)
@@ -495,7 +579,7 @@ def model_forward(
     taps: t.Optional[t.Dict[str, Tensor]] = None,
 ) -> Tensor:
     """x is the CORE input (post-cropper)."""
-    z = vit_core(cfg, sd, x, mouse_id, behaviors, pupil_centers, masks=masks, taps=taps)
+    z = (cct_core if cfg.core == "cct" else vit_core)(cfg, sd, x, mouse_id, behaviors, pupil_centers, masks=masks, taps=taps)
     if taps is not None:
         taps["core"] = z
     shifts = core_shifter(sd, mouse_id, pupil_centers) if cfg.shift_mode in (2, 3, 4) else None
@@ -512,7 +596,7 @@ def core_param_keys(sd: SD) -> t.List[str]:
         if not k.startswith("core."):
             continue
         leaf = k.rsplit(".", 1)[-1]
-        if leaf in ("reg_scale", "keep_prop", "mask", "max_value"):
+        if leaf in ("reg_scale", "keep_prop", "mask", "max_value") or k.endswith("tokenizer.pos_embedding"):
             continue
         if leaf == "scale" and sd[k].dim() == 0:
             continue

@@ -44,6 +44,47 @@ def source_grid_from(coords: np.ndarray, dim: int) -> np.ndarray:
     return (g / np.abs(g).max()).astype(np.float32)
 
 
+def _cct_core_state(cfg: Config, seed: int, put) -> None:
+    """Core entries of a CCT model (keys of core/cct.py): conv tokenizer, sine position buffer, blocks with qkv width
+    3 * (emb_dim // heads), per-block DropPath buffers."""
+    c, _, _ = cfg.input_shape
+    D, H, M, P = cfg.emb_dim, cfg.num_heads, cfg.mlp_dim, cfg.patch_size
+    inner = D // H
+    L = cfg.num_patches
+    pd = c * P * P
+    put("core.tokenizer.conv2d.weight", _normal(seed, "core.tokenizer.w", (D, c, P, P), np.sqrt(2.0 / pd)))
+    if cfg.pos_emb == "sine":  # cct.py:17-27
+        pe = np.array([[p / (10000 ** (2 * (i // 2) / D)) for i in range(D)] for p in range(L)], dtype=np.float32)
+        pe[:, 0::2] = np.sin(pe[:, 0::2])
+        pe[:, 1::2] = np.cos(pe[:, 1::2])
+        put("core.tokenizer.pos_embedding", pe[None])
+    ws = 0.06
+    rates = np.linspace(0, cfg.drop_path, cfg.num_blocks)
+    for k in range(cfg.num_blocks):
+        b = f"core.transformer.blocks.{k}."
+        put(b + "mha.scale", np.float32(inner ** -0.5))
+        put(b + "mha.layer_norm.weight", 1.0 + _normal(seed, b + "ln1w", (D,), 0.1))
+        put(b + "mha.layer_norm.bias", _normal(seed, b + "ln1b", (D,), 0.1))
+        put(b + "mha.qkv.weight", _normal(seed, b + "qkv", (3 * inner, D), 2 * ws))
+        put(b + "mha.projection.0.weight", _normal(seed, b + "proj", (D, inner), 2 * ws))
+        put(b + "mha.projection.0.bias", _normal(seed, b + "projb", (D,), 0.05))
+        put(b + "mlp.0.weight", 1.0 + _normal(seed, b + "ln2w", (D,), 0.1))
+        put(b + "mlp.0.bias", _normal(seed, b + "ln2b", (D,), 0.1))
+        put(b + "mlp.1.weight", _normal(seed, b + "fc1", (M, D), ws))
+        put(b + "mlp.1.bias", _normal(seed, b + "fc1b", (M,), 0.05))
+        put(b + "mlp.4.weight", _normal(seed, b + "fc2", (D, M), ws))
+        put(b + "mlp.4.bias", _normal(seed, b + "fc2b", (D,), 0.05))
+        put(b + "drop_path.keep_prop", np.float32(1.0 - rates[k]))
+        if cfg.behavior_mode in (3, 4):
+            for key in (cfg.mouse_ids if cfg.behavior_mode == 4 else ("share",)):
+                m = f"{b}b_mlp.models.{key}."
+                put(m + "0.weight", _normal(seed, m + "w0", (D // 2, 5), 0.3))
+                put(m + "0.bias", _normal(seed, m + "b0", (D // 2,), 0.05))
+                put(m + "3.weight", _normal(seed, m + "w3", (D, D // 2), 0.15))
+                put(m + "3.bias", _normal(seed, m + "b3", (D,), 0.05))
+    put("core.reg_scale", np.float32(cfg.core_reg_scale))
+
+
 def make_state_dict(cfg: Config, seed: int = 1234) -> t.Dict[str, torch.Tensor]:
     c, h, w = cfg.input_shape
     D, H, M, P = cfg.emb_dim, cfg.num_heads, cfg.mlp_dim, cfg.patch_size
@@ -52,6 +93,14 @@ def make_state_dict(cfg: Config, seed: int = 1234) -> t.Dict[str, torch.Tensor]:
 
     def put(k, v):
         sd[k] = np.asarray(v, dtype=np.float32)
+
+    if cfg.core == "cct":
+        _cct_core_state(cfg, seed, put)
+        return _finish_state_dict(cfg, seed, sd, put)
+    return _vit_state_dict(cfg, seed, sd, put, c, D, H, M, P, T)
+
+
+def _vit_state_dict(cfg, seed, sd, put, c, D, H, M, P, T):
 
     pe = "core.patch_embedding."
     put(pe + "cls_token", _normal(seed, pe + "cls", (1, 1, D), 1.0))
@@ -114,7 +163,12 @@ def make_state_dict(cfg: Config, seed: int = 1234) -> t.Dict[str, torch.Tensor]:
                     put(m + "3.bias", _normal(seed, m + "b3", (D,), 0.05))
     put("core.reg_scale", np.float32(cfg.core_reg_scale))
     put("core.transformer.drop_path.keep_prop", np.float32(1.0 - cfg.drop_path))
+    return _finish_state_dict(cfg, seed, sd, put)
 
+
+def _finish_state_dict(cfg, seed, sd, put):
+    """readouts / shifters (the same modules for every core), then numpy -> torch"""
+    D = cfg.emb_dim
     for mid in cfg.mouse_ids:
         n = cfg.num_neurons[mid]
         r = f"readouts.{mid}."
@@ -188,6 +242,12 @@ def config_c2(neurons: t.Optional[t.Dict[str, int]] = None) -> Config:
 
 
 RAGGED_NEURONS = {"A": 7776, "B": 7939, "C": 8202, "D": 7440, "E": 7928, "F": 8107, "G": 8372}
+
+
+def config_cct(neurons: t.Optional[t.Dict[str, int]] = None) -> Config:
+    """The reference's default CCT arguments (train.py:591-612): 4 blocks, emb_dim 160, 4 heads (qkv width 3 x 40, head dim 10),
+    MLP 488, patch 8 / stride 1, sine positions; 36 x 64 gray input -> 18 x 32 = 576 tokens."""
+    return Config(core="cct", emb_dim=160, num_neurons=neurons or {"A": 500})
 
 
 def config_c4() -> Config:

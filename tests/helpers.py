@@ -63,10 +63,10 @@ def build_native_model(cfg, sd, device, dropout=None):
         num_heads=cfg.num_heads, behavior_mode=cfg.behavior_mode, use_lsa=cfg.use_lsa, disable_bias=cfg.disable_bias,
         patch_mode=cfg.patch_mode, patch_stride=cfg.patch_stride, shift_mode=cfg.shift_mode,
         disable_grid_predictor=cfg.disable_grid_predictor, grid_predictor_dim=cfg.grid_predictor_dim,
-        p_dropout=cfg.p_dropout, t_dropout=cfg.t_dropout, drop_path=cfg.drop_path,
+        p_dropout=cfg.p_dropout, t_dropout=cfg.t_dropout, drop_path=cfg.drop_path, core=cfg.core, pos_emb=cfg.pos_emb,
     )
     args.output_shapes = {m: (cfg.num_neurons[m],) for m in cfg.mouse_ids}
     model = v1t_amd.Model(args, make_ds(cfg.num_neurons))
     r = model.load_state_dict(sd, strict=False)
-    assert not r.unexpected_keys and set(r.missing_keys) <= {"image_cropper.grid", "elu1.one"}, r
+    assert not r.unexpected_keys and set(r.missing_keys) <= {"image_cropper.grid", "elu1.one"}, r  # every key of the reference-shaped state dict has a home
     return model.to(device), args

@@ -625,3 +625,95 @@ def test_native_step_eps_statistics(dev):
     assert abs(float((a ** 3).mean())) < 1e-2 and abs(float((a ** 4).mean()) - 3) < 3e-2  # skewness 0, kurtosis 3
     assert abs(float((a[:-1] * a[1:]).mean())) < 3e-3 and abs(float((a * c).mean())) < 3e-3  # neighbours / streams uncorrelated
     assert float(a.abs().max()) < 6.5 and bool(torch.isfinite(a).all())
+
+
+def _cct_cfgs():
+    a = W.config_cct()
+    b = W.config_cct({"A": 200})
+    b.num_blocks, b.behavior_mode, b.pos_emb, b.emb_dim, b.mlp_dim, b.num_heads = 2, 0, "none", 64, 128, 2
+    c = W.config_cct({"A": 200, "B": 123})
+    c.num_blocks, c.behavior_mode, c.emb_dim, c.mlp_dim, c.mouse_ids, c.input_shape = 1, 4, 144, 96, ("A", "B"), (2, 36, 64)
+    return {"g13": (a, 1234), "g13b": (b, 77), "g13c": (c, 78)}
+
+
+@pytest.mark.parametrize("name", ["g13", "g13b", "g13c"])
+def test_cct_core_vs_reference_golden(golden, dev, name):
+    """G13: the CCT core (core/cct.py:247-317; conv tokenizer + ReLU + max pool, sine positions, qkv width 3 D / H and head
+    dim D / H^2, no class token) behind the same registry as the ViT core: predictions, loss, regulariser, the tokenizer tap and
+    every parameter gradient against the real reference - at its default CCT arguments (g13: 4 blocks, D = 160, 4 heads ->
+    head dim 10, 576 tokens), a 2-block model without behaviour / positions (g13b) and per-mouse BehaviorMLPs on a 2-channel
+    input with head dim 9 (g13c)."""
+    import v1t_amd
+    from v1t_amd.losses import elu1_poisson_loss
+
+    cfg, seed = _cct_cfgs()[name]
+    sd = W.make_state_dict(cfg, seed)
+    batch = W.make_batch(cfg, "A", 2, seed)
+    model, _ = build_native_model(cfg, sd, dev)
+    assert type(model.core) is v1t_amd.CCTCore and model.core.cls_tokens == 0
+    model.train(False)
+    with torch.no_grad():
+        y = _fwd(model, batch, "A", dev)
+    assert_close(f"{name}.y", y.cpu().numpy(), golden[f"{name}/y"], Y_RTOL, Y_ATOL)
+    u = _fwd(model, batch, "A", dev, activate=False)
+    core = model.core
+    B, T, DP, D = 2, core.num_tokens, core.padded_dim, cfg.emb_dim
+    x0 = core.workspace_tensor("x0")[:B * T * DP * 4].view(torch.float32).view(B, T, DP)
+    assert float(x0[:, :, D:].abs().max()) == 0.0 if DP > D else True
+    assert_close(f"{name}.tokenizer", sample(x0[:, :, :D]), golden[f"{name}/tap/patch_embed"], 1e-3, 4e-3)  # conv with fp16 operands (2^-11 per product, 64 products of O(1) terms), fp32 accumulate
+    loss, _ = elu1_poisson_loss(u, batch["response"].to(dev), 4500.0, 2)
+    reg = model.regularizer("A")
+    (loss + reg).backward()
+    assert abs(float(loss) - float(golden[f"{name}/loss"])) <= 1e-4 * abs(float(golden[f"{name}/loss"]))
+    assert abs(float(reg) - float(golden[f"{name}/reg"])) <= 1e-5 * abs(float(golden[f"{name}/reg"]))
+    n = 0
+    for k, p in model.named_parameters():
+        gk = f"{name}/grad/{k}"
+        if gk not in golden:
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        refg = golden[gk]
+        if float(np.abs(refg).max()) == 0.0:
+            assert float(g.abs().max()) == 0.0, k
+        else:
+            check_rel(f"{name}.grad.{k}", sample(g), refg, G_TOL)
+        nrm, rn = float(g.double().norm()), float(golden[f"{name}/gradnorm/{k}"])
+        record_margin(f"{name}.gradnorm.{k}", abs(nrm - rn), GN_TOL * rn + 1e-12)
+        assert abs(nrm - rn) <= GN_TOL * rn + 1e-12, k
+        n += 1
+    assert n >= 16 and f"{name}/grad/core.tokenizer.conv2d.weight" in golden
+
+
+def test_cct_training_step_and_unsupported(dev):
+    """The fused trainer over a CCT model (native step: same C-ABI sequence, class-token offset 0), dropout + DropPath rates
+    per block; attention rollout and `--pos_emb learn` raise like / instead of the reference's failures."""
+    import v1t_amd
+    from v1t_amd.rollout import rollout_rows
+    from v1t_amd.synthetic import default_args, make_batch, make_ds
+    from v1t_amd.trainer import Trainer
+
+    neurons = {"A": 300, "B": 211}
+    args = default_args(core="cct", pos_emb="sine", input_shape=(1, 36, 64), resize_image=0, emb_dim=160, num_blocks=2, batch_size=4)
+    args.output_shapes = {m: (n,) for m, n in neurons.items()}
+    args.mouse_ids = list(neurons)
+    ds = make_ds(neurons)
+    torch.manual_seed(3)
+    model = v1t_amd.Model(args, ds).to(dev)
+    tr = Trainer(args, model, ds)
+    batches = {m: make_batch(args, m, neurons[m], 4, dev, seed=i) for i, m in enumerate(neurons)}
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    losses = [float(tr.train_step(batches)["loss"]) for _ in range(4)]
+    assert len(tr._native_cache) == 1 and next(iter(tr._native_cache.values())) is not None
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    after = model.state_dict()
+    assert float((after["core.tokenizer.conv2d.weight"] - before["core.tokenizer.conv2d.weight"]).abs().max()) > 0
+    assert torch.equal(after["core.tokenizer.pos_embedding"], before["core.tokenizer.pos_embedding"])  # a buffer: never stepped
+    b = batches["A"]
+    with pytest.raises(NotImplementedError):
+        rollout_rows(model.core, model.image_cropper(b["image"], "A", b["behavior"], b["pupil_center"])[0], b["behavior"], b["pupil_center"], "A")
+    args.pos_emb = "learn"
+    with pytest.raises(NotImplementedError):
+        v1t_amd.Model(args, ds)
+    args.pos_emb, args.behavior_mode = "sine", 2
+    with pytest.raises(AssertionError):  # core.py:27-28
+        v1t_amd.Model(args, ds)

@@ -1,22 +1,24 @@
 """v1t_amd — MI355X-native (gfx950) V1T hot path: ViT core + Gaussian2d readout behind the reference's
 core / readout plugin registries. See DESIGN.md and INTEGRATION.md."""
 from .core import Core, ViTCore, get_core, register as register_core  # noqa: F401
+from .cct import CCTCore  # noqa: F401  (importing it fills the "cct" registry entry, as core/__init__.py:1 does in the reference)
 from .readout import Gaussian2DReadout, Readout, Readouts, register as register_readout  # noqa: F401
 from .model import ELU1, CoreShifter, CoreShifters, ImageCropper, Model  # noqa: F401
 
-__all__ = ["Core", "ViTCore", "get_core", "register_core", "Gaussian2DReadout", "Readout", "Readouts", "register_readout",
+__all__ = ["Core", "ViTCore", "CCTCore", "get_core", "register_core", "Gaussian2DReadout", "Readout", "Readouts", "register_readout",
            "ELU1", "CoreShifter", "CoreShifters", "ImageCropper", "Model", "install_into_reference"]
 
 
 def install_into_reference() -> bool:
-    """If the reference package `v1t` is importable, overwrite its registry entries "vit" and
+    """If the reference package `v1t` is importable, overwrite its registry entries "vit", "cct" and
     "gaussian2d" (core/core.py:8-16, readout/readout.py:10-18) with the native classes, so that the
-    reference's own `train.py --core vit --readout gaussian2d` picks them up unchanged."""
+    reference's own `train.py --core vit --readout gaussian2d` (or `--core cct`) picks them up unchanged."""
     try:
         from v1t.models.core import core as ref_core  # type: ignore
         from v1t.models.readout import readout as ref_readout  # type: ignore
     except Exception:
         return False
     ref_core.register("vit")(ViTCore)
+    ref_core.register("cct")(CCTCore)
     ref_readout.register("gaussian2d")(Gaussian2DReadout)
     return True

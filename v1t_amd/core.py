@@ -100,7 +100,7 @@ class _VitFn(torch.autograd.Function):
         if training and core.drop_path_rate > 0.0:
             ps = core._path_scale_override
             if ps is None:
-                keep = 1.0 - core.drop_path_rate
+                keep = 1.0 - core.drop_path_rates.to(images.device)[:, None, None]  # (blocks, 1, 1): one rate per block
                 ps = torch.floor(keep + torch.rand((core.num_blocks, 2, B), dtype=torch.float32, device=images.device)) / keep
             ps = ps.to(device=images.device, dtype=torch.float32).contiguous()
             assert ps.shape == (core.num_blocks, 2, B)
@@ -224,16 +224,21 @@ class ViTCore(Core):
             num_mice=len(self.mouse_ids), use_lsa=int(bool(args.use_lsa)), use_bias=int(not args.disable_bias),
             p_dropout=float(args.p_dropout), t_dropout=float(args.t_dropout), ln_eps=1e-5,
         )
+        self._finish_init(args, cfg, c)
+
+    def _finish_init(self, args, cfg, c: int) -> None:
+        """Plan, module tree under the reference's names, flat arena, bookkeeping (shared with the CCT core, cct.py)."""
         self._cfg = cfg
         lib = L.load()
         plan = C.c_void_p()
         L.check(lib.v1t_vit_create(C.byref(cfg), C.byref(plan)), "vit_create")
         self._plan = plan
         self.num_tokens = lib.v1t_vit_tokens(plan)
+        self.cls_tokens = lib.v1t_vit_cls_tokens(plan)  # 1: token 0 is the class token (ViT); 0: patches only (CCT)
         self.padded_dim = lib.v1t_vit_padded_dim(plan)
         self.emb_dim = args.emb_dim
         gh, gw = lib.v1t_vit_grid_h(plan), lib.v1t_vit_grid_w(plan)
-        assert (gh, gw) == find_shape(self.num_tokens - 1)
+        assert (gh, gw) == find_shape(self.num_tokens - self.cls_tokens)
         self.output_shape = (args.emb_dim, gh, gw)
 
         self._build_modules(args, c)
@@ -246,6 +251,8 @@ class ViTCore(Core):
         self._block_events = None  # set by the data-parallel trainer (dist.MouseSharding.reduce_core_overlapped)
         self._path_scale_override = None  # tests: (num_blocks, 2, B) factors to replay instead of drawing them
         self.num_blocks = int(args.num_blocks)
+        if not hasattr(self, "drop_path_rates"):  # ViT: one DropPath module for every block (vit.py:333)
+            self.drop_path_rates = torch.full((self.num_blocks,), self.drop_path_rate, dtype=torch.float32)
         # the attention-probability dropout (vit.py:263) runs at round(256 p) / 256 (include/v1t_amd.h): say so when that is not p
         self.attention_dropout_rate = float(lib.v1t_attention_dropout_rate(float(args.t_dropout))) if float(args.t_dropout) > 0 else 0.0
         if float(args.t_dropout) > 0 and abs(self.attention_dropout_rate - float(args.t_dropout)) > 0.02 * float(args.t_dropout):
@@ -374,7 +381,7 @@ class ViTCore(Core):
         late: t.List[t.Tuple[int, int]] = []
         for sl in sorted((x for x in a.slots if x.is_param), key=lambda x: x.offset):
             key = names[id(sl.tensor)]
-            if key.startswith("transformer.blocks.") and ".b-mlp." not in key:
+            if key.startswith("transformer.blocks.") and ".b-mlp." not in key and ".b_mlp." not in key:
                 blocks.setdefault(int(key.split(".")[2]), []).append((sl.offset, sl.numel))
             else:
                 late.append((sl.offset, sl.numel))
@@ -430,14 +437,14 @@ class ViTCore(Core):
         elif self.behavior_mode == 2:
             beh = behaviors.to(torch.float32).contiguous()
         midx = self.mouse_ids.index(mouse_id) if self.behavior_mode == 4 else 0
-        self._anchor.requires_grad_(any(p.requires_grad for p in (self.patch_embedding.cls_token,)) and not self.frozen)
+        self._anchor.requires_grad_(next(self.parameters()).requires_grad and not self.frozen)  # freeze() flips every parameter
         need_bwd = (torch.is_grad_enabled() and self._anchor.requires_grad) or keep_workspace
         return _VitFn.apply(self, inputs, beh, midx, self._anchor, need_bwd)
 
     def tokens_to_output(self, tokens: torch.Tensor) -> torch.Tensor:
         c, h, w = self.output_shape
         # (B, C', h, w) exactly like vit.py:434-435, as a zero-copy strided view of the token-major buffer
-        out = tokens[:, 1:, :c].unflatten(1, (h, w)).permute(0, 3, 1, 2)
+        out = tokens[:, self.cls_tokens:, :c].unflatten(1, (h, w)).permute(0, 3, 1, 2)
         out._v1t_tokens = tokens  # lets the native readout skip the view chain (and its backward kernels)
         return out
 

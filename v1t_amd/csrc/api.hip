@@ -48,6 +48,11 @@ inline long long align_up(long long x, long long a) { return (x + a - 1) / a * a
 struct v1t_vit {
     v1t_vit_config c;
     int C, IH, IW, P, S, NH, NW, L, T, D, DP, H, HD, HDP, M, MP, NB, IN, J, PD;
+    int HE, HEP;      // head dim (unpadded / padded to 32): emb_dim for the ViT core (vit.py:218), emb_dim / heads^2 for CCT (cct.py:110-127)
+    int cls;          // class tokens in front of the patches: 1 (ViT) or 0 (CCT)
+    bool cct;         // core_kind 1
+    int CH, CW, RCI;  // CCT: conv output grid (before the max pool), rows of the unfolded-patch matrix per image (CH * CW; ViT: T)
+    long long o_cpos; // CCT: fixed position table (buffer) or -1
     int gh, gw;
     bool inject;
     int nbmlp;
@@ -84,6 +89,7 @@ namespace {
 struct WsLayout {
     long long x0, beta, hid, u_hi, u_lo;
     long long u32, pmean1, prstd1, py, pmean2, prstd2;  // patch modes 2/3 (0 bytes otherwise)
+    long long cconv, cidx;                              // CCT tokenizer: conv output fp32 [B*CH*CW][DP], arg-max of the pool windows u8 [B*L][DP]
     // per block
     long long blk_stride, xa, xm, xo, z1, qkv, o, lse2, mean1, rstd1, z2, mean2, rstd2, hpre, hact;
     long long z1_lo, o_lo, z2_lo, hact_lo;  // low planes (forward-only consumers)
@@ -102,8 +108,11 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
     w.x0 = take(R * h->DP * 4);
     w.beta = take((long long)h->NB * B * h->DP * 4);
     w.hid = take((long long)h->NB * B * std::max(h->J, 1) * 4);
-    w.u_hi = take(h->s_pw >= 0 ? R * h->PDX * 2 : 0);
-    w.u_lo = take(h->s_pw >= 0 ? R * h->PDX * 2 : 0);
+    const long long RU = (long long)B * h->RCI;  // rows of the unfolded-patch matrix
+    w.u_hi = take(h->s_pw >= 0 ? RU * h->PDX * 2 : 0);
+    w.u_lo = take(h->s_pw >= 0 ? RU * h->PDX * 2 : 0);
+    w.cconv = take(h->cct ? RU * h->DP * 4 : 0);
+    w.cidx = take(h->cct ? R * h->DP : 0);
     const bool pln = h->c.patch_mode >= 2, pln2 = h->c.patch_mode == 3;
     w.u32 = take(pln ? R * h->PDX * 4 : 0);
     w.pmean1 = take(pln ? R * 4 : 0);
@@ -162,10 +171,11 @@ TnPlan tn_plan(const v1t_vit* h, long long R) {
     p.mc_fc1 = tn_mchunk(R, (MP + 127) / 128);
     p.mc_proj = tn_mchunk(R, ((DP + 127) / 128) * h->H);
     p.mc_qkv = tn_mchunk(R, (3 * HDP + 127) / 128);
-    p.mc_patch = tn_mchunk(R, ((DP + 159) / 160) * (h->PDX / 128));
+    const long long RU = R / h->T * h->RCI;
+    p.mc_patch = tn_mchunk(RU, ((DP + 159) / 160) * (h->PDX / 128));
     p.slab = std::max(std::max(gemm_tn_slab_bytes((int)R, DP, MP, p.mc_fc2), gemm_tn_slab_bytes((int)R, MP, DP, p.mc_fc1)),
                       std::max(gemm_tn_slab_bytes((int)R, DP, HDP, p.mc_proj), gemm_tn_slab_bytes((int)R, 3 * HDP, DP, p.mc_qkv)));
-    if (h->s_pw >= 0) p.slab = std::max(p.slab, gemm_tn_slab_bytes((int)R, DP, h->PDX, p.mc_patch));
+    if (h->s_pw >= 0) p.slab = std::max(p.slab, gemm_tn_slab_bytes((int)RU, DP, h->PDX, p.mc_patch));
     return p;
 }
 
@@ -187,8 +197,9 @@ ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     s.dqkv = take(R * 3 * h->HDP * 2);
     s.dbeta = take((long long)h->NB * B * h->DP * 4);
     s.slab = take((long long)tn_plan(h, R).slab);
-    s.pu = take(h->s_pw >= 0 ? R * h->PDX * 2 : 0);
-    s.pgd = take(h->s_pw >= 0 ? R * h->DP * 2 : 0);
+    const long long RU = (long long)B * h->RCI;
+    s.pu = take(h->s_pw >= 0 ? RU * h->PDX * 2 : 0);
+    s.pgd = take(h->s_pw >= 0 ? RU * h->DP * 2 : 0);
     s.pdu = take(h->c.patch_mode >= 2 ? R * h->PD * 4 : 0);
     s.ds = take(g_attn_ds && !h->c.use_lsa ? (long long)attn_ds_bytes(B, h->H, h->T) : 0);  // materialised dS' of one block
     s.total = cur;
@@ -334,19 +345,45 @@ const char* v1t_error_string(int code) {
 
 int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     if (!cfg || !out) return V1T_ERR_ARG;
-    if (cfg->patch_mode < 0 || cfg->patch_mode > 3) return V1T_ERR_UNSUPPORTED;
-    if (cfg->patch_mode == 2 && cfg->in_channels != 1) return V1T_ERR_UNSUPPORTED;  // vit.py:84 sizes the SPT patch as (c + 4) * P^2: single-channel only
+    const bool cct = cfg->core_kind == 1;
+    if (cfg->core_kind != 0 && cfg->core_kind != 1) return V1T_ERR_UNSUPPORTED;
+    if (!cct && (cfg->patch_mode < 0 || cfg->patch_mode > 3)) return V1T_ERR_UNSUPPORTED;
+    if (!cct && cfg->patch_mode == 2 && cfg->in_channels != 1) return V1T_ERR_UNSUPPORTED;  // vit.py:84 sizes the SPT patch as (c + 4) * P^2: single-channel only
     if (cfg->patch_stride < 1 || cfg->patch_stride > cfg->patch_size) return V1T_ERR_ARG;
     if (cfg->behavior_mode != 0 && cfg->behavior_mode != 2 && cfg->behavior_mode != 3 && cfg->behavior_mode != 4) return V1T_ERR_ARG;
+    if (cct && (cfg->behavior_mode == 2 || cfg->conv_pad < 0 || cfg->pos_mode < 0 || cfg->pos_mode > 1)) return V1T_ERR_ARG;  // core.py:27-28: mode 2 is ViT-only
     v1t_vit* h = new v1t_vit();
     h->c = *cfg;
+    if (cct) { h->c.patch_mode = 0; h->c.use_lsa = 0; h->c.use_bias = 1; }
+    cfg = &h->c;
+    h->cct = cct;
+    h->cls = cct ? 0 : 1;
     h->C = cfg->in_channels; h->IH = cfg->in_h; h->IW = cfg->in_w; h->P = cfg->patch_size; h->S = cfg->patch_stride;
-    h->NH = (h->IH - h->P) / h->S + 1;
-    h->NW = (h->IW - h->P) / h->S + 1;
+    h->CH = h->CW = 0;
+    if (cct) {  // Conv2d(k = P, stride = S, padding = conv_pad) then MaxPool2d(kernel 3, stride 2, padding 1) (cct.py:46-56)
+        h->CH = (h->IH + 2 * cfg->conv_pad - h->P) / h->S + 1;
+        h->CW = (h->IW + 2 * cfg->conv_pad - h->P) / h->S + 1;
+        if (h->CH < 1 || h->CW < 1) { delete h; return V1T_ERR_ARG; }
+        h->NH = (h->CH + 2 - 3) / 2 + 1;
+        h->NW = (h->CW + 2 - 3) / 2 + 1;
+    } else {
+        h->NH = (h->IH - h->P) / h->S + 1;
+        h->NW = (h->IW - h->P) / h->S + 1;
+    }
     if (h->NH < 1 || h->NW < 1) { delete h; return V1T_ERR_ARG; }
-    h->L = h->NH * h->NW; h->T = h->L + 1;
+    h->L = h->NH * h->NW; h->T = h->L + h->cls;
+    h->RCI = cct ? h->CH * h->CW : h->T;
     h->D = cfg->emb_dim; h->DP = round_up(h->D, 32);
-    h->H = cfg->num_heads; h->HD = h->H * h->D; h->HDP = h->H * h->DP;
+    h->H = cfg->num_heads;
+    if (cct) {  // inner = emb_dim // heads is the WHOLE qkv width of one of q / k / v; it is then cut into `heads` heads (cct.py:110-127)
+        const int inner = h->D / h->H;
+        if (h->H < 1 || inner < h->H || inner % h->H != 0) { delete h; return V1T_ERR_ARG; }  // the reference's assert (cct.py:111-113)
+        h->HE = inner / h->H;
+    } else {
+        h->HE = h->D;
+    }
+    h->HEP = round_up(h->HE, 32);
+    h->HD = h->H * h->HE; h->HDP = h->H * h->HEP;
     h->M = cfg->mlp_dim; h->MP = round_up(h->M, 32);
     h->NB = cfg->num_blocks;
     h->inject = cfg->behavior_mode == 2 || cfg->behavior_mode == 3 || cfg->behavior_mode == 4;
@@ -355,15 +392,22 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     h->PD = (cfg->patch_mode == 2 ? h->C + 4 : h->C) * h->P * h->P;
     h->nbmlp = cfg->behavior_mode == 4 ? std::max(cfg->num_mice, 1) : 1;
     if (h->DP > 160 || (h->DP != 32 && h->DP != 64 && h->DP != 96 && h->DP != 128 && h->DP != 160)) { delete h; return V1T_ERR_UNSUPPORTED; }
+    if (h->HEP > 160) { delete h; return V1T_ERR_UNSUPPORTED; }
     find_shape(h->L, &h->gh, &h->gw);
 
     // ---- parameter arena (natural shapes, reference state-dict names)
     long long cur = 0;
     const bool bias = cfg->use_bias != 0;
-    h->o_cls = h->add("patch_embedding.cls_token", {1, 1, h->D}, true, cur);
-    h->o_pos = h->add("patch_embedding.pos_embedding", {h->T, h->D}, true, cur);
+    h->o_cls = h->o_pos = h->o_pb = h->o_cpos = -1;
     h->o_pln_w = h->o_pln_b = h->o_pln2_w = h->o_pln2_b = -1;
-    if (cfg->patch_mode == 0) {
+    if (cct) {
+        h->o_pw = h->add("tokenizer.conv2d.weight", {h->D, h->C, h->P, h->P}, true, cur);
+    } else {
+        h->o_cls = h->add("patch_embedding.cls_token", {1, 1, h->D}, true, cur);
+        h->o_pos = h->add("patch_embedding.pos_embedding", {h->T, h->D}, true, cur);
+    }
+    if (cct) {
+    } else if (cfg->patch_mode == 0) {
         h->o_pw = h->add("patch_embedding.projection.2.weight", {h->D, h->PD}, true, cur);
         h->o_pb = h->add("patch_embedding.projection.2.bias", {h->D}, true, cur);
     } else if (cfg->patch_mode == 2) {  // PatchShifting, Unfold, Rearrange, LayerNorm(patch), Linear (vit.py:83-91)
@@ -386,22 +430,23 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     for (int k = 0; k < h->NB; ++k) {
         BlockOff& b = h->blk[k];
         const std::string p = "transformer.blocks." + std::to_string(k) + ".";
+        const std::string mlp = cct ? "mlp." : "mlp.model.";  // cct.py:161-168: the Sequential itself is the attribute
         b.ln1w = h->add(p + "mha.layer_norm.weight", {h->D}, true, cur);
         b.ln1b = h->add(p + "mha.layer_norm.bias", {h->D}, true, cur);
-        b.qkv = h->add(p + "mha.to_qkv.weight", {3LL * h->HD, h->D}, true, cur);
+        b.qkv = h->add(p + (cct ? "mha.qkv.weight" : "mha.to_qkv.weight"), {3LL * h->HD, h->D}, true, cur);
         b.proj = h->add(p + "mha.projection.0.weight", {h->D, h->HD}, true, cur);
         b.projb = bias ? h->add(p + "mha.projection.0.bias", {h->D}, true, cur) : -1;
         b.scale = cfg->use_lsa ? h->add(p + "mha.scale", {h->H}, true, cur) : -1;
-        b.ln2w = h->add(p + "mlp.model.0.weight", {h->D}, true, cur);
-        b.ln2b = h->add(p + "mlp.model.0.bias", {h->D}, true, cur);
-        b.fc1 = h->add(p + "mlp.model.1.weight", {h->M, h->D}, true, cur);
-        b.fc1b = bias ? h->add(p + "mlp.model.1.bias", {h->M}, true, cur) : -1;
-        b.fc2 = h->add(p + "mlp.model.4.weight", {h->D, h->M}, true, cur);
-        b.fc2b = bias ? h->add(p + "mlp.model.4.bias", {h->D}, true, cur) : -1;
+        b.ln2w = h->add(p + mlp + "0.weight", {h->D}, true, cur);
+        b.ln2b = h->add(p + mlp + "0.bias", {h->D}, true, cur);
+        b.fc1 = h->add(p + mlp + "1.weight", {h->M, h->D}, true, cur);
+        b.fc1b = bias ? h->add(p + mlp + "1.bias", {h->M}, true, cur) : -1;
+        b.fc2 = h->add(p + mlp + "4.weight", {h->D, h->M}, true, cur);
+        b.fc2b = bias ? h->add(p + mlp + "4.bias", {h->D}, true, cur) : -1;
         if (h->inject) {
             b.bmlp.resize(h->nbmlp);
             for (int m = 0; m < h->nbmlp; ++m) {
-                const std::string q = p + "b-mlp.models." + (cfg->behavior_mode == 4 ? "@" + std::to_string(m) : std::string("share")) + ".";
+                const std::string q = p + (cct ? "b_mlp.models." : "b-mlp.models.") + (cfg->behavior_mode == 4 ? "@" + std::to_string(m) : std::string("share")) + ".";
                 b.bmlp[m].w1 = h->add(q + "0.weight", {h->J, h->IN}, true, cur);
                 b.bmlp[m].b1 = bias ? h->add(q + "0.bias", {h->J}, true, cur) : -1;
                 b.bmlp[m].w3 = h->add(q + "3.weight", {h->D, h->J}, true, cur);
@@ -413,6 +458,7 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     if (!cfg->use_lsa)
         for (int k = 0; k < h->NB; ++k)
             h->blk[k].scale = h->add("transformer.blocks." + std::to_string(k) + ".mha.scale", {}, false, cur);
+    if (cct && cfg->pos_mode == 1) h->o_cpos = h->add("tokenizer.pos_embedding", {1, h->L, h->D}, false, cur);
     h->arena_floats = cur;
 
     // ---- shadow layout + pack table
@@ -425,22 +471,23 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     auto desc = [&](long long src, int src_ld, long long dst, int drows, int dcols, int rp, int rv, int cp, int cv, int tr, int f32) {
         PackDesc d;
         d.src_off = src; d.dst_off = dst; d.src_ld = src_ld; d.drows = drows; d.dcols = dcols;
-        d.rseg_pad = rp; d.rseg_valid = rv; d.cseg_pad = cp; d.cseg_valid = cv; d.transpose = tr; d.out_f32 = f32 & 1; d.lo_plane = (f32 >> 1) & 1 ? (g_fwd_f16 ? 2 : 1) : 0;
+        d.rseg_pad = rp; d.rseg_valid = rv; d.cseg_pad = cp; d.cseg_valid = cv; d.transpose = tr; d.out_f32 = f32 & 1; d.lo_plane = (f32 & 4) ? 1 : ((f32 >> 1) & 1 ? (g_fwd_f16 ? 2 : 1) : 0);  // 4: always the bf16 residual (split-bf16 operand)
         h->pack.push_back(d);
     };
     for (int k = 0; k < h->NB; ++k) {
         BlockOff& b = h->blk[k];
         const int DP = h->DP, D = h->D, MP = h->MP, M = h->M, HDP = h->HDP;
-        b.s_qkv = stake(3LL * HDP * DP * 2);   desc(b.qkv, D, b.s_qkv, 3 * HDP, DP, DP, D, DP, D, 0, 0);
-        b.s_qkv_t = stake(3LL * HDP * DP * 2); desc(b.qkv, D, b.s_qkv_t, DP, 3 * HDP, DP, D, DP, D, 1, 0);
-        b.s_proj = stake((long long)DP * HDP * 2);   desc(b.proj, h->HD, b.s_proj, DP, HDP, DP, D, DP, D, 0, 0);
-        b.s_proj_t = stake((long long)DP * HDP * 2); desc(b.proj, h->HD, b.s_proj_t, HDP, DP, DP, D, DP, D, 1, 0);
+        const int HEP = h->HEP, HE = h->HE;  // head segments of the qkv rows / proj columns
+        b.s_qkv = stake(3LL * HDP * DP * 2);   desc(b.qkv, D, b.s_qkv, 3 * HDP, DP, HEP, HE, DP, D, 0, 0);
+        b.s_qkv_t = stake(3LL * HDP * DP * 2); desc(b.qkv, D, b.s_qkv_t, DP, 3 * HDP, HEP, HE, DP, D, 1, 0);
+        b.s_proj = stake((long long)DP * HDP * 2);   desc(b.proj, h->HD, b.s_proj, DP, HDP, DP, D, HEP, HE, 0, 0);
+        b.s_proj_t = stake((long long)DP * HDP * 2); desc(b.proj, h->HD, b.s_proj_t, HDP, DP, DP, D, HEP, HE, 1, 0);
         b.s_fc1 = stake((long long)MP * DP * 2);   desc(b.fc1, D, b.s_fc1, MP, DP, MP, M, DP, D, 0, 0);
         b.s_fc1_t = stake((long long)MP * DP * 2); desc(b.fc1, D, b.s_fc1_t, DP, MP, MP, M, DP, D, 1, 0);
         b.s_fc2 = stake((long long)DP * MP * 2);   desc(b.fc2, M, b.s_fc2, DP, MP, DP, D, MP, M, 0, 0);
         b.s_fc2_t = stake((long long)DP * MP * 2); desc(b.fc2, M, b.s_fc2_t, MP, DP, DP, D, MP, M, 1, 0);
-        b.s_qkv_lo = stake(3LL * HDP * DP * 2);       desc(b.qkv, D, b.s_qkv_lo, 3 * HDP, DP, DP, D, DP, D, 0, 2);
-        b.s_proj_lo = stake((long long)DP * HDP * 2); desc(b.proj, h->HD, b.s_proj_lo, DP, HDP, DP, D, DP, D, 0, 2);
+        b.s_qkv_lo = stake(3LL * HDP * DP * 2);       desc(b.qkv, D, b.s_qkv_lo, 3 * HDP, DP, HEP, HE, DP, D, 0, 2);
+        b.s_proj_lo = stake((long long)DP * HDP * 2); desc(b.proj, h->HD, b.s_proj_lo, DP, HDP, DP, D, HEP, HE, 0, 2);
         b.s_fc1_lo = stake((long long)MP * DP * 2);   desc(b.fc1, D, b.s_fc1_lo, MP, DP, MP, M, DP, D, 0, 2);
         b.s_fc2_lo = stake((long long)DP * MP * 2);   desc(b.fc2, M, b.s_fc2_lo, DP, MP, DP, D, MP, M, 0, 2);
         b.s_projb = b.s_fc1b = b.s_fc2b = -1;
@@ -456,10 +503,14 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
     if (cfg->patch_mode >= 2) {
         h->s_pw_t = stake((long long)h->PD * h->DP * 2); desc(h->o_pw, h->PD, h->s_pw_t, h->PD, h->DP, h->DP, h->D, h->PD, h->PD, 1, 0);
     }
+    if (cct && h->PD % 32 != 0) { delete h; return V1T_ERR_UNSUPPORTED; }  // the conv tokenizer exists as the MFMA GEMM over unfolded patches only
     if (h->PD % 32 == 0) {  // MFMA patch embedding (both patch modes store the weight as [D][C*P*P])
         h->s_pw = stake((long long)h->DP * h->PD * 2);    desc(h->o_pw, h->PD, h->s_pw, h->DP, h->PD, h->DP, h->D, h->PD, h->PD, 0, 0);
-        h->s_pw_lo = stake((long long)h->DP * h->PD * 2); desc(h->o_pw, h->PD, h->s_pw_lo, h->DP, h->PD, h->DP, h->D, h->PD, h->PD, 0, 2);
-        h->s_pb = stake(h->DP * 4);                       desc(h->o_pb, h->D, h->s_pb, 1, h->DP, 1, 1, h->DP, h->D, 0, 1);
+        // (CCT: the conv runs in split-bf16 - three MFMA products, ~2^-17 - whatever the other linears use: the arg-max of the
+        // max pool behind it decides where gradients go, and near-ties flip 30x more often at fp16 operand precision; it is 0.1 %
+        // of the model's FLOPs)
+        h->s_pw_lo = stake((long long)h->DP * h->PD * 2); desc(h->o_pw, h->PD, h->s_pw_lo, h->DP, h->PD, h->DP, h->D, h->PD, h->PD, 0, cct ? 4 : 2);
+        if (h->o_pb >= 0) { h->s_pb = stake(h->DP * 4);   desc(h->o_pb, h->D, h->s_pb, 1, h->DP, 1, 1, h->DP, h->D, 0, 1); }
     }
     h->shadow_bytes = std::max<long long>(sc, 256);
     h->d_pack = nullptr;
@@ -490,6 +541,7 @@ int v1t_vit_tensor_info(const v1t_vit* h, int idx, char* name, int name_cap, lon
     return V1T_OK;
 }
 int v1t_vit_tokens(const v1t_vit* h) { return h->T; }
+int v1t_vit_cls_tokens(const v1t_vit* h) { return h->cls; }
 int v1t_vit_padded_dim(const v1t_vit* h) { return h->DP; }
 int v1t_vit_grid_h(const v1t_vit* h) { return h->gh; }
 int v1t_vit_grid_w(const v1t_vit* h) { return h->gw; }
@@ -552,7 +604,23 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
     float* xcur = (h->NB == 0) ? out : (float*)(ws + w.x0);
     pa.x = xcur;
     pa.drop = make_drop(train, h->c.p_dropout, seed, 0xFFFFu);
-    if (h->s_pw >= 0) {  // unfold -> split-bf16 MFMA GEMM with the bias / position / class-token / dropout epilogue
+    if (h->cct) {
+        // conv tokenizer (cct.py:46-104): zero-padded unfold -> fp16-operand MFMA GEMM against the conv weight [D][C*P*P] -> ReLU,
+        // 3 x 3 / stride 2 max pool, + position table, dropout in one pass (the arg-max of every window is kept for the backward)
+        bf16_t* u_hi = (bf16_t*)(ws + w.u_hi);
+        bf16_t* u_lo = (bf16_t*)(ws + w.u_lo);
+        ConvTokArgs ct{};
+        ct.img = images; ct.B = B; ct.C = h->C; ct.IH = h->IH; ct.IW = h->IW; ct.P = h->P; ct.stride = h->S; ct.pad = h->c.conv_pad;
+        ct.CH = h->CH; ct.CW = h->CW; ct.NH = h->NH; ct.NW = h->NW; ct.D = D; ct.DP = DP;
+        CHECK(launch_conv_unfold(ct, u_hi, u_lo, 0, h->PDX, s));  // hi + bf16 residual planes
+        GemmNTArgs g{};
+        g.A = u_hi; g.A_lo = u_lo; g.lda = h->PDX; g.B = (const bf16_t*)(sh + h->s_pw); g.B_lo = (const bf16_t*)(sh + h->s_pw_lo); g.ldb = h->PD;
+        g.M = B * h->RCI; g.N = DP; g.K = h->PD; g.ldc = DP; g.C = (float*)(ws + w.cconv);
+        CHECK(launch_gemm_nt(g, EPI_F32, s));
+        ct.conv = (const float*)(ws + w.cconv); ct.pos = h->o_cpos >= 0 ? arena + h->o_cpos : nullptr; ct.x = xcur; ct.idx = (unsigned char*)(ws + w.cidx);
+        ct.drop = pa.drop;
+        CHECK(launch_cct_pool_fwd(ct, s));
+    } else if (h->s_pw >= 0) {  // unfold -> split-bf16 MFMA GEMM with the bias / position / class-token / dropout epilogue
         bf16_t* u_hi = (bf16_t*)(ws + w.u_hi);
         bf16_t* u_lo = (bf16_t*)(ws + w.u_lo);
         const int pm = h->c.patch_mode;
@@ -632,7 +700,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = o; at.ldo = HDP; at.o_lo = (bf16_t*)(wb + w.o_lo); at.lo_f16 = g_fwd_f16; at.lse2 = (float*)(wb + w.lse2);
         at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
         at.adrop = make_adrop(train, h->c.t_dropout, seed, 8 * k + 0);
-        CHECK(launch_attn_fwd(at, DP, s));
+        CHECK(launch_attn_fwd(at, h->HEP, s));
 
         g = GemmNTArgs{};
         g.A = o; g.lda = HDP; g.B = (const bf16_t*)(sh + b.s_proj); g.ldb = HDP; g.M = R; g.N = DP; g.K = HDP; g.C = xm; g.ldc = DP;
@@ -768,7 +836,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         // ---- attention branch: dWo += dy^T o
         t = GemmTNArgs{};
         t.Y = dy; t.ldy = DP; t.X = o; t.ldx = HDP; t.M = R; t.NY = DP; t.NX = HDP; t.dW = grads + b.proj; t.ldw = h->HD;
-        t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
+        t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->HEP; t.xseg_valid = h->HE; t.alpha = 1.f;
         t.m_chunk = tp.mc_proj; t.slab = slab;
         CHECK(launch_gemm_tn(t, s));
         // dO = dy . Wo
@@ -782,12 +850,12 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         at.dO = dO; at.lddo = HDP; at.delta = delta; at.dqkv = dqkv; at.lddqkv = 3 * HDP;
         at.dscale = h->c.use_lsa ? grads + b.scale : nullptr;
         if (g_attn_ds && !h->c.use_lsa) { at.ds = (bf16_t*)(sc + sl.ds); at.ldds = attn_ds_ld(h->T); }
-        CHECK(launch_attn_delta(at, DP, delta, s));
-        CHECK(launch_attn_bwd(at, DP, s));
+        CHECK(launch_attn_delta(at, h->HEP, delta, s));
+        CHECK(launch_attn_bwd(at, h->HEP, s));
         // dWqkv += dqkv^T z1
         t = GemmTNArgs{};
         t.Y = dqkv; t.ldy = 3 * HDP; t.X = z1; t.ldx = DP; t.M = R; t.NY = 3 * HDP; t.NX = DP; t.dW = grads + b.qkv; t.ldw = D;
-        t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
+        t.yseg_pad = h->HEP; t.yseg_valid = h->HE; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
         t.m_chunk = tp.mc_qkv; t.slab = slab;
         CHECK(launch_gemm_tn(t, s));
         // dz1 = dqkv . Wqkv
@@ -816,7 +884,24 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
     pa.D = D; pa.DP = DP; pa.x = (float*)gin;
     pa.drop = make_drop(train, h->c.p_dropout, seed, 0xFFFFu);
     pa.dW = grads + h->o_pw; pa.dbias = grads + h->o_pb; pa.dcls = grads + h->o_cls; pa.dpos = grads + h->o_pos;
-    if (h->s_pw >= 0 && h->c.patch_mode >= 2) {
+    if (h->cct) {
+        // conv tokenizer backward: route d x0 through the dropout mask, the saved arg-max of every pool window and the ReLU into the
+        // conv output grid (bf16), re-unfold the images and dW += d conv^T . U  (no input gradient: the cropper samples nearest)
+        bf16_t* gd = (bf16_t*)(sc + sl.pgd);
+        bf16_t* u = (bf16_t*)(sc + sl.pu);
+        ConvTokArgs ct{};
+        ct.img = images; ct.B = B; ct.C = h->C; ct.IH = h->IH; ct.IW = h->IW; ct.P = h->P; ct.stride = h->S; ct.pad = h->c.conv_pad;
+        ct.CH = h->CH; ct.CW = h->CW; ct.NH = h->NH; ct.NW = h->NW; ct.D = D; ct.DP = DP;
+        ct.x = (float*)gin; ct.idx = (unsigned char*)(ws + w.cidx); ct.drop = pa.drop;
+        CHECK(launch_cct_pool_bwd(ct, gd, s));
+        CHECK(launch_conv_unfold(ct, u, nullptr, 0, h->PDX, s));
+        GemmTNArgs t{};
+        const int RU = B * h->RCI;
+        t.Y = gd; t.ldy = DP; t.X = u; t.ldx = h->PDX; t.M = RU; t.NY = DP; t.NX = h->PDX; t.dW = grads + h->o_pw; t.ldw = h->PD;
+        t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->PDX; t.xseg_valid = h->PD; t.alpha = 1.f;
+        t.m_chunk = tp.mc_patch; t.slab = slab;
+        CHECK(launch_gemm_tn(t, s));
+    } else if (h->s_pw >= 0 && h->c.patch_mode >= 2) {
         // modes 2 / 3: [LayerNorm(D) backward] -> dW (+ dbias) against the normalised patches of the forward -> dU -> LayerNorm(patch) parameter gradients
         const char* ws = (const char*)workspace;
         bf16_t* gd = (bf16_t*)(sc + sl.pgd);

@@ -32,6 +32,27 @@ struct PatchArgs {
     // backward accumulators (fp32, natural shapes)
     float* dW; float* dbias; float* dcls; float* dpos;
 };
+// CCT conv tokenizer (reference core/cct.py:30-104): Conv2d(C -> D, kernel P, stride, zero padding `pad`, no bias) as unfold + MFMA
+// GEMM, then ReLU -> MaxPool2d(kernel 3, stride 2, padding 1) -> "b c h w -> b (h w) c" -> + position table -> dropout.
+struct ConvTokArgs {
+    const float* img;        // [B][C][IH][IW]
+    int B, C, IH, IW, P, stride, pad;
+    int CH, CW;              // conv output grid
+    int NH, NW;              // pooled grid (tokens per image = NH * NW)
+    int D, DP;
+    const float* conv;       // [B*CH*CW][DP] fp32 conv output (pool forward)
+    const float* pos;        // [NH*NW][D] or nullptr
+    float* x;                // forward: tokens out [B*NH*NW][DP] (pad columns 0); backward: gradient wrt the tokens (in)
+    unsigned char* idx;      // [B*NH*NW][DP]: window element 0..8 (3 * dy + dx) that holds the maximum, 255 = ReLU inactive (no gradient)
+    DropCfg drop;
+};
+// U[(b*CH + cy)*CW + cx][j] = img[b][c][cy*stride - pad + kh][cx*stride - pad + kw] (0 outside the image), j = (c*P + kh)*P + kw;
+// columns >= C*P*P are zero. hi (bf16) and optional second plane (fp16 / bf16 residual) like launch_patch_unfold.
+int launch_conv_unfold(const ConvTokArgs& a, bf16_t* u_hi, bf16_t* u_lo, int lo_f16, int ldu, hipStream_t s);
+int launch_cct_pool_fwd(const ConvTokArgs& a, hipStream_t s);
+// gd[(b*CH + cy)*CW + cx][d] (bf16) = sum over the pool windows whose maximum sits at (cy, cx): dropout_bwd(a.x[b][window][d])
+int launch_cct_pool_bwd(const ConvTokArgs& a, bf16_t* gd, hipStream_t s);
+
 int launch_patch_embed_fwd(const PatchArgs& a, hipStream_t s);
 int launch_patch_embed_bwd(const PatchArgs& a, hipStream_t s);
 // MFMA form of the patch embedding (C*P*P % 32 == 0): the unfolded patches as a bf16 matrix U [B*T][ldu]

@@ -133,6 +133,93 @@ __global__ __launch_bounds__(256) void patch_unfold_kernel(PatchArgs a, bf16_t* 
     if (u_lo) *(bf16x8*)(u_lo + row * ldu + 8 * jc) = lo;
 }
 
+// ---- CCT conv tokenizer (elementwise.h, ConvTokArgs)
+__global__ __launch_bounds__(256) void conv_unfold_kernel(ConvTokArgs a, bf16_t* u_hi, bf16_t* u_lo, int lo_f16, int ldu) {
+    const int PD = a.C * a.P * a.P, PP = a.P * a.P, cpr = ldu / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long rows = (long long)a.B * a.CH * a.CW;
+    if (idx >= rows * cpr) return;
+    const int jc = (int)(idx % cpr);
+    const long long row = idx / cpr;
+    const int cx = (int)(row % a.CW), cy = (int)((row / a.CW) % a.CH), b = (int)(row / ((long long)a.CW * a.CH));
+    const int y0 = cy * a.stride - a.pad, x0 = cx * a.stride - a.pad;
+    const float* img = a.img + (size_t)b * a.C * a.IH * a.IW;
+    bf16x8 hi = {}, lo = {};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = 8 * jc + e;
+        float v = 0.f;
+        if (j < PD) {
+            const int c = j / PP, y = y0 + (j % PP) / a.P, x = x0 + j % a.P;
+            if (y >= 0 && y < a.IH && x >= 0 && x < a.IW) v = img[((size_t)c * a.IH + y) * a.IW + x];
+        }
+        hi[e] = (bf16_t)v;
+        lo[e] = aux_plane(v, hi[e], lo_f16);
+    }
+    *(bf16x8*)(u_hi + row * ldu + 8 * jc) = hi;
+    if (u_lo) *(bf16x8*)(u_lo + row * ldu + 8 * jc) = lo;
+}
+// one thread per (token row, column): max over the 3 x 3 window (stride 2, padding 1: out-of-grid elements do not take part, as
+// MaxPool2d pads with -inf) of relu(conv), first maximum in row-major scan order like ATen's max_pool2d
+__global__ __launch_bounds__(256) void cct_pool_fwd_kernel(ConvTokArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int L = a.NH * a.NW;
+    if (i >= (long long)a.B * L * a.DP) return;
+    const int d = (int)(i % a.DP);
+    const long long row = i / a.DP;
+    const int l = (int)(row % L), b = (int)(row / L);
+    float out = 0.f;
+    unsigned char arg = 255;
+    if (d < a.D) {
+        const int ny = l / a.NW, nx = l % a.NW;
+        float best = -3.0e38f;
+        int bi = -1;
+        for (int dy = 0; dy < 3; ++dy) {
+            const int cy = 2 * ny - 1 + dy;
+            if (cy < 0 || cy >= a.CH) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int cx = 2 * nx - 1 + dx;
+                if (cx < 0 || cx >= a.CW) continue;
+                const float v = fmaxf(a.conv[(((size_t)b * a.CH + cy) * a.CW + cx) * a.DP + d], 0.f);  // ReLU first (cct.py:88-89)
+                if (v > best) { best = v; bi = 3 * dy + dx; }
+            }
+        }
+        // a maximum of 0 means every element of the window is clipped by the ReLU: no gradient passes
+        arg = (best > 0.f) ? (unsigned char)bi : (unsigned char)255;
+        out = best + (a.pos ? a.pos[(size_t)l * a.D + d] : 0.f);
+        if (a.drop.thresh) out = drop_keep(a.drop.key, (uint32_t)row, (uint32_t)d, a.drop.thresh) ? out * a.drop.inv_keep : 0.f;
+    }
+    a.x[row * a.DP + d] = out;
+    a.idx[row * a.DP + d] = arg;
+}
+// one thread per (conv position, column): the <= 4 pool windows that contain the position
+__global__ __launch_bounds__(256) void cct_pool_bwd_kernel(ConvTokArgs a, bf16_t* gd) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long rows = (long long)a.B * a.CH * a.CW;
+    if (i >= rows * a.DP) return;
+    const int d = (int)(i % a.DP);
+    const long long row = i / a.DP;
+    const int cx = (int)(row % a.CW), cy = (int)((row / a.CW) % a.CH), b = (int)(row / ((long long)a.CW * a.CH));
+    const int L = a.NH * a.NW;
+    float g = 0.f;
+    if (d < a.D) {
+        for (int ny = cy / 2; ny <= (cy + 1) / 2; ++ny) {          // windows with 2 ny - 1 <= cy <= 2 ny + 1
+            if (ny >= a.NH) continue;
+            const int dy = cy - (2 * ny - 1);
+            for (int nx = cx / 2; nx <= (cx + 1) / 2; ++nx) {
+                if (nx >= a.NW) continue;
+                const int dx = cx - (2 * nx - 1);
+                const long long trow = (long long)b * L + ny * a.NW + nx;
+                if (a.idx[trow * a.DP + d] != (unsigned char)(3 * dy + dx)) continue;
+                float t = a.x[trow * a.DP + d];
+                if (a.drop.thresh) t = drop_keep(a.drop.key, (uint32_t)trow, (uint32_t)d, a.drop.thresh) ? t * a.drop.inv_keep : 0.f;
+                g += t;
+            }
+        }
+    }
+    gd[row * a.DP + d] = (bf16_t)g;
+}
+
 // dpos / dcls as patch_bwd_pos_kernel, plus the bf16 copy of the masked gradient (pad columns zero)
 __global__ void patch_bwd_pos_cast_kernel(PatchArgs a, bf16_t* gd) {
     const int L = a.NH * a.NW, T = L + 1;
@@ -921,6 +1008,21 @@ int launch_dropout_mask(uint8_t* out, long long rows, long long cols, DropCfg d,
 int launch_patch_unfold(const PatchArgs& a, bf16_t* u_hi, bf16_t* u_lo, int lo_f16, int ldu, hipStream_t s) {
     const long long n = (long long)a.B * (a.NH * a.NW + 1) * (ldu / 8);
     hipLaunchKernelGGL(patch_unfold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, u_hi, u_lo, lo_f16, ldu);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_conv_unfold(const ConvTokArgs& a, bf16_t* u_hi, bf16_t* u_lo, int lo_f16, int ldu, hipStream_t s) {
+    const long long n = (long long)a.B * a.CH * a.CW * (ldu / 8);
+    hipLaunchKernelGGL(conv_unfold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, u_hi, u_lo, lo_f16, ldu);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_cct_pool_fwd(const ConvTokArgs& a, hipStream_t s) {
+    const long long n = (long long)a.B * a.NH * a.NW * a.DP;
+    hipLaunchKernelGGL(cct_pool_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_cct_pool_bwd(const ConvTokArgs& a, bf16_t* gd, hipStream_t s) {
+    const long long n = (long long)a.B * a.CH * a.CW * a.DP;
+    hipLaunchKernelGGL(cct_pool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, gd);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 int launch_patch_bwd_pos_cast(const PatchArgs& a, bf16_t* gd, hipStream_t s) {

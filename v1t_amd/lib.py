@@ -25,6 +25,7 @@ class VitConfig(C.Structure):
         ("emb_dim", c_int), ("num_heads", c_int), ("mlp_dim", c_int), ("num_blocks", c_int),
         ("behavior_mode", c_int), ("num_mice", c_int), ("use_lsa", c_int), ("use_bias", c_int),
         ("p_dropout", c_float), ("t_dropout", c_float), ("ln_eps", c_float),
+        ("core_kind", c_int), ("conv_pad", c_int), ("pos_mode", c_int),
     ]
 
 
@@ -39,6 +40,7 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_vit_num_tensors": (c_int, [c_void_p]),
     "v1t_vit_tensor_info": (c_int, [c_void_p, c_int, C.c_char_p, c_int, C.POINTER(c_ll), C.POINTER(c_int), C.POINTER(c_ll), C.POINTER(c_int)]),
     "v1t_vit_tokens": (c_int, [c_void_p]),
+    "v1t_vit_cls_tokens": (c_int, [c_void_p]),
     "v1t_vit_padded_dim": (c_int, [c_void_p]),
     "v1t_vit_grid_h": (c_int, [c_void_p]),
     "v1t_vit_grid_w": (c_int, [c_void_p]),

@@ -307,7 +307,7 @@ class Gaussian2DReadout(Readout):
         tokens = getattr(inputs, "_v1t_tokens", None)
         if tokens is not None and tokens.shape[0] == B:
             T, DP = tokens.shape[1], tokens.shape[2]
-            zbuf, geom = tokens, (DP, T * DP, DP, B, c, h, w, n, self.feat_stride)  # skip the CLS row
+            zbuf, geom = tokens, ((T - h * w) * DP, T * DP, DP, B, c, h, w, n, self.feat_stride)  # skip the class-token row (ViT; the CCT core has none)
         else:
             zbuf = inputs.permute(0, 2, 3, 1).contiguous().to(torch.float32)  # (B, h, w, C) channel-last
             geom = (0, h * w * c, c, B, c, h, w, n, self.feat_stride)

@@ -69,6 +69,9 @@ def rollout_rows(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, p
     `full_chain`: multiply the (T x T) matrices out as the reference does (attention_rollout.py:113-117, `v1t_rollout_matmul`,
     2 T^3 flops per image and block on the MFMAs) instead of the row-vector chain (2 T^2): same result up to fp32
     re-association, ~1000x the arithmetic - there for parity with the reference's algorithm and as a benchmark (config C5)."""
+    if not getattr(core, "cls_tokens", 1):
+        raise NotImplementedError("attention rollout reads the class token's row (attention_rollout.py:118); the CCT core has no class token "
+                                  "(the reference's Recorder does not find cct.py's Attention modules either)")
     if full_chain:
         return _rollout_rows_full(core, images, behaviors, pupil_centers, mouse_id, return_headmax)
     was_training = core.training

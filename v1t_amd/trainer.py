@@ -325,8 +325,8 @@ class _NativeStep:
                 streams[i].wait_event(fwd_done)
             with side(i):
                 s_ = torch.cuda.current_stream().cuda_stream
-                zptr = self.tokens.data_ptr() + 4 * (off * T * DP + DP)  # this unit's images, CLS row skipped
-                gptr = self.gout.data_ptr() + 4 * (off * T * DP + DP)
+                zptr = self.tokens.data_ptr() + 4 * (off * T * DP + core.cls_tokens * DP)  # this unit's images, class-token row skipped
+                gptr = self.gout.data_ptr() + 4 * (off * T * DP + core.cls_tokens * DP)
                 L.check(lib.v1t_gaussian2d_forward(zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["bias"], t_["u"].data_ptr(), s_),
                         "gaussian2d_forward")
                 scale = math.sqrt(trainer.ds_sizes[m] / full)
@@ -356,8 +356,8 @@ class _NativeStep:
             n, N = t_["n"], t_["N"]
             with side(i):
                 s_ = torch.cuda.current_stream().cuda_stream
-                zptr = self.tokens.data_ptr() + 4 * (off * T * DP + DP)
-                gptr = self.gout.data_ptr() + 4 * (off * T * DP + DP)
+                zptr = self.tokens.data_ptr() + 4 * (off * T * DP + core.cls_tokens * DP)
+                gptr = self.gout.data_ptr() + 4 * (off * T * DP + core.cls_tokens * DP)
                 L.check(lib.v1t_gaussian2d_backward_parts(zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["du"].data_ptr(), gptr, T * DP, DP,
                                                           t_["dgrid"].data_ptr(), t_["dfeat"], t_["dbias"], t_["rws"].data_ptr(), t_["rws"].numel(), 2, s_),
                         "gaussian2d_backward")  # d grid, d features, d bias
