@@ -229,6 +229,24 @@ DEVFN float half_max(float x) {
     return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform n (the immediate must be a literal)
+DEVFN void wait_vmcnt_dyn(int n) {
+    switch (n) {
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+// raw barrier: waits for this wave's LDS operations only (a __syncthreads() would also drain the LDS-DMA queue)
+DEVFN void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 DEVFN void zero16(f32x16& x) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = 0.f;
@@ -784,6 +802,254 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void attn_fwd2_kernel(AttnArgs a
     KS_END(1500, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward with FOUR waves per SIMD (round 3). Why: in the kernels above a wave runs S -> softmax -> P.V one after the other, ~260
+// instructions per 32-key tile at ~10 cycles each (in-kernel timeline, tools/kprof.py: MFMA chains, LDS and exp latencies are exposed
+// because a SIMD holds only two such waves - each needs ~230 registers), and the matrix pipe is busy 47 % of the time. Here the tile
+// is cut between two waves of <= 128 registers: waves 0-7 ("S-waves", 32 queries each: Q fragments, S^T = K Q^T, the online softmax,
+// dropout; they never touch V or O) hand the bf16 P^T fragments - already the B operand of the second product - through LDS to
+// waves 8-15 ("PV-waves", SIMD partners w + 8: O^T += V^T P^T, 80 accumulator registers, all K / V staging, the output). A SIMD then
+// holds two S-waves and two PV-waves whose stalls overlap. One barrier per 32-key tile; the PV-waves work one tile behind.
+// K / V tiles of 32 keys in a 5-deep ring (tile t in slot t % 5: K is read in interval t - 1 - the S-waves run their chain one tile
+// ahead of their softmax - V in interval t + 1, the LDS-DMA of tile t + 3 is issued in interval t into the slot tile t - 2 left in
+// interval t - 1). The running maximum lives in the S-waves; when it
+// moves (deferred: RESCALE_THR) they publish the factor per query and a flag, and the PV-wave scales O before it adds the tile.
+constexpr int F3_PAIRS = 8, F3_NBUF = 5;
+template <int DP, bool DROP>
+__global__ __launch_bounds__(128 * F3_PAIRS, 4) void attn_fwd3_kernel(AttnArgs a) {
+    using G = Geo<DP>;
+    using DmaK = TileDma<DP, G::RSTR, 32, F3_PAIRS>;
+    using DmaV = TileDma<DP, G::TSTR, 32, F3_PAIRS>;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[F3_NBUF][DmaK::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[F3_NBUF][DmaV::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) u32x4 sP[2][F3_PAIRS][2][64];  // [tile parity][pair][k-step][lane]
+    __shared__ float sAlpha[2][F3_PAIRS][64];                              // rescale factor of the lane's query
+    __shared__ int sFlag[2][F3_PAIRS];                                     // 1: the factors of this tile are to be applied
+    __shared__ float sInv[F3_PAIRS][64];                                   // epilogue: (1 / keep) / row sum
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pr = wave & (F3_PAIRS - 1);      // pair: S-wave pr and PV-wave pr + 8 own queries [32 pr, 32 pr + 32) of the block
+    const bool pv = wave >= F3_PAIRS;          // wave-uniform role
+    int rb, h, b;
+    decode_block(a, blockIdx.x, gridDim.x, rb, h, b, 32 * F3_PAIRS);
+    const int q = rb * (32 * F3_PAIRS) + 32 * pr + (lane & 31);
+    const int h2 = lane >> 5;
+    const int HD = a.H * DP;
+    const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
+    const bf16_t* kbase = qkv_b + HD + h * DP;
+    const bf16_t* vbase = qkv_b + 2 * HD + h * DP;
+    const int nt = (a.T + 31) / 32;
+    const bool dead_pair = rb * (32 * F3_PAIRS) + 32 * pr >= a.T;  // all 32 queries beyond T: stage and keep the barriers only
+
+    if (pv) {
+        // ------------------------------------------------------------------ PV-wave
+        DmaK dmaK;
+        DmaV dmaV;
+        dmaK.init(lane, pr, a.ldqkv);
+        dmaV.init(lane, pr, a.ldqkv);
+        // vector-memory operations this wave issues per tile (counted waits)
+        const int nops = min(DmaK::PW, max(0, DmaK::NINST - pr * DmaK::PW)) + min(DmaV::PW, max(0, DmaV::NINST - pr * DmaV::PW));
+        auto stage = [&](int t) {
+            dmaK.issue(kbase, 32 * t, a.T, sK[t % F3_NBUF]);
+            dmaV.issue(vbase, 32 * t, a.T, sV[t % F3_NBUF]);
+        };
+        stage(0);
+        if (nt > 1) stage(1);
+        if (nt > 2) stage(2);
+        f32x16 o[G::DB];
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d) zero16(o[d]);
+        const int voff = tr_lane_off(lane, G::TSTR);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // tiles 0 .. 2 in LDS
+        for (int i = 0; i <= nt; ++i) {  // interval i: the S-waves finish tile i (and issue the chain of tile i + 1), this wave works on tile i - 1
+#ifndef V1T_F3_NODMA  // dev ablation: without it the tiles of the prologue are re-used (garbage results, timing only)
+            if (i + 3 < nt) stage(i + 3);
+#endif
+            if (i >= 1 && !dead_pair) {
+                const int j = i - 1, par = j & 1;
+                const u32x4 pa = sP[par][pr][0][lane], pb = sP[par][pr][1][lane];
+                const int flag = __builtin_amdgcn_readfirstlane(sFlag[par][pr]);
+                if (flag) {  // the running maximum moved in tile j: O of the tiles before it is scaled first
+                    const float al = sAlpha[par][pr][lane];
+#pragma unroll
+                    for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[d][r] *= al;
+                }
+                const bf16_t* vp = &sV[j % F3_NBUF][voff];
+                const bf16x8 p0 = __builtin_bit_cast(bf16x8, pa), p1 = __builtin_bit_cast(bf16x8, pb);
+#ifdef V1T_F3_NOLDS  // dev ablation: operands from registers instead of LDS fragments (garbage results, timing only)
+                (void)vp;
+#pragma unroll
+                for (int d = 0; d < G::DB; ++d) {
+                    o[d] = mfma32(p1, p0, o[d]);
+                    o[d] = mfma32(p0, p1, o[d]);
+                }
+#else
+#pragma unroll
+                for (int d = 0; d < G::DB; ++d) {
+                    o[d] = mfma32(tr_frag<G::TSTR>(vp, 0, 32 * d), p0, o[d]);
+                    o[d] = mfma32(tr_frag<G::TSTR>(vp, 16, 32 * d), p1, o[d]);
+                }
+#endif
+            }
+            // everything issued before this interval has landed (tile i + 2, whose K the S-waves read in the next interval, among
+            // it); this interval's own operations (tile i + 3) may stay in flight
+#ifndef V1T_F3_NODMA
+            if (i + 3 < nt) wait_vmcnt_dyn(nops);
+            else
+#endif
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+        if (q < a.T) {
+            const float inv = sInv[pr][lane];
+            bf16_t* orow = a.o + ((size_t)b * a.T + q) * a.ldo + h * DP;
+#pragma unroll
+            for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    bf16x4 w, wl;
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        const float v = o[d][4 * rq + jx] * inv;
+                        w[jx] = (bf16_t)v;
+                        wl[jx] = aux_plane(v, w[jx], a.lo_f16);
+                    }
+                    *(bf16x4*)(orow + 32 * d + 8 * rq + 4 * h2) = w;
+                    if (a.o_lo) *(bf16x4*)(a.o_lo + (orow - a.o) + 32 * d + 8 * rq + 4 * h2) = wl;
+                }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- S-wave
+    // Software-pipelined over the tiles: interval i issues the chain S^T(i + 1) = K(i + 1) Q^T one MFMA per slot (its K fragment read
+    // LA slots ahead) with a slice of tile i's softmax (exp2, row sum, dropout, packing) in each slot, fenced by sched_barrier(0) -
+    // the wave issues in order, so its own MFMAs and its vector work only overlap if they alternate in the instruction stream.
+    const float c = a.scale[a.scale_per_head ? h : 0] * LOG2E;
+    bf16x8 qf[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+        u32x4 t = (q < a.T) ? *(const u32x4*)(qkv_b + (size_t)q * a.ldqkv + h * DP + 16 * ks + 8 * h2) : u32x4{0, 0, 0, 0};
+        qf[ks] = *(bf16x8*)&t;
+    }
+    float m2 = NEG_BIG, lsum = 0.f;
+    const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
+    const uint32_t dbase = a.adrop.key + ((uint32_t)(b * a.H + h) * T2 + ((uint32_t)q >> 1)) * ADROP_K1 + (uint32_t)(2 * h2) * ADROP_K2;
+    const uint32_t sh_even = 16 * (q & 1), sh_odd = sh_even + 8;
+    const int koff = (lane & 31) * G::RSTR + 8 * h2;
+    touch(qf);
+    touch(c);
+    __builtin_amdgcn_s_barrier();  // tiles 0 .. 2 in LDS (the PV-waves waited for them)
+    if (dead_pair) {
+        for (int i = 0; i <= nt; ++i) lds_barrier();
+        return;
+    }
+    auto mask_tail = [&](int t, f32x16& s) {  // keys beyond T (last tile only)
+        if (32 * t + 32 > a.T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = (32 * t + acc_row(r, lane) >= a.T) ? NEG_BIG : s[r];
+        }
+    };
+    uint32_t w0 = 0, w1 = 0;
+    auto element = [&](int t, f32x16& s, int r, float negm) {  // element r of tile t: score -> P (dropped), row sum
+        const int g = r >> 2, jx = r & 3;
+        if constexpr (DROP) {
+            if (jx == 0) {
+                const uint32_t x0 = dbase + (uint32_t)(16 * t + 4 * g) * ADROP_K2;
+                w0 = mix1(x0);
+                w1 = mix1(x0 + ADROP_K2);
+            }
+        }
+#ifdef V1T_F3_STUB  // dev ablation: no element-wise work at all (what is left is MFMA + LDS + staging + barriers)
+        (void)g; (void)negm;
+        asm volatile("" : "+v"(s[r]));
+        return;
+#endif
+        const float p = fast_exp2(fmaf(s[r], c, negm));
+        lsum += p;
+        if constexpr (DROP) {
+            const bool keep = __builtin_amdgcn_ubfe(jx < 2 ? w0 : w1, (jx & 1) ? sh_odd : sh_even, 8u) >= a.adrop.thresh8;
+            s[r] = keep ? p : 0.f;
+        } else {
+            s[r] = p;
+        }
+    };
+    f32x16 sA, sB;
+    {  // tile 0's chain, un-pipelined
+        zero16(sA);
+        const bf16_t* kp = &sK[0][koff];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) sA = mfma32(*(const bf16x8*)(kp + 16 * ks), qf[ks], sA);
+    }
+    constexpr int LA = 3;
+    auto interval = [&](int i, f32x16& s, f32x16& s2) {
+        const int par = i & 1;
+        mask_tail(i, s);
+        mfma_result_fence();
+        float pmax = vmax3(s[0], s[1], s[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) pmax = vmax3(pmax, s[r], s[r + 1]);
+        pmax = half_max(vmax2(pmax, s[15])) * c;
+        int flag = 0;
+        if (!__all(pmax <= m2 + RESCALE_THR)) {
+            const float mn = fmaxf(m2, pmax);
+            const float alpha = fast_exp2(m2 - mn);
+            lsum *= alpha;
+            m2 = mn;
+            sAlpha[par][pr][lane] = alpha;
+            flag = 1;
+        }
+        if (lane == 0) sFlag[par][pr] = flag;
+        const float negm = -m2;
+        const bool next = i + 1 < nt;  // wave-uniform
+        unsigned ka = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&sK[(i + 1) % F3_NBUF][koff];
+        asm volatile("" : "+v"(ka));  // opaque base: fragment addresses stay immediates
+        auto frag = [&](int m) { return *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(ka + 32u * (unsigned)m); };
+        bf16x8 fr[G::KS];
+        if (next) {
+#pragma unroll
+            for (int m = 0; m < LA; ++m) fr[m] = frag(m);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s2[r] = 0.f;
+        bf16x8 n0, n1;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < G::KS; ++m) {
+            if (next) {
+#ifdef V1T_F3_NOLDS
+                s2 = mfma32(qf[(m + 1) % G::KS], qf[m], s2);
+#else
+                if (m + LA < G::KS) fr[m + LA] = frag(m + LA);
+                s2 = mfma32(fr[m], qf[m], s2);
+#endif
+            }
+#pragma unroll
+            for (int it = m * 18 / G::KS; it < (m + 1) * 18 / G::KS; ++it) {  // 16 element slices + 2 packing slices over the slots
+                if (it < 16) element(i, s, it, negm);
+                else if (it == 16) n0 = acc_to_b_pk(s, 0);
+                else n1 = acc_to_b_pk(s, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sP[par][pr][0][lane] = __builtin_bit_cast(u32x4, n0);
+        sP[par][pr][1][lane] = __builtin_bit_cast(u32x4, n1);
+        lds_barrier();
+    };
+    for (int i = 0; i < nt; i += 2) {
+        interval(i, sA, sB);
+        if (i + 1 < nt) interval(i + 1, sB, sA);
+    }
+    {  // interval nt: the PV-waves finish the last tile; they read the normalisation behind the last barrier
+        const float ltot = lsum + __shfl_xor(lsum, 32);
+        sInv[pr][lane] = (DROP ? a.adrop.inv_keep : 1.0f) / ltot;
+        if (q < a.T && h2 == 0) a.lse2[((size_t)b * a.H + h) * a.T + q] = m2 + log2f(ltot);
+        lds_barrier();
+    }
+}
+
 // delta[b][h][t] = keep_prob * sum_d dO * O. 16 lanes per (row, head) segment: a load instruction reads 256 contiguous
 // bytes of each of its 4 segments (one thread per segment read 16 B at a 320-B stride per lane: 3.4 TB/s).
 template <int DP>
@@ -1227,6 +1493,14 @@ int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
     }
+    static const bool v3 = std::getenv("V1T_ATTN_FWD_V3") != nullptr;  // dev: the 16-wave S / PV role kernel
+    if constexpr (DP >= 128 && !DIAG) {
+        if (v3) {
+            hipLaunchKernelGGL((attn_fwd3_kernel<DP, DROP>), grid, dim3(128 * F3_PAIRS), 0, s, a);
+            prof_end(PROF_ATTN_FWD, s);
+            return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+        }
+    }
     static const bool stagger = std::getenv("V1T_ATTN_FWD_STAGGER") != nullptr;  // dev: A/B of the rotated second half
     if constexpr (DP >= 128 && !DIAG) {
         if (stagger) {
@@ -1331,24 +1605,6 @@ __global__ __launch_bounds__(256) void attn_delta2_kernel(AttnArgs a, float* nls
     }
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform n (the immediate must be a literal)
-DEVFN void wait_vmcnt_dyn(int n) {
-    switch (n) {
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-// raw barrier: waits for this wave's LDS operations only (a __syncthreads() would also drain the LDS-DMA queue)
-DEVFN void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 DEVFN int b2_slot(int t) { return (t + 3) - B2_SLOTS * ((t + 3) / B2_SLOTS); }  // tiles 0, 1 in slots 3, 4: slots 0-2 hold K / V images during the prologue
 
 #ifdef V1T_KCLK
