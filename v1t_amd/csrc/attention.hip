@@ -1553,7 +1553,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(AttnArgs a, int 
 //       the partner reads them back: no transposition);
 //   waves 4-7 ("consumers", SIMD partners of 0-3): dV^T += dO^T P, dK^T += Q^T dS' (20 MFMAs, 160 accumulator
 //       registers), the dS' block stored to HBM as two 16-B-per-lane instructions (the old kernel: 16 two-byte stores),
-//       and all LDS-DMA staging (Q / dO tiles of 32 rows into a 4-slot ring, two tiles ahead, counted vmcnt).
+//       and its half of the LDS-DMA staging (Q / dO tiles of 32 rows into a 5-slot ring, three tiles ahead, counted vmcnt).
 // One barrier per 32-query block; the consumer works one block behind the producer. The matrix pipe of a SIMD then sees
 // 40 MFMAs per block from two waves whose element-wise / LDS phases overlap the partner's MFMAs.
 constexpr int B2_SLOTS = 5;  // tiles live at step i: i - 1 (consumer), i (waits for the consumer), i + 1 (producer), i + 2 (landing), i + 3 (being issued)
@@ -1564,7 +1564,6 @@ struct Bwd2Lds {
     bf16_t d[B2_SLOTS][Dma::LDS_ELEMS];
     float rc[B2_SLOTS][64];   // [0, 32): -lse2 of the slot's queries, [32, 64): -keep_prob * delta
     u32x4 hand[2][4][4][64];  // [block parity][pair][P k-step 0, P k-step 1, dS' k-step 0, dS' k-step 1][lane]
-    u32x4 keep[2][4][2][64];  // [block parity][pair][row groups 0-1, 2-3][lane]: dropout keep words, consumer -> producer
 };
 
 // row constants for the kernel below, padded to 32-query blocks: pad rows get nlse = -1e30 (P = 0), ndelta = 0.
@@ -1713,9 +1712,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     // ---- dropout of P (common.h): the lane's fixed coordinate is its key (column), the varying one the query row. A hash
     // word serves a 2 x 2 block of (query, key); the lane's two decisions of a word sit in the bytes key & 1 and 2 + (key & 1),
     // so after a shift by 8 (key & 1) both are decided by ONE 9-bit SWAR compare: ((w & 0x00FF00FF) | 0x01000100) - thr * 0x00010001
-    // has bit 8 / bit 24 set iff byte 0 / byte 2 >= thr (keep). The CONSUMER evaluates this for block i + 1 in the shadow of
-    // its MFMAs (8 words per block: row pairs (8 g + 4 h2 + 2 u, + 1), word index 2 g + u) and hands the 8 words to the
-    // producer through LDS, where a decision then costs a 1-bit v_bfe_i32 and a v_and instead of hash + compare + select.
+    // has bit 8 / bit 24 set iff byte 0 / byte 2 >= thr (keep): 8 words per block (row pairs (8 g + 4 h2 + 2 u, + 1), word index
+    // 2 g + u), a decision then costs a 1-bit v_bfe_i32 and a v_and. The PRODUCER hashes them itself, one word in the slot that first
+    // needs it. (Round 2 had the consumers do it and pass the words through LDS; since then the consumers have become the
+    // critical path of a step - 2640 against 2000 cycles of own work - and the exchange cost 1.4 % of the backward.)
     const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
     const uint32_t dbase = a.adrop.key + ((uint32_t)bh * T2 + (uint32_t)(2 * h2)) * ADROP_K1 + ((uint32_t)key >> 1) * ADROP_K2;
     const uint32_t dshift = 8 * (key & 1);
@@ -1790,7 +1790,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
             constexpr bool ISSUED = decltype(issued_tag)::value;
             KP_STAMP(0);
             KS_MARK(0);
+#ifndef V1T_B2_NODMA  // dev ablations (timing only, garbage results): V1T_B2_NODMA / NOSTORE / NOVALU / NOKEEP / NOFRAG
             if constexpr (ISSUED) stage(i + 3);
+#endif
             KS_MARK(1);
             const int slot = b2_slot(i + 1);  // block nq does not exist: a stale tile, results never used
             init_rows(slot, s2, dp2, nd2);
@@ -1800,6 +1802,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
             unsigned da = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.d[slot][roff];
             asm volatile("" : "+v"(qa), "+v"(da));
             auto frag = [&](int m) {
+#ifdef V1T_B2_NOFRAG
+                return kf[(m + 1) % G::KS];
+#endif
                 const unsigned ad = (m < G::KS ? qa : da) + 32u * (unsigned)(m % G::KS);
                 return *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)ad;
             };
@@ -1807,10 +1812,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
 #pragma unroll
             for (int m = 0; m < LA; ++m) fr[m] = frag(m);
             u32x4 kw[2] = {};
-            if constexpr (DROP) {
-                kw[0] = lds.keep[i & 1][pw][0][lane];
-                kw[1] = lds.keep[i & 1][pw][1][lane];
-            }
             u32x4* hb = lds.hand[i & 1][pw][0];
             KP_STAMP(1);
             KS_MARK(2);
@@ -1825,9 +1826,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
                 for (int it = m * 20 / NSLOT; it < (m + 1) * 20 / NSLOT; ++it) {  // 16 element slices + 4 fragment slices over the slots
                     if (it < 16) {
                         const int r = it, g = it >> 2, j = it & 3;
+#ifdef V1T_B2_NOVALU
+                        (void)g; (void)j;
+                        asm volatile("" : "+v"(s[r]), "+v"(dp[r]));
+                        continue;
+#endif
                         const float p = fast_exp2(s[r]);
                         if constexpr (DROP) {
                             const int wi = 2 * g + (j >> 1);  // keep word of this row pair; bit 8 / 24: even / odd row
+                            // the producer hashes its own keep words (one per row pair, in the slot that first needs it): the
+                            // consumers are the critical path of a step (ablation: their 8 hash words cost the kernel 7 %) while
+                            // the producers wait ~600 cycles at every barrier
+                            if ((j & 1) == 0) kw[wi >> 2][wi & 3] = keep_word(i, wi);
                             uint32_t km;  // asm: hipcc otherwise rewrites the 1-bit sign extension + and into and + compare + select
                             if ((j & 1) == 0) asm("v_bfe_i32 %0, %1, 8, 1" : "=v"(km) : "v"(kw[wi >> 2][wi & 3]));
                             else asm("v_bfe_i32 %0, %1, 24, 1" : "=v"(km) : "v"(kw[wi >> 2][wi & 3]));
@@ -1916,19 +1926,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     bf16_t* ds_wave = a.ds + ((bh * nq) * nkb + (size_t)(rb * 4 + pw)) * 1024 + lane * 8;
     const unsigned kmask = kok ? 0xFFFFFFFFu : 0u;  // keys beyond T: zeros (the dQ GEMM multiplies them with clamped K rows)
     const bool ktail = rb * 128 + 32 * pw + 32 > a.T;
-    auto keep_block = [&](int blk) {  // all 8 keep words of a block at once (prologue / step 0; later ones ride between the MFMAs)
-        if constexpr (DROP) {
-            u32x4 k0, k1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                k0[e] = keep_word(blk, e);
-                k1[e] = keep_word(blk, 4 + e);
-            }
-            lds.keep[blk & 1][pw][0][lane] = k0;
-            lds.keep[blk & 1][pw][1][lane] = k1;
-        }
-    };
-    keep_block(0);
     store_kv();
     KSP_MARK(1);
     lds_barrier();  // K / V images written
@@ -1943,7 +1940,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     KS_MARK(6);
     // step 0: nothing to consume yet
     if (nq > 3) stage(3);
-    keep_block(1);
     KSP_MARK(4);
     if (nq > 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1961,13 +1957,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         const u32x4* hb = lds.hand[j & 1][pw][0];
         const u32x4 p0 = hb[lane], p1 = hb[64 + lane];
         const u32x4 s0 = hb[128 + lane], s1 = hb[192 + lane];
+#ifndef V1T_B2_NODMA
         if constexpr (ISSUED) stage(i + 3);
+#endif
         KP_STAMP(1);
         KS_MARK(1);
         unsigned ta = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.d[slot][toff];
         unsigned qa = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds.q[slot][toff];
         asm volatile("" : "+v"(ta), "+v"(qa));
         auto frag = [&](int m) {
+#ifdef V1T_B2_NOFRAG
+            return __builtin_bit_cast(bf16x8, (m & 1) ? p1 : s0);
+#endif
             const bf16_t* p = (const bf16_t*)(const __attribute__((address_space(3))) bf16_t*)(uintptr_t)(m < 2 * G::DB ? ta : qa);
             return tr_frag_perm<G::RSTR>(p, 16 * (m & 1), 32 * ((m % (2 * G::DB)) >> 1));
         };
@@ -1983,13 +1984,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
                 m1[e] &= kmask;
             }
         }
+#ifndef V1T_B2_NOSTORE
         *(u32x4*)dst = m0;
         *(u32x4*)(dst + 512) = m1;
+#else
+        asm volatile("" ::"v"(m0), "v"(m1), "v"(dst));
+#endif
         KP_STAMP(2);
         KS_MARK(2);
         const bf16x8 P0 = __builtin_bit_cast(bf16x8, p0), P1 = __builtin_bit_cast(bf16x8, p1);
         const bf16x8 S0 = __builtin_bit_cast(bf16x8, s0), S1 = __builtin_bit_cast(bf16x8, s1);
-        u32x4 kw[2] = {};
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < NSLOT; ++m) {
@@ -1997,10 +2001,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
             const int d = (m % (2 * G::DB)) >> 1;
             if (m < 2 * G::DB) dv[d] = mfma32(fr[m], (m & 1) ? P1 : P0, dv[d]);
             else dk[d] = mfma32(fr[m], (m & 1) ? S1 : S0, dk[d]);
-            if constexpr (DROP) {  // keep words of block i + 1: one per slot, then the two 16-B writes
-                if (m < 8) kw[m >> 2][m & 3] = keep_word(i + 1, m);
-                else if (m < 10) lds.keep[(i + 1) & 1][pw][m - 8][lane] = kw[m - 8];
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // everything issued before this step has landed (the tile the producers read in step i + 1 among it); this step's
