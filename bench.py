@@ -19,7 +19,7 @@ dropout ON (p=0.0229 / 0.2544, counter-based masks), readout position sampling O
 N > 1: per-mouse data parallelism (config C3): mice are sharded over ranks, the shared core's gradient arena is
 all-reduced (SUM) over RCCL in per-block buckets behind the backward; total work per step is fixed (112 images)
 => "scaling": "strong". Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel timed
-live with hipEvents on its stream; HBM traffic from the tracked PMC summary profiles/r02_pmc_attention.json, which must
+live with hipEvents on its stream; HBM traffic from the tracked PMC summary profiles/r03_pmc_attention.json, which must
 describe the launch shape of this run) and, at N = 1, `cpu_baseline` (the CPU oracle timed on the host).
 """
 from __future__ import annotations
@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_attention.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_attention.json")  # collected by tools/pmc_bench.sh on the GPU box (separate --pmc passes)
 
 
 def algorithmic_flops(args, n_neurons: int) -> dict:
@@ -64,8 +64,8 @@ def cpu_model() -> str:
 def cpu_baseline() -> dict:
     """The CPU oracle (oracle/v1t_oracle.py, verified against the reference in the build container) timed on this host, fp32
     (SURVEY.md 8d / BASELINE.md 3): the C2 training step of ONE mouse at the metric's batch (B = 16: forward + backward, every
-    parameter gradient), at two thread counts (32 threads and every hardware thread - more threads than cores only add contention
-    at these GEMM sizes, so both are reported and `value` is the better one), the C2 eval forward at B = 16 and the C1 training
+    parameter gradient), at two thread counts (32 threads and one per physical core - more threads only add contention at these GEMM
+    sizes, so both are reported and `value` is the better one), the C2 eval forward at B = 16 and the C1 training
     step at B = 8. One warm-up + `reps` timed repetitions per leg, bounded so that the whole baseline stays near 30 s."""
     from oracle import v1t_oracle as O
     from oracle import weights as W
@@ -100,11 +100,25 @@ def cpu_baseline() -> dict:
         with torch.no_grad():
             O.model_forward(cfg, sd, bt["image"], "A", bt["behavior"], bt["pupil_center"])
 
+    try:
+        import psutil
+
+        ncores = psutil.cpu_count(logical=False) or ncpu
+    except Exception:  # noqa: BLE001
+        ncores = ncpu
     best = None
-    for nthr in sorted({min(ncpu, 32), ncpu}):
+    for nthr in sorted({min(ncpu, 32), ncores}):
         torch.set_num_threads(nthr)
-        rate = round(B / timed(c2_train, 2), 3)
-        legs[f"c2_train_{nthr}thr"] = {"images_per_s": rate, "batch": B, "threads": nthr}
+        if best is not None:
+            # the all-cores leg: oversubscribed GEMMs of this size can be an order of magnitude slower than 32 threads (0.13 against
+            # 1.5 images/s with 256 threads on the 2 x 64-core round-3 host). One un-warmed repetition bounds the time it can take;
+            # it is reported as such and only counts if it wins.
+            t0 = time.time()
+            c2_train()
+            rate, note = round(B / (time.time() - t0), 3), "single un-warmed repetition"
+        else:
+            rate, note = round(B / timed(c2_train, 2), 3), "median of the timed repetitions"
+        legs[f"c2_train_{nthr}thr"] = {"images_per_s": rate, "batch": B, "threads": nthr, "timing": note}
         if best is None or rate > best[0]:
             best = (rate, nthr)
     torch.set_num_threads(best[1])
@@ -124,7 +138,7 @@ def cpu_baseline() -> dict:
             "sample": f"oracle fp32 (no dropout masks): C2 train step (fwd+bwd) of 1 mouse x 8000 neurons at the metric's batch B={B} with "
                       f"{' and '.join(str(v['threads']) for k, v in legs.items() if k.startswith('c2_train_'))} threads (value = the better), C2 eval "
                       f"forward B={B}, C1 train step B=8; 1 warm-up + 1-3 timed reps each (median; 1 rep when a repetition takes > 4 s), {time.time() - t_start:.0f} s in all, torch "
-                      f"{torch.__version__} CPU, host has {ncpu} hardware threads"}
+                      f"{torch.__version__} CPU, host has {ncores} cores / {ncpu} hardware threads"}
 
 
 def pmc_traffic(kernel: str, images: int, H: int, T: int, DP: int):
@@ -454,7 +468,7 @@ def main():
             "model_tflops_per_s": round(fl["train_per_image"] * images / dt / 1e12, 2),
             "model_frac_of_bf16_peak": round(fl["train_per_image"] * images / dt / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": {"kernel": label, "bound": "mfma", "achieved": round(achieved, 2),
-                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": None if traffic is None else "measured offline: " + os.path.relpath(PMC_FILE, ROOT),
                          "launches": launches.value, "avg_ms": round(avg_ms, 4), "flops_per_launch": per_launch},
         }
         if world == 1 and not a.no_cpu_baseline:

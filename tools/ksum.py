@@ -1,4 +1,6 @@
-"""Dev tool: per-segment cycle sums of one workgroup of attn_fwd2_kernel (build: tools/build_ksum.sh)."""
+"""Dev tool: per-segment cycle sums (KS_MARK probes) of one workgroup of the attention backward dK/dV kernel (KSUM_BWD=1) or forward.
+Build the probe library with V1T_BUILD_LIB=libv1t_amd_ksum.so V1T_HIPCC_EXTRA=-DV1T_KSUM python -m v1t_amd.build, then
+KSUM_BWD=1 python tools/ksum.py 0.2544 loop,dma,init,slots,vmcnt,barrier,pro,epi"""
 import ctypes as C
 import os
 import sys

@@ -1,10 +1,11 @@
-# usage (GPU box): bash tools/pmc_bench.sh  -> gpurun_out/r02_pmc_attention.json + .txt: per-launch FETCH_SIZE / WRITE_SIZE (KiB) of the
+# usage (GPU box): bash tools/pmc_bench.sh  -> gpurun_out/${RND:-r03}_pmc_attention.json + .txt: per-launch FETCH_SIZE / WRITE_SIZE (KiB) of the
 # attention kernels inside bench.py (112-image training launches, dropout on) and inside the C5 eval pass (256-image launches),
 # separate --pmc passes as MI355X_MICROARCH.md prescribes; FETCH_SIZE needs x2 on gfx950 (applied by bench.py, not here).
-# Copy the two files to profiles/ (tracked) - bench.py reads profiles/r02_pmc_attention.json at run time.
+# Copy the two files to profiles/ (tracked) - bench.py reads profiles/${RND:-r03}_pmc_attention.json at run time.
+export RND=${RND:-r03}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcb_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc > /tmp/pmcb_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcb_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-pmc > /tmp/pmcb_$C.log 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmce_$C -- python3 $GRAFT_REPO_ROOT/bench.py --config c5 --steps 1 --warmup 1 --no-cpu-baseline --no-pmc > /tmp/pmce_$C.log 2>&1
 done
 python3 - <<'PY'
@@ -29,7 +30,7 @@ for tag, images, suffix in (("pmcb", 112, ""), ("pmce", 256, "_eval")):
             e["fetch_kib" if c == "FETCH_SIZE" else "write_kib"] = sum(v) / len(v)
             lines.append(f"{c:10s} {k[:80]:80s} images/launch={images:4d} n={len(v):3d} mean={sum(v)/len(v):14.1f} min={min(v):14.1f} max={max(v):14.1f}")
 os.makedirs(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "r02_pmc_attention.json"), "w"), indent=1)
-open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "r02_pmc_attention_fetch_write.txt"), "w").write("\n".join(lines) + "\n")
+json.dump(out, open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", os.environ["RND"] + "_pmc_attention.json"), "w"), indent=1)
+open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", os.environ["RND"] + "_pmc_attention_fetch_write.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines)); print(json.dumps(out))
 PY

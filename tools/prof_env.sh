@@ -1,7 +1,7 @@
 # usage (GPU box): bash tools/prof_env.sh <tag> <grep-pattern>   (env vars pass through) -> per-step kernel times of bench.py
 TAG=$1; PAT=$2
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/p_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --min-seconds 0 --no-cpu-baseline > /tmp/p_$TAG.log 2>&1
 python3 - "$TAG" "$PAT" <<'PY'
 import csv, glob, sys, re
 tag, pat = sys.argv[1], sys.argv[2]

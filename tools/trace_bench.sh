@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/trace_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/t_$TAG
-rocprofv3 --kernel-trace --output-format csv -d /tmp/t_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/t_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --min-seconds 0 --no-cpu-baseline > $OUT/bench.log 2>&1
 cp $(ls /tmp/t_$TAG/*/*kernel_trace.csv | head -1) $OUT/kernel_trace.csv
 python3 $GRAFT_REPO_ROOT/tools/gap_report.py $OUT/kernel_trace.csv > $OUT/gaps.txt 2>&1
 tail -1 $OUT/bench.log | cut -c1-300

@@ -530,279 +530,6 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// Forward, software-pipelined - OPT-IN (V1T_ATTN_FWD_V2=1, DP >= 128, no LSA diagonal; attn_fwd_kernel above is the default: this
-// one ties with it). Same geometry and products as attn_fwd_kernel
-// (8 waves x 32 queries share 64-key K/V stages; S^T = K Q^T with the query on the lane, O^T += V^T P^T with P^T straight
-// from the accumulator), but a wave keeps THREE key tiles in flight: iteration t issues, one MFMA per "slot",
-//     O^T += V^T P^T of tile t - 1   (KS MFMAs)   and   S'^T = K Q^T of tile t + 1   (KS MFMAs),
-// and between them, fenced by sched_barrier(0), the element-wise stage of tile t (exp2, row sum, dropout, bf16 packing).
-// attn_fwd_kernel runs those three phases one after the other in each wave (matrix pipe ~36 % busy, kprof timeline: a
-// wave spends ~2700 cycles per tile for 640 cycles of MFMA); here the vector instructions ride in the MFMAs' shadow.
-// Q is pre-multiplied by c = scale log2(e) and the S' accumulator starts from -m (the running reference maximum of the
-// row), so P = exp2(S') needs no multiply-add; the reference moves only when a score exceeds it by FWD2_THR (in log2
-// units; bf16 / fp32 have 8 exponent bits, so 2^24 sums are harmless), which takes the (rare) un-pipelined path.
-constexpr float FWD2_THR = 24.0f;
-template <int DP, bool DROP>
-__global__ __launch_bounds__(64 * FWD_WAVES, 2) void attn_fwd2_kernel(AttnArgs a) {
-    using G = Geo<DP>;
-    // K/V staging is issued by the first-dispatched half of the workgroup only (waves 0-3): the younger half loses the
-    // issue arbitration on every slot (ksum timeline: 90 vs 70 cycles per slot; s_setprio 1 for it merely swaps the roles) and
-    // would carry its DMA pieces on top, while the older half waits for it at every stage barrier
-    constexpr int DMA_WAVES = FWD_WAVES / 2;
-    using DmaK = TileDma<DP, G::RSTR, 64, DMA_WAVES>;
-    using DmaV = TileDma<DP, G::TSTR, 64, DMA_WAVES>;
-    constexpr int NB = 3;  // stage buffers: V of stage k - 1 and K of stage k + 1 are read while stage k + 2 lands
-    __shared__ __attribute__((aligned(16))) bf16_t sK[NB][DmaK::LDS_ELEMS];
-    __shared__ __attribute__((aligned(16))) bf16_t sV[NB][DmaV::LDS_ELEMS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int rb, h, b;
-    decode_block(a, blockIdx.x, gridDim.x, rb, h, b, 32 * FWD_WAVES);
-    const int q = rb * (32 * FWD_WAVES) + 32 * wave + (lane & 31);
-    const int h2 = lane >> 5;
-    const int HD = a.H * DP;
-    const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
-    const bf16_t* kbase = qkv_b + HD + h * DP;
-    const bf16_t* vbase = qkv_b + 2 * HD + h * DP;
-    const float c = a.scale[a.scale_per_head ? h : 0] * LOG2E;
-    KS_DECL;
-    DmaK dmaK;
-    DmaV dmaV;
-    dmaK.init(lane, wave & (DMA_WAVES - 1), a.ldqkv);
-    dmaV.init(lane, wave & (DMA_WAVES - 1), a.ldqkv);
-    const bool loader = wave < DMA_WAVES;  // wave-uniform
-
-    bf16x8 qf[G::KS];
-#pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) {
-        u32x4 t = (q < a.T) ? *(const u32x4*)(qkv_b + (size_t)q * a.ldqkv + h * DP + 16 * ks + 8 * h2) : u32x4{0, 0, 0, 0};
-        qf[ks] = *(bf16x8*)&t;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16_t)((float)qf[ks][j] * c);
-    }
-    f32x16 o[G::DB];
-#pragma unroll
-    for (int d = 0; d < G::DB; ++d) zero16(o[d]);
-    float m2 = 0.f, lsum = 0.f;  // reference maximum of the row (scaled log2 domain); per-lane partial sum of exp2(S' )
-
-    // dropout: lane-fixed coordinate = q (row), varying = key (common.h)
-    const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
-    const uint32_t dbase = a.adrop.key + ((uint32_t)(b * a.H + h) * T2 + ((uint32_t)q >> 1)) * ADROP_K1 + (uint32_t)(2 * h2) * ADROP_K2;
-    const uint32_t sh_even = 16 * (q & 1), sh_odd = sh_even + 8;
-    const int koff = (lane & 31) * G::RSTR + 8 * h2;
-    const int voff = tr_lane_off(lane, G::TSTR);
-    const int nt = (a.T + 31) / 32, ns = (nt + 1) / 2;
-
-    auto kptr = [&](int t) { return &sK[(t >> 1) % NB][32 * (t & 1) * G::RSTR + koff]; };
-    auto vptr = [&](int t) { return &sV[(t >> 1) % NB][32 * (t & 1) * G::TSTR + voff]; };
-    auto stage = [&](int st) {
-        if (loader) {
-            dmaK.issue(kbase, 64 * st, a.T, sK[st % NB]);
-            dmaV.issue(vbase, 64 * st, a.T, sV[st % NB]);
-        }
-    };
-    // S'^T of tile t, un-pipelined (prologue and the rescale path): accumulator starts from `init`. Fenced per MFMA so that the
-    // fragments of these rarely executed paths do not all sit in registers at once (the kernel is at the 256-register cap).
-    auto chain_s = [&](int t, f32x16& s, float init) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = init;
-        const bf16_t* kp = kptr(t);
-#pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            s = mfma32(*(const bf16x8*)(kp + 16 * ks), qf[ks], s);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto chain_pv = [&](int t, const bf16x8& p0, const bf16x8& p1) {
-        const bf16_t* vp = vptr(t);
-#pragma unroll
-        for (int d = 0; d < G::DB; ++d) {
-            o[d] = mfma32(tr_frag<G::TSTR>(vp, 0, 32 * d), p0, o[d]);
-            o[d] = mfma32(tr_frag<G::TSTR>(vp, 16, 32 * d), p1, o[d]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto mask_tail = [&](int t, f32x16& s) {  // keys beyond T (last tile only): P = 0
-        if (32 * t + 32 > a.T) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = (32 * t + acc_row(r, lane) >= a.T) ? NEG_BIG : s[r];
-        }
-    };
-    auto row_max = [&](const f32x16& s) {
-        mfma_result_fence();
-        float pmax = vmax3(s[0], s[1], s[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) pmax = vmax3(pmax, s[r], s[r + 1]);
-        return half_max(vmax2(pmax, s[15]));
-    };
-    // element r of tile t: S' -> exp2, row sum, dropout (x 1/keep in the epilogue); result back in s[r]
-    uint32_t w0 = 0, w1 = 0;
-    auto element = [&](int t, f32x16& s, int r) {
-        const int g = r >> 2, j = r & 3;
-        if constexpr (DROP) {
-            if (j == 0) {
-                const uint32_t x0 = dbase + (uint32_t)(16 * t + 4 * g) * ADROP_K2;
-                w0 = mix1(x0);
-                w1 = mix1(x0 + ADROP_K2);
-            }
-        }
-        const float p = fast_exp2(s[r]);
-        lsum += p;
-        if constexpr (DROP) {
-            const bool keep = __builtin_amdgcn_ubfe(j < 2 ? w0 : w1, (j & 1) ? sh_odd : sh_even, 8u) >= a.adrop.thresh8;
-            s[r] = keep ? p : 0.f;
-        } else {
-            s[r] = p;
-        }
-    };
-
-    // ---- prologue: stages 0 and 1 staged, tile 0 fixes the reference maximum
-    stage(0);
-    if (ns > 1) stage(1);
-    touch(qf);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    KS_MARK(7);
-    f32x16 sA, sB;
-    chain_s(0, sA, 0.f);
-    mask_tail(0, sA);
-    m2 = row_max(sA);  // tile 0 relative to itself: pmax = 0 (initial value)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sA[r] -= m2;
-    bf16x8 p0, p1;  // P^T of the previous tile (B operand of its P . V), pending; zeros before tile 0 (its P . V adds nothing)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) p0[j] = p1[j] = (bf16_t)0.f;
-
-    // One iteration: tile t's scores are in `s` (relative to m2), tile t - 1's P^T pending in (p0, p1); issues P.V of t - 1 and
-    // the score chain of t + 1 into `s2` around the element-wise stage of t.
-    constexpr int NSLOT = 2 * G::KS, LA = 3;
-    float pmax = 0.f;  // row maximum of the tile about to be processed, relative to m2 (computed inside the previous iteration)
-    auto iteration = [&](int t, f32x16& s, f32x16& s2) {
-        KS_MARK(0);
-        const int tp = max(t - 1, 0);
-        mask_tail(t, s);
-        // reference check (T13): a score above m2 + THR moves the reference; everything still at the old reference is scaled
-        // exactly once: O, the row sum, the pending P^T of tile t - 1 and the scores of this tile (tile t + 1's chain starts
-        // from the new reference below)
-        if (!__all(pmax <= FWD2_THR)) {
-            const float mn = m2 + fmaxf(pmax, 0.f);
-            const float alpha = fast_exp2(m2 - mn);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {  // the pending P^T of tile t - 1 is still at the old reference: scale it as well
-                p0[j] = (bf16_t)((float)p0[j] * alpha);
-                p1[j] = (bf16_t)((float)p1[j] * alpha);
-            }
-#pragma unroll
-            for (int d = 0; d < G::DB; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            lsum *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] -= mn - m2;
-            m2 = mn;
-        }
-        KS_MARK(1);
-        unsigned ka = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)kptr(t + 1);
-        unsigned va = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)vptr(tp);
-        asm volatile("" : "+v"(ka), "+v"(va));  // opaque bases: fragment addresses stay immediates
-        const bf16_t* vp = (const bf16_t*)(const __attribute__((address_space(3))) bf16_t*)(uintptr_t)va;
-        // slot m < KS: S'^T chain of tile t + 1 over the head dimension (first, so that its row maximum can be taken in the
-        // later slots); m >= KS: O^T += V^T P^T of tile t - 1 (d block (m - KS) >> 1, k-step m & 1)
-        auto frag = [&](int m) {
-            if (m >= G::KS) return tr_frag<G::TSTR>(vp, 16 * (m & 1), 32 * ((m - G::KS) >> 1));
-            return *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(ka + 32u * (unsigned)m);
-        };
-        bf16x8 fr[NSLOT];
-#pragma unroll
-        for (int m = 0; m < LA; ++m) fr[m] = frag(m);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s2[r] = -m2;
-        bf16x8 n0, n1;
-        float mx = 0.f;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < NSLOT; ++m) {
-            if (m + LA < NSLOT) fr[m + LA] = frag(m + LA);
-            if (m < G::KS) s2 = mfma32(fr[m], qf[m], s2);
-            else o[(m - G::KS) >> 1] = mfma32(fr[m], (m & 1) ? p1 : p0, o[(m - G::KS) >> 1]);
-            // 16 element slices + 2 packing slices dealt over the slots of this iteration
-#pragma unroll
-            for (int it = m * 18 / NSLOT; it < (m + 1) * 18 / NSLOT; ++it) {
-                if (it < 16) element(t, s, it);
-                else if (it == 16) n0 = acc_to_b_pk(s, 0);
-                else n1 = acc_to_b_pk(s, 1);
-            }
-            // row maximum of tile t + 1 (its chain ended KS slots ago... two slots ago at the earliest)
-            if (m == G::KS + 2) {
-                mfma_result_fence();
-                mx = vmax3(s2[0], s2[1], s2[2]);
-                mx = vmax3(mx, s2[3], s2[4]);
-                mx = vmax3(mx, s2[5], s2[6]);
-            } else if (m == G::KS + 4) {
-                mx = vmax3(mx, s2[7], s2[8]);
-                mx = vmax3(mx, s2[9], s2[10]);
-                mx = vmax3(mx, s2[11], s2[12]);
-            } else if (m == G::KS + 6) {
-                mx = vmax3(mx, s2[13], s2[14]);
-                pmax = half_max(vmax2(mx, s2[15]));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        p0 = n0;
-        p1 = n1;
-        KS_MARK(2);
-    };
-    // stage bookkeeping around iteration t (odd t = 2 k + 1 reads K of stage k + 1 for the first time): wait for that stage,
-    // barrier (every wave is past V of stage k - 1), then stage k + 2 goes into the freed buffer
-    auto sync_stage = [&](int t) {
-        if ((t & 1) && (t >> 1) + 1 < ns) {
-            KS_MARK(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            KS_MARK(3);
-            __builtin_amdgcn_s_barrier();
-            KS_MARK(4);
-            if ((t >> 1) + 2 < ns) stage((t >> 1) + 2);
-            KS_MARK(5);
-        }
-    };
-    if (nt > 1) {
-        sync_stage(1);  // tile 2 (stage 1) is read by iteration 1; iteration 0 below needs tile 1 only
-    }
-    for (int t = 0; t < nt; t += 2) {
-        iteration(t, sA, sB);
-        if (t + 1 < nt) {
-            if (t + 1 > 1) sync_stage(t + 1);
-            iteration(t + 1, sB, sA);
-        }
-    }
-    KS_MARK(0);
-    chain_pv(nt - 1, p0, p1);
-    KS_MARK(6);
-
-    const float ltot = lsum + __shfl_xor(lsum, 32);
-    const float inv = (DROP ? a.adrop.inv_keep : 1.0f) / ltot;
-    if (q < a.T) {
-        if (h2 == 0) a.lse2[((size_t)b * a.H + h) * a.T + q] = m2 + log2f(ltot);
-        bf16_t* orow = a.o + ((size_t)b * a.T + q) * a.ldo + h * DP;
-#pragma unroll
-        for (int d = 0; d < G::DB; ++d)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                bf16x4 w, wl;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = o[d][4 * rq + j] * inv;
-                    w[j] = (bf16_t)v;
-                    wl[j] = aux_plane(v, w[j], a.lo_f16);
-                }
-                *(bf16x4*)(orow + 32 * d + 8 * rq + 4 * h2) = w;
-                if (a.o_lo) *(bf16x4*)(a.o_lo + (orow - a.o) + 32 * d + 8 * rq + 4 * h2) = wl;
-            }
-    }
-    KS_MARK(6);
-    KS_END(1500, wave, lane);
-}
-
-// ------------------------------------------------------------------------------------------
 // Forward with FOUR waves per SIMD (round 3). Why: in the kernels above a wave runs S -> softmax -> P.V one after the other, ~260
 // instructions per 32-key tile at ~10 cycles each (in-kernel timeline, tools/kprof.py: MFMA chains, LDS and exp latencies are exposed
 // because a SIMD holds only two such waves - each needs ~230 registers), and the matrix pipe is busy 47 % of the time. Here the tile
@@ -1482,17 +1209,6 @@ template <int DP, bool DROP, bool DIAG>
 int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
     dim3 grid(((a.T + 32 * FWD_WAVES - 1) / (32 * FWD_WAVES)) * a.H * a.B);
     prof_begin(PROF_ATTN_FWD, s);
-    // dev switch: the software-pipelined kernel. Measured a tie to +3 % SLOWER than attn_fwd_kernel at the 112-image shape
-    // (995 vs 965 us): its slots run at the vector-issue floor, but the two waves of a SIMD no longer cover each other's
-    // serial phases, and cycles saved come back as a lower clock (1.78-1.97 GHz under this load)
-    static const bool v2 = std::getenv("V1T_ATTN_FWD_V2") != nullptr;
-    if constexpr (DP >= 128 && !DIAG) {
-        if (v2) {
-            hipLaunchKernelGGL((attn_fwd2_kernel<DP, DROP>), grid, dim3(64 * FWD_WAVES), 0, s, a);
-            prof_end(PROF_ATTN_FWD, s);
-            return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
-        }
-    }
     static const bool v3 = std::getenv("V1T_ATTN_FWD_V3") != nullptr;  // dev: the 16-wave S / PV role kernel
     if constexpr (DP >= 128 && !DIAG) {
         if (v3) {
