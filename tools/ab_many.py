@@ -37,6 +37,15 @@ def bwd(lb):
 
 
 fwd(libs[0])
+torch.cuda.synchronize()
+o_ref, lse_ref = o.float().clone(), lse.clone()
+for i, lb in enumerate(libs[1:], 1):  # same inputs, same dropout stream: the builds must agree
+    o.zero_()
+    lse.zero_()
+    fwd(lb)
+    torch.cuda.synchronize()
+    print(f"{os.path.basename(paths[i])}: forward vs {os.path.basename(paths[0])}: max |dO| {float((o.float() - o_ref).abs().max()):.3e} (|o| max {float(o_ref.abs().max()):.3f}), "
+          f"max |dlse2| {float((lse - lse_ref).abs().max()):.3e}")
 res = {(i, k): [] for i in range(len(libs)) for k in ("fwd", "bwd")}
 for r in range(5):
     for i, lb in enumerate(libs):
@@ -50,6 +59,11 @@ for r in range(5):
             torch.cuda.synchronize()
             if r > 0:
                 res[(i, k)].append(e0.elapsed_time(e1) / 4 * 1e3)
+for i, lb in enumerate(libs):  # checksum of the backward's output (compare across builds / environment switches)
+    dqkv.zero_()
+    bwd(lb)
+    torch.cuda.synchronize()
+    print(f"{os.path.basename(paths[i])}: dqkv checksum {float(dqkv.double().abs().sum()):.9e} nan {int(torch.isnan(dqkv.float()).sum())}")
 for i, pth in enumerate(paths):
     f, bw = sorted(res[(i, "fwd")]), sorted(res[(i, "bwd")])
     print(f"{os.path.basename(pth):28s} fwd median {f[len(f) // 2]:8.1f} us   bwd (delta + dK/dV + dQ) median {bw[len(bw) // 2]:8.1f} us")
