@@ -74,7 +74,8 @@ long long v1t_vit_shadow_bytes(const v1t_vit* h);                 /* bf16 padded
 long long v1t_vit_workspace_bytes(const v1t_vit* h, int batch, int save_for_backward);
 long long v1t_vit_scratch_bytes(const v1t_vit* h, int batch);     /* backward-only scratch */
 /* byte offset of a named intermediate inside the forward workspace (tests / rollout): names
- * "x0","xa","xm","z1","qkv","o","lse2","z2","hpre","hact","beta"; returns <0 if unknown */
+ * "x0","xa","xm","z1","qkv","o","lse2","z2","hpre","hact","beta"; returns <0 if unknown. "o" / "hact" are the bf16 planes of
+ * the attention output / GELU output: zero-sized (never written) in plans whose backward reads the forward's fp16 planes */
 long long v1t_vit_workspace_offset(const v1t_vit* h, int batch, int save_for_backward, const char* name, int block);
 
 /* refresh the shadow from the fp32 arena (after an optimizer step / load_state_dict) */

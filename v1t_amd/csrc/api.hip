@@ -96,6 +96,17 @@ struct WsLayout {
     long long total;
 };
 
+// V1T_NOSPLIT=<mask> (dev, numerics ablation): bit 0/1/2/3 runs QKV / proj / FC1 / FC2 of the forward in plain bf16
+static const int g_nosplit = std::getenv("V1T_NOSPLIT") ? atoi(std::getenv("V1T_NOSPLIT")) : 0;
+// Operand format of the forward linear layers (patch projection, QKV, proj, FC1, FC2): fp16 planes + one fp16 MFMA per
+// step (default; 0.28 of the 1e-3 parity bound on the default V1T), or V1T_FWD_BF16X3=1 (dev, numerics ablation): bf16
+// hi + lo planes and three MFMAs (0.07 of the bound, 2.4x the GEMM time). The second plane of every forward activation /
+// weight holds the one or the other; the bf16 "hi" planes are what the backward reads (except the
+// attention output / GELU output in fp16 mode: x16_attn_out / x16_gelu_out below).
+static const int g_fwd_f16 = (std::getenv("V1T_FWD_BF16X3") && atoi(std::getenv("V1T_FWD_BF16X3"))) ? 0 : 1;
+static bool x16_attn_out(const v1t_vit* h, long long R);
+static bool x16_gelu_out(const v1t_vit* h, long long R);
+
 WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
     WsLayout w;
     const long long R = (long long)B * h->T;
@@ -126,7 +137,7 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
     w.xo = take(R * h->DP * 4) - b0;
     w.z1 = take(R * h->DP * 2) - b0;
     w.qkv = take(R * 3 * h->HDP * 2) - b0;
-    w.o = take(R * h->HDP * 2) - b0;
+    w.o = take(x16_attn_out(h, R) ? 0 : R * h->HDP * 2) - b0;  // no bf16 plane where the backward reads the fp16 one
     w.lse2 = take((long long)B * h->H * h->T * 4) - b0;
     w.mean1 = take(R * 4) - b0;
     w.rstd1 = take(R * 4) - b0;
@@ -134,7 +145,7 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
     w.mean2 = take(R * 4) - b0;
     w.rstd2 = take(R * 4) - b0;
     w.hpre = take((R + 127) / 128 * 128 * h->MP * 2) - b0;  // gelu' in accumulator-fragment order (full 128-row tiles)
-    w.hact = take(R * h->MP * 2) - b0;
+    w.hact = take(x16_gelu_out(h, R) ? 0 : R * h->MP * 2) - b0;
     w.z1_lo = take(R * h->DP * 2) - b0;
     w.o_lo = take(R * h->HDP * 2) - b0;
     w.z2_lo = take(R * h->DP * 2) - b0;
@@ -179,6 +190,18 @@ TnPlan tn_plan(const v1t_vit* h, long long R) {
     return p;
 }
 
+// The attention output and the GELU output exist as two 16-bit planes: bf16 (the X operand of the weight-gradient GEMMs dWo / dW2 and of
+// the row constants) and fp16 (the A operand of the forward's projection / FC2 GEMM). Where the weight-gradient kernel can convert its X
+// fragments (gemm_tn_takes_f16_x) the bf16 plane is never written: the backward reads the fp16 one (237 + 190 MB less per block and
+// 112-image step at the default shape).
+static const bool g_keep_bf16 = std::getenv("V1T_KEEP_BF16_PLANES") != nullptr;  // dev (A/B): write and read the bf16 planes as before
+static bool x16_attn_out(const v1t_vit* h, long long R) {
+    return !g_keep_bf16 && g_fwd_f16 && !(g_nosplit & 2) && gemm_tn_takes_f16_x(h->DP, h->HDP, tn_plan(h, R).mc_proj);
+}
+static bool x16_gelu_out(const v1t_vit* h, long long R) {
+    return !g_keep_bf16 && g_fwd_f16 && !(g_nosplit & 8) && gemm_tn_takes_f16_x(h->DP, h->MP, tn_plan(h, R).mc_fc2);
+}
+
 ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     ScratchLayout s;
     const long long R = (long long)B * h->T;
@@ -221,13 +244,6 @@ DropCfg make_drop(bool training, float p, uint64_t seed, uint32_t stream) {
     return d;
 }
 
-// V1T_NOSPLIT=<mask> (dev, numerics ablation): bit 0/1/2/3 runs QKV / proj / FC1 / FC2 of the forward in plain bf16
-static const int g_nosplit = std::getenv("V1T_NOSPLIT") ? atoi(std::getenv("V1T_NOSPLIT")) : 0;
-// Operand format of the forward linear layers (patch projection, QKV, proj, FC1, FC2): fp16 planes + one fp16 MFMA per
-// step (default; 0.28 of the 1e-3 parity bound on the default V1T), or V1T_FWD_BF16X3=1 (dev, numerics ablation): bf16
-// hi + lo planes and three MFMAs (0.07 of the bound, 2.4x the GEMM time). The second plane of every forward activation /
-// weight holds the one or the other; the bf16 "hi" planes are what the backward reads either way.
-static const int g_fwd_f16 = (std::getenv("V1T_FWD_BF16X3") && atoi(std::getenv("V1T_FWD_BF16X3"))) ? 0 : 1;
 // LayerNorm followed by the GEMM that reads it: one fused A-stationary launch where the shape allows (gemm.h, launch_ln_gemm;
 // fp16 operands, K = DP <= 160, N % 128 == 0), else the two kernels. V1T_LN_FUSE=0 (dev): always the two kernels.
 static const int g_ln_fuse = (std::getenv("V1T_LN_FUSE") && !atoi(std::getenv("V1T_LN_FUSE"))) ? 0 : 1;
@@ -671,6 +687,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
             CHECK(launch_bmlp_fwd(ba, s));
         }
 
+    const bool x16o = x16_attn_out(h, R), x16a = x16_gelu_out(h, R);  // only the fp16 planes of o / gelu(h) are written
     for (int k = 0; k < h->NB; ++k) {
         const BlockOff& b = h->blk[k];
         char* wb = ws + (save ? k : 0) * w.blk_stride;
@@ -697,7 +714,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         CHECK(ln_then_gemm(l1, g, EPI_BF16, s));
 
         AttnArgs at{};
-        at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = o; at.ldo = HDP; at.o_lo = (bf16_t*)(wb + w.o_lo); at.lo_f16 = g_fwd_f16; at.lse2 = (float*)(wb + w.lse2);
+        at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = x16o ? nullptr : o; at.ldo = HDP; at.o_lo = (bf16_t*)(wb + w.o_lo); at.lo_f16 = g_fwd_f16; at.lse2 = (float*)(wb + w.lse2);
         at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
         at.adrop = make_adrop(train, h->c.t_dropout, seed, 8 * k + 0);
         CHECK(launch_attn_fwd(at, h->HEP, s));
@@ -722,7 +739,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         g.A_lo = (const bf16_t*)(wb + w.z2_lo); g.B_lo = (const bf16_t*)(sh + b.s_fc1_lo); g.C2_lo = (bf16_t*)(wb + w.hact_lo);
         if (g_nosplit & 4) g.A_lo = g.B_lo = nullptr;
         fwd_operands(g);
-        g.C2 = hact; g.ldc2 = MP; g.bias = b.s_fc1b >= 0 ? (const float*)(sh + b.s_fc1b) : nullptr;
+        g.C2 = x16a ? nullptr : hact; g.ldc2 = MP; g.bias = b.s_fc1b >= 0 ? (const float*)(sh + b.s_fc1b) : nullptr;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
         CHECK(ln_then_gemm(l2, g, EPI_BIAS_GELU, s));
 
@@ -774,6 +791,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
     if (h->inject && hipMemsetAsync(dbeta, 0, (size_t)h->NB * B * DP * 4, s) != hipSuccess) return V1T_ERR_LAUNCH;
     const TnPlan tp = tn_plan(h, R);
     float* slab = tp.slab ? (float*)(sc + sl.slab) : nullptr;
+    const bool x16o = x16_attn_out(h, R), x16a = x16_gelu_out(h, R);  // the forward left only the fp16 planes of o / gelu(h)
 
     const float* gin = gout;
     if (h->NB > 0) {
@@ -800,7 +818,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
 
         // ---- MLP branch: dW2 += dy^T hact
         GemmTNArgs t{};
-        t.Y = dy; t.ldy = DP; t.X = hact; t.ldx = MP; t.M = R; t.NY = DP; t.NX = MP; t.dW = grads + b.fc2; t.ldw = M;
+        t.Y = dy; t.ldy = DP; t.X = x16a ? (const bf16_t*)(wb + w.hact_lo) : hact; t.x_f16 = x16a; t.ldx = MP; t.M = R; t.NY = DP; t.NX = MP; t.dW = grads + b.fc2; t.ldw = M;
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = MP; t.xseg_valid = M; t.alpha = 1.f;
         t.m_chunk = tp.mc_fc2; t.slab = slab;
         CHECK(launch_gemm_tn(t, s));
@@ -835,7 +853,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
 
         // ---- attention branch: dWo += dy^T o
         t = GemmTNArgs{};
-        t.Y = dy; t.ldy = DP; t.X = o; t.ldx = HDP; t.M = R; t.NY = DP; t.NX = HDP; t.dW = grads + b.proj; t.ldw = h->HD;
+        t.Y = dy; t.ldy = DP; t.X = x16o ? (const bf16_t*)(wb + w.o_lo) : o; t.x_f16 = x16o; t.ldx = HDP; t.M = R; t.NY = DP; t.NX = HDP; t.dW = grads + b.proj; t.ldw = h->HD;
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->HEP; t.xseg_valid = h->HE; t.alpha = 1.f;
         t.m_chunk = tp.mc_proj; t.slab = slab;
         CHECK(launch_gemm_tn(t, s));
@@ -844,7 +862,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         g.A = dy; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_proj_t); g.ldb = DP; g.M = R; g.N = HDP; g.K = DP; g.C = dO; g.ldc = HDP;
         CHECK(launch_gemm_nt(g, EPI_BF16, s));
         AttnArgs at{};
-        at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = (bf16_t*)o; at.ldo = HDP; at.lse2 = (float*)(wb + w.lse2);
+        at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = x16o ? (bf16_t*)(wb + w.o_lo) : (bf16_t*)o; at.o_f16 = x16o; at.ldo = HDP; at.lse2 = (float*)(wb + w.lse2);
         at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
         at.adrop = make_adrop(train, h->c.t_dropout, seed, 8 * k + 0);
         at.dO = dO; at.lddo = HDP; at.delta = delta; at.dqkv = dqkv; at.lddqkv = 3 * HDP;

@@ -8,7 +8,8 @@
 
 struct AttnArgs {
     const bf16_t* qkv; int ldqkv;  // [rows][3*H*DP]: q | k | v, each H heads of DP (zero padded) columns
-    bf16_t* o; int ldo;            // [rows][H*DP]
+    bf16_t* o; int ldo;            // [rows][H*DP]; forward: may be nullptr when only the second plane is wanted; backward: fp16 values when o_f16
+    int o_f16;
     bf16_t* o_lo;                  // forward only: second plane of o or nullptr: bf16 residual o - float(bf16(o)), or fp16(o) when lo_f16
     int lo_f16;
     float* lse2;                   // [B][H][T]  log2-domain: max + log2(sum)

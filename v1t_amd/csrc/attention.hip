@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     const float inv = (DROP ? a.adrop.inv_keep : 1.0f) / ltot;
     if (q < a.T) {
         if (h2 == 0) a.lse2[((size_t)b * a.H + h) * a.T + q] = m2 + log2f(ltot);
-        bf16_t* orow = a.o + ((size_t)b * a.T + q) * a.ldo + h * DP;
+        const size_t orow = ((size_t)b * a.T + q) * a.ldo + h * DP;
 #pragma unroll
         for (int d = 0; d < G::DB; ++d)
 #pragma unroll
@@ -523,8 +523,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
                     w[j] = (bf16_t)v;
                     wl[j] = aux_plane(v, w[j], a.lo_f16);
                 }
-                *(bf16x4*)(orow + 32 * d + 8 * rq + 4 * h2) = w;
-                if (a.o_lo) *(bf16x4*)(a.o_lo + (orow - a.o) + 32 * d + 8 * rq + 4 * h2) = wl;
+                if (a.o) *(bf16x4*)(a.o + orow + 32 * d + 8 * rq + 4 * h2) = w;
+                if (a.o_lo) *(bf16x4*)(a.o_lo + orow + 32 * d + 8 * rq + 4 * h2) = wl;
             }
     }
 }
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(128 * F3_PAIRS, 4) void attn_fwd3_kernel(AttnArgs a
         }
         if (q < a.T) {
             const float inv = sInv[pr][lane];
-            bf16_t* orow = a.o + ((size_t)b * a.T + q) * a.ldo + h * DP;
+            const size_t orow = ((size_t)b * a.T + q) * a.ldo + h * DP;
 #pragma unroll
             for (int d = 0; d < G::DB; ++d)
 #pragma unroll
@@ -643,8 +643,8 @@ __global__ __launch_bounds__(128 * F3_PAIRS, 4) void attn_fwd3_kernel(AttnArgs a
                         w[jx] = (bf16_t)v;
                         wl[jx] = aux_plane(v, w[jx], a.lo_f16);
                     }
-                    *(bf16x4*)(orow + 32 * d + 8 * rq + 4 * h2) = w;
-                    if (a.o_lo) *(bf16x4*)(a.o_lo + (orow - a.o) + 32 * d + 8 * rq + 4 * h2) = wl;
+                    if (a.o) *(bf16x4*)(a.o + orow + 32 * d + 8 * rq + 4 * h2) = w;
+                    if (a.o_lo) *(bf16x4*)(a.o_lo + orow + 32 * d + 8 * rq + 4 * h2) = wl;
                 }
         }
         return;
@@ -796,8 +796,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, float* delt
         for (int c = sub; c < CH; c += 16) {
             const bf16x8 x = *(const bf16x8*)(po + 8 * c);
             const bf16x8 y = *(const bf16x8*)(pd + 8 * c);
+            if (a.o_f16) {  // kernel-uniform
+                const f16x8 xh = __builtin_bit_cast(f16x8, x);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
+                for (int j = 0; j < 8; ++j) acc += (float)xh[j] * (float)y[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
+            }
         }
     }
     acc += __shfl_xor(acc, 8);
@@ -1305,8 +1311,14 @@ __global__ __launch_bounds__(256) void attn_delta2_kernel(AttnArgs a, float* nls
         for (int c = sub; c < CH; c += 16) {
             const bf16x8 x = *(const bf16x8*)(po + 8 * c);
             const bf16x8 y = *(const bf16x8*)(pd + 8 * c);
+            if (a.o_f16) {  // kernel-uniform
+                const f16x8 xh = __builtin_bit_cast(f16x8, x);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
+                for (int j = 0; j < 8; ++j) acc += (float)xh[j] * (float)y[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
+            }
         }
     }
     acc += __shfl_xor(acc, 8);

@@ -33,6 +33,21 @@ DEVFN f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 // the predicted responses (DESIGN.md "Numerics"). The planes travel in bf16_t-typed buffers as raw 16-bit patterns.
 typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+// a fragment whose 16-bit lanes hold fp16 values (the forward's second planes) as bf16 operand: 8 conversions + 4 packed roundings
+DEVFN bf16x8 f16_frag_to_bf16(bf16x8 x) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    const f16x8 h = __builtin_bit_cast(f16x8, x);
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2_ v = {(float)h[2 * j], (float)h[2 * j + 1]};
+        const bf16x2_ b = __builtin_convertvector(v, bf16x2_);
+        r[2 * j] = b[0];
+        r[2 * j + 1] = b[1];
+    }
+    return r;
+}
 DEVFN f32x16 mfma32h(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }

@@ -57,7 +57,11 @@ struct GemmTNArgs {
     // optional fp32 scratch of gemm_tn_slab_bytes() bytes: partial tiles go there with plain stores and a
     // reduce kernel adds them into dW (float atomics run at ~1.3 TB/s chip-wide and bound this GEMM otherwise)
     float* slab;
+    // X holds fp16 values (the forward's second plane of the attention output / GELU output): converted to bf16 fragment by fragment.
+    // Only where gemm_tn_takes_f16_x() says so (the 160 x 128 workgroup shape, one X block per wave).
+    int x_f16;
 };
+bool gemm_tn_takes_f16_x(int NY, int NX, int m_chunk);
 size_t gemm_tn_slab_bytes(int M, int NY, int NX, int m_chunk);
 
 int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s);

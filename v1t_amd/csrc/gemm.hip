@@ -82,7 +82,7 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
                     acc[nb][r] = a;
                 } else if (ok) {
                     const bf16_t ah = (bf16_t)a;
-                    g.C2[(size_t)row * g.ldc2 + col] = ah;
+                    if (g.C2) g.C2[(size_t)row * g.ldc2 + col] = ah;
                     if (g.C2_lo) g.C2_lo[(size_t)row * g.ldc2 + col] = aux_plane(a, ah, g.f16);
                 }
             } else if constexpr (EPI == EPI_DGELU) {
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64 * NW, (EPI == EPI_BIAS_GELU && BK == 32 && NBLK 
     } else if constexpr (EPI == EPI_BIAS_GELU) {
         gemm_epilogue<NBLK, EPI, true>(g, acc, resv, m0, n0, wave, lane);  // gelu' (fragment order) written, activation left in acc
         __syncthreads();
-        staged_store(g.C2, g.ldc2, [](float v) { return (bf16_t)v; });
+        if (g.C2) staged_store(g.C2, g.ldc2, [](float v) { return (bf16_t)v; });
         if (g.C2_lo) {
             const int f16 = g.f16;
             staged_store(g.C2_lo, g.ldc2, [f16](float v) { return aux_plane(v, (bf16_t)v, f16); });
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
         } else {
             f32x16 resv[NBLK];
             gemm_epilogue<NBLK, EPI_BIAS_GELU, true>(g, acc, resv, m0p, n0, wv, lane);  // gelu' written (fragment order), activation left in acc
-            staged_store(acc, g.C2, g.ldc2, n0, [](float v) { return (bf16_t)v; });
+            if (g.C2) staged_store(acc, g.C2, g.ldc2, n0, [](float v) { return (bf16_t)v; });
             if (g.C2_lo) staged_store(acc, g.C2_lo, g.ldc2, n0, [](float v) { return aux_plane(v, (bf16_t)v, 1); });
         }
         if (tn + nsplit < ntn) swrite(buf ^ 1);
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs g) {
 // buffered; rows past the end of the chunk are clamped for the fetch and masked in the 1-block operand.
 constexpr int TN2_ROWS = 64, TN2_STR = 160, TN2_CPR = TN2_STR / 8;
 
-template <int YB, int XB>
+template <int YB, int XB, bool XF16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs g) {
     constexpr int WY = (YB == 1) ? 4 : 1, WX = 4 / WY;
     constexpr int YW = 32 * YB * WY, XW = 32 * XB * WX;
@@ -762,6 +762,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs g) {
                     if (k0 + j >= valid) {
                         if constexpr (YB == 1) a[0][j] = 0; else b[0][j] = 0;
                     }
+            }
+            if constexpr (XF16) {
+#pragma unroll
+                for (int xb = 0; xb < XB; ++xb) b[xb] = f16_frag_to_bf16(b[xb]);
             }
 #pragma unroll
             for (int yb = 0; yb < YB; ++yb)
@@ -925,13 +929,17 @@ size_t gemm_tn_slab_bytes(int M, int NY, int NX, int m_chunk) {
     return 0;
 }
 
+bool gemm_tn_takes_f16_x(int NY, int NX, int m_chunk) { return m_chunk % TN2_ROWS == 0 && NY % 160 == 0 && NX % 128 == 0 && NY <= 320; }
+
 int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s) {
     if (a.NY % 32 != 0 || a.NX % 32 != 0 || a.m_chunk % 32 != 0 || (a.ldy % 8) || (a.ldx % 8)) return V1T_ERR_ARG;
+    if (a.x_f16 && !gemm_tn_takes_f16_x(a.NY, a.NX, a.m_chunk)) return V1T_ERR_UNSUPPORTED;
     if (a.M <= 0) return V1T_OK;
     const int gz = (a.M + a.m_chunk - 1) / a.m_chunk;
     if (a.m_chunk % TN2_ROWS == 0 && a.NY % 160 == 0 && a.NX % 128 == 0 && a.NY <= 320) {
         const int gx = a.NY / 160, gy2 = a.NX / 128;
-        hipLaunchKernelGGL((gemm_tn2_kernel<5, 1>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+        if (a.x_f16) hipLaunchKernelGGL((gemm_tn2_kernel<5, 1, true>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_tn2_kernel<5, 1>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
         if (a.slab) hipLaunchKernelGGL((tn_reduce_kernel<5, 1>), dim3(gx * gy2 * 20), dim3(256), 0, s, a, gx, gy2, gz);
         return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
     }
