@@ -757,6 +757,18 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
     return V1T_OK;
 }
 
+// dz = dY . W (fp32, g.C) followed by the backward of the LayerNorm in front of that linear layer: one kernel where the shape allows
+// (gemm.h, launch_gemm_ln_bwd: dz stays in the accumulators), else the GEMM and ln_bwd_kernel. V1T_LNBWD_UNFUSED=1 (dev, A/B): always two.
+static const bool g_lnbwd_unfused = std::getenv("V1T_LNBWD_UNFUSED") != nullptr;
+static int dx_then_ln_bwd(const GemmNTArgs& g, const LnBwdArgs& lb, hipStream_t s) {
+    if (!g_lnbwd_unfused) {
+        const int rc = launch_gemm_ln_bwd(g, lb, s);
+        if (rc != V1T_ERR_UNSUPPORTED) return rc;
+    }
+    const int rc = launch_gemm_nt(g, EPI_F32, s);
+    return rc != V1T_OK ? rc : launch_ln_bwd(lb, s);
+}
+
 int v1t_vit_backward(const v1t_vit* h, const float* arena, const void* shadow, const float* images, const float* behaviors,
                      int mouse_idx, int B, const void* workspace, void* scratch, long long scratch_bytes, int training,
                      uint64_t seed, const float* path_scale, const float* gout, float* grads, void* stream) {
@@ -839,7 +851,6 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         // dz2 = d_hpre . W1
         g = GemmNTArgs{};
         g.A = dhpre; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc1_t); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = dz; g.ldc = DP;
-        CHECK(launch_gemm_nt(g, EPI_F32, s));
         // LN2 backward: G = gin + dx; dy = dropout_bwd(G) for the projection output; dbo += colsum
         LnBwdArgs lb{};
         lb.dz = dz; lb.x = xm; lb.mean = (const float*)(wb + w.mean2); lb.rstd = (const float*)(wb + w.rstd2); lb.gamma = arena + b.ln2w;
@@ -848,7 +859,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         lb.drop_next = make_drop(train, h->c.t_dropout, seed, 8 * k + 1);
         lb.scale_next = path_scale ? path_scale + (size_t)(2 * k + 0) * B : nullptr;
         lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
-        CHECK(launch_ln_bwd(lb, s));
+        CHECK(dx_then_ln_bwd(g, lb, s));
         gin = G;
 
         // ---- attention branch: dWo += dy^T o
@@ -879,7 +890,6 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         // dz1 = dqkv . Wqkv
         g = GemmNTArgs{};
         g.A = dqkv; g.lda = 3 * HDP; g.B = (const bf16_t*)(sh + b.s_qkv_t); g.ldb = 3 * HDP; g.M = R; g.N = DP; g.K = 3 * HDP; g.C = dz; g.ldc = DP;
-        CHECK(launch_gemm_nt(g, EPI_F32, s));
         // LN1 backward: G = G + dx; d(beta_k) = token sums; dy for block k-1's FC2 output
         lb = LnBwdArgs{};
         lb.dz = dz; lb.x = xa; lb.mean = (const float*)(wb + w.mean1); lb.rstd = (const float*)(wb + w.rstd1); lb.gamma = arena + b.ln1w;
@@ -892,7 +902,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
             lb.scale_next = path_scale ? path_scale + (size_t)(2 * (k - 1) + 1) * B : nullptr;
         }
         lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
-        CHECK(launch_ln_bwd(lb, s));
+        CHECK(dx_then_ln_bwd(g, lb, s));
         // every gradient of block k's attention / MLP parameters is now in `grads` (its BehaviorMLP's follow at the end)
         if (block_done && block_done[k] && hipEventRecord((hipEvent_t)block_done[k], s) != hipSuccess) return V1T_ERR_LAUNCH;
     }

@@ -105,6 +105,21 @@ DEVFN bf16x8 lds_tr_frag_nat(const bf16_t* img, int stride, int k0, int m0, int 
     return r;
 }
 
+// ---- raw buffer access ------------------------------------------------------------------
+// A buffer resource over [p, p + bytes): loads / stores take a 32-bit per-lane byte offset (one address register instead of a 64-bit
+// pair per access, the base sits in scalar registers) and the hardware range-checks offset + immediate against `bytes`: an
+// out-of-range load returns 0, an out-of-range store is dropped - masked rows cost no branch (offset | BUF_OOB).
+constexpr uint32_t BUF_OOB = 0x80000000u;
+DEVFN __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+DEVFN float buf_load_f32(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+DEVFN void buf_store_f32(__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, soff, 0);
+}
+
 // ---- LDS-DMA (global_load_lds) --------------------------------------------------------
 // One LDS-DMA wave-instruction: 16 B per lane from each lane's own global address to lds_base + 16*lane.
 // Issued through inline asm ON PURPOSE: for the builtin, hipcc cannot tell which LDS buffer a pending DMA

@@ -70,3 +70,7 @@ int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s);
 // not read, l.z (bf16 plane), l.mean, l.rstd and l.xout are written, l.z_lo is not. V1T_ERR_UNSUPPORTED: use ln_fwd + gemm_nt.
 struct LnFwdArgs;
 int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t s);
+// dz = A . B^T (bf16 operands, N = l.DP <= 160) consumed in registers by the LayerNorm backward `l` describes (l.dz is not read; same
+// outputs as launch_gemm_nt(EPI_F32) + launch_ln_bwd). V1T_ERR_UNSUPPORTED: use those two.
+struct LnBwdArgs;
+int launch_gemm_ln_bwd(const GemmNTArgs& g, const LnBwdArgs& l, hipStream_t s);

@@ -866,6 +866,244 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTNArgs g, int gx, in
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// dX GEMM of a branch's first linear layer fused with the backward of the LayerNorm in front of it (round 3): dz = A . B^T never goes to
+// HBM (118 MB written and read back per LayerNorm and 112-image step at the default shape). A 128-row x DP tile holds complete rows, so
+// everything ln_bwd_kernel (elementwise.hip) does happens on the accumulators: row statistics over the 32 lanes of a half-wave x NBLK
+// blocks (DPP butterfly), G = gin + rstd (dz gamma - mean(dz gamma) - xhat mean(dz gamma xhat)), the column partials for dgamma / dbeta /
+// the injection gradient / the next branch's bias (one in-lane sum over a lane's 16 rows per block, then half-waves, waves through LDS,
+// one atomic per column and workgroup) and the dropout-backward / bf16 cast of G for the next (earlier) branch, staged through LDS into
+// 16-B row stores. Four rows at a time (one accumulator register group): x and gin are read with the accumulator layout's 4-B accesses
+// (128 B per half-wave and row), 20 + 20 loads in flight per group, so the live set stays at the accumulators + one row group.
+// Tiles are image-aligned (grid = row blocks of an image x images) because the injection gradient is per image.
+DEVFN float half32_sum(float v) {  // sum over the 32 lanes of a half-wave, returned to every lane
+    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);  // row_mirror: every lane holds the sum of its 16-lane row
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // rows 0 <-> 1, 2 <-> 3
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int NBLK, bool NEXT>
+__global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(GemmNTArgs g, LnBwdArgs l) {
+    constexpr int NW = 4, BK = 32, BM = 32 * NW, NT = 64 * NW;
+    constexpr int LS = BK + 8, KC = BK / 8;
+    constexpr int A_ITERS = BM * KC / NT;
+    constexpr int BN = 32 * NBLK;
+    constexpr int B_CHUNKS = BN * KC;
+    constexpr int B_ITERS = (B_CHUNKS + NT - 1) / NT;
+    constexpr int CS = BN + 8;  // staging row stride of the bf16 output (elements)
+    constexpr int SMEM = (2 * BM * LS + 2 * BN * LS) > (BM * CS) ? (2 * BM * LS + 2 * BN * LS) : (BM * CS);
+    __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
+    static_assert(4 * BN * 4 <= 32 * CS * 2, "column partials fit the wave's staging region");
+    bf16_t (*sA)[BM * LS] = (bf16_t (*)[BM * LS])smem;
+    bf16_t (*sB)[BN * LS] = (bf16_t (*)[BN * LS])(smem + 2 * BM * LS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntb = (l.T + BM - 1) / BM;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / ntb, t0 = (lid % ntb) * BM;
+    const size_t row0 = (size_t)b * l.T;
+    const int nk = g.K / BK;
+
+    u32x4 ra[A_ITERS], rb[B_ITERS];
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int c = tid + NT * i, row = c / KC, kc = c % KC;
+            ra[i] = *(const u32x4*)(g.A + (row0 + min(t0 + row, l.T - 1)) * g.lda + k0 + 8 * kc);  // rows past the image: clamped, masked below
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + NT * i, row = c / KC, kc = c % KC;
+            if (c < B_CHUNKS) rb[i] = *(const u32x4*)(g.B + (size_t)row * g.ldb + k0 + 8 * kc);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int c = tid + NT * i, row = c / KC, kc = c % KC;
+            *(u32x4*)(&sA[buf][row * LS + 8 * kc]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + NT * i, row = c / KC, kc = c % KC;
+            if (c < B_CHUNKS) *(u32x4*)(&sB[buf][row * LS + 8 * kc]) = rb[i];
+        }
+    };
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int frag_off = (lane & 31) * LS + 8 * (lane >> 5);
+    auto ktile = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const bf16x8 a = *(const bf16x8*)(&sA[buf][32 * wave * LS + frag_off + 16 * ks]);
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) {
+                const bf16x8 bb = *(const bf16x8*)(&sB[buf][32 * nb * LS + frag_off + 16 * ks]);
+                acc[nb] = mfma32(a, bb, acc[nb]);
+            }
+        }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int buf = kt & 1;
+        gload(kt + 1);
+        ktile(buf);
+        swrite(buf ^ 1);
+        __syncthreads();
+    }
+    ktile((nk - 1) & 1);
+    __syncthreads();  // every wave is done with the operand tiles: the bf16 staging below reuses them
+
+    // ---- LayerNorm backward on the accumulators: column = 32 nb + (lane & 31), row = 32 wave + acc_row(r, lane)
+    const float snext = l.scale_next ? l.scale_next[b] : 1.f;
+    const float invD = 1.0f / (float)l.D;
+    float gam[NBLK], adg[NBLK], adb[NBLK], ainj[NBLK], abn[NBLK];
+    bool cok[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+        const int col = 32 * nb + (lane & 31);
+        cok[nb] = col < l.D;
+        gam[nb] = cok[nb] ? l.gamma[col] : 0.f;
+        adg[nb] = adb[nb] = ainj[nb] = abn[nb] = 0.f;
+    }
+    if (t0 + BM > l.T) {  // ragged last tile of the image (workgroup-uniform): its clamped rows contribute nothing
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool rok = t0 + 32 * wave + acc_row(r, lane) < l.T;
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) acc[nb][r] = rok ? acc[nb][r] : 0.f;
+        }
+    }
+    bf16_t* st = smem + wave * 32 * CS;
+    constexpr int RPG = 4;  // accumulator rows per group: 8 NBLK loads in flight per group
+    // dropout of the next branch without a branch: threshold 0 keeps everything (hash >= 0), factor 1
+    const uint32_t dthr = (NEXT && l.drop_next.thresh) ? l.drop_next.thresh : 0u;
+    const float dinv = (NEXT && l.drop_next.thresh) ? l.drop_next.inv_keep : 1.0f;
+    // the image's rows as buffers: rows past the image read 0 (x, gin, mean, rstd = 0: G = 0 there) and their stores are dropped
+    const uint32_t img_bytes = (uint32_t)l.T * (uint32_t)l.DP * 4u;
+    const __amdgpu_buffer_rsrc_t x_r = buf_rsrc(l.x + row0 * l.DP, img_bytes), gin_r = buf_rsrc(l.gin + row0 * l.DP, img_bytes);
+    const __amdgpu_buffer_rsrc_t gout_r = buf_rsrc(l.gout + row0 * l.DP, img_bytes);
+    const __amdgpu_buffer_rsrc_t mean_r = buf_rsrc(l.mean + row0, (uint32_t)l.T * 4u), rstd_r = buf_rsrc(l.rstd + row0, (uint32_t)l.T * 4u);
+#pragma unroll
+    for (int rg = 0; rg < 16 / RPG; ++rg) {
+        // one row group at a time: without the fence the scheduler hoists every group's 40 loads to the top
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        float mean[RPG], rstd[RPG], xh[NBLK][RPG], gi[NBLK][RPG];
+        uint32_t trow[RPG], eoff[RPG];  // row inside the image, byte offset of (row, lane & 31) from the image's first row
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            trow[i] = (uint32_t)(t0 + 32 * wave + acc_row(RPG * rg + i, lane));
+            eoff[i] = (trow[i] * (uint32_t)l.DP + (uint32_t)(lane & 31)) * 4u;
+            if (trow[i] >= (uint32_t)l.T) eoff[i] |= BUF_OOB;
+            mean[i] = buf_load_f32(mean_r, trow[i] * 4u, 0);
+            rstd[i] = buf_load_f32(rstd_r, trow[i] * 4u, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int i = 0; i < RPG; ++i) {
+                xh[nb][i] = buf_load_f32(x_r, eoff[i], 128 * nb);
+                gi[nb][i] = buf_load_f32(gin_r, eoff[i], 128 * nb);
+            }
+        float s1[RPG], s2[RPG];
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            s1[i] = s2[i] = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) {
+                const float xc = (xh[nb][i] - mean[i]) * rstd[i];
+                xh[nb][i] = cok[nb] ? xc : 0.f;
+                const float dy = acc[nb][RPG * rg + i] * gam[nb];  // pad columns: gamma = 0
+                s1[i] += dy;
+                s2[i] = fmaf(dy, xh[nb][i], s2[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            s1[i] = half32_sum(s1[i]) * invD;
+            s2[i] = half32_sum(s2[i]) * invD;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) {
+            const int col = 32 * nb + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < RPG; ++i) {
+                const float dz = acc[nb][RPG * rg + i];
+                const float gfull = fmaf(rstd[i], fmaf(-xh[nb][i], s2[i], dz * gam[nb] - s1[i]), gi[nb][i]);
+                const float go = cok[nb] ? gfull : 0.f;  // rows past the image: gi = rstd = 0
+                adg[nb] = fmaf(dz, xh[nb][i], adg[nb]);
+                adb[nb] += dz;
+                ainj[nb] += go;
+                buf_store_f32(gout_r, eoff[i], 128 * nb, go);
+                if constexpr (NEXT) {
+                    const bool keep = drop_hash(l.drop_next.key, (uint32_t)row0 + trow[i], col) >= dthr;
+                    const bf16_t vb = (bf16_t)(keep ? go * snext * dinv : 0.f);
+                    abn[nb] += (float)vb;
+                    st[acc_row(RPG * rg + i, lane) * CS + col] = vb;
+                }
+            }
+        }
+        // the column sums must be formed HERE: left alone the compiler sinks all 4 x 16 x NBLK additions behind the loop and keeps
+        // (spills) every G and dy value until then
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) asm volatile("" : "+v"(adg[nb]), "+v"(adb[nb]), "+v"(ainj[nb]), "+v"(abn[nb]));
+    }
+    if constexpr (NEXT) {  // wave-private staging -> 16-B chunks of consecutive row segments
+        constexpr int CPR = BN / 8;
+#pragma unroll
+        for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < 32 * CPR) {
+                const int row = c / CPR, ch = c % CPR;
+                const int t = t0 + 32 * wave + row;
+                if (t < l.T) *(u32x4*)(l.dy_next + (row0 + t) * l.DP + 8 * ch) = *(const u32x4*)(st + row * CS + 8 * ch);
+            }
+        }
+    }
+    // column partials: the two half-waves hold different rows of the same columns; each wave parks its 4 x BN sums in its own staging
+    // region (its read-back above is complete: LDS operations of a wave execute in order)
+    float* sred_w = (float*)(smem + wave * 32 * CS);
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+        float q[4] = {adg[nb], adb[nb], ainj[nb], abn[nb]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned u = __float_as_uint(q[k]);
+            const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            q[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            if (lane < 32) sred_w[k * BN + 32 * nb + lane] = q[k];
+        }
+    }
+    __syncthreads();
+    const int c = tid;
+    if (c < l.D) {
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float* sw = (const float*)(smem + w * 32 * CS);
+            r0 += sw[c];
+            r1 += sw[BN + c];
+            r2 += sw[2 * BN + c];
+            r3 += sw[3 * BN + c];
+        }
+        atomicAdd(&l.dgamma[c], r0);
+        atomicAdd(&l.dbeta[c], r1);
+        if (l.dinject) atomicAdd(&l.dinject[(size_t)b * l.DP + c], r2);
+        if (NEXT && l.dbias_next) atomicAdd(&l.dbias_next[c], r3);
+    }
+}
+
 }  // namespace
 
 
@@ -908,6 +1146,24 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
         default: return V1T_ERR_UNSUPPORTED;
     }
 #undef LNG_CASE
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+
+int launch_gemm_ln_bwd(const GemmNTArgs& g, const LnBwdArgs& l, hipStream_t s) {
+    if (g.N != l.DP || l.DP % 32 != 0 || l.DP > 160 || g.K % 32 != 0 || (g.lda % 8) || (g.ldb % 8) || g.A_lo || g.f16) return V1T_ERR_UNSUPPORTED;
+    if (g.M != l.B * l.T || l.D > l.DP || !l.gin || !l.gout || !l.dgamma || !l.dbeta) return V1T_ERR_ARG;
+    if (g.M <= 0) return V1T_OK;
+    const dim3 grid(((l.T + 127) / 128) * l.B), blk(256);
+#define V1T_GLB(NB)                                                                                       \
+    case NB:                                                                                              \
+        if (l.dy_next) hipLaunchKernelGGL((gemm_lnbwd_kernel<NB, true>), grid, blk, 0, s, g, l);          \
+        else hipLaunchKernelGGL((gemm_lnbwd_kernel<NB, false>), grid, blk, 0, s, g, l);                   \
+        break;
+    switch (l.DP / 32) {
+        V1T_GLB(1) V1T_GLB(2) V1T_GLB(3) V1T_GLB(4) V1T_GLB(5)
+        default: return V1T_ERR_UNSUPPORTED;
+    }
+#undef V1T_GLB
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 
