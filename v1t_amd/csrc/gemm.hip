@@ -91,9 +91,10 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
                     d = v * (float)(r < 8 ? gp0[r & 7] : gp1[r & 7]);  // aux = gelu'(pre-activation), saved by FC1
                     if (g.drop.thresh) d = drop_keep(g.drop.key, row, col, g.drop.thresh) ? d * g.drop.inv_keep : 0.f;
                     const bf16_t db = (bf16_t)d;
-                    ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = db;
+                    if constexpr (!STAGED) ((bf16_t*)g.C)[(size_t)row * g.ldc + col] = db;
                     d = (float)db;
                 }
+                if constexpr (STAGED) acc[nb][r] = d;
                 csum += d;
             }
         }
@@ -256,6 +257,12 @@ __global__ __launch_bounds__(64 * NW, (EPI == EPI_BIAS_GELU && BK == 32 && NBLK 
             const int f16 = g.f16;
             staged_store(g.C2_lo, g.ldc2, [f16](float v) { return aux_plane(v, (bf16_t)v, f16); });
         }
+    } else if constexpr (EPI == EPI_DGELU) {
+        // the gradient (already rounded to bf16) is left in acc and leaves through the same staged 16-B row stores: element-wise it
+        // was 64 two-byte stores per lane, 64 B of two rows per instruction (190 MB per 112-image launch at the default shape)
+        gemm_epilogue<NBLK, EPI, true>(g, acc, resv, m0, n0, wave, lane);
+        __syncthreads();
+        staged_store((bf16_t*)g.C, g.ldc, [](float v) { return (bf16_t)v; });
     } else {
         gemm_epilogue<NBLK, EPI>(g, acc, resv, m0, n0, wave, lane);
     }
@@ -1171,6 +1178,7 @@ int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 != 0 || a.N % 32 != 0 || (a.lda % 8) || (a.ldb % 8)) return V1T_ERR_ARG;
     if (epi == EPI_BF16 && !a.A_lo && (a.ldc % 8)) return V1T_ERR_ARG;  // 16-B output chunks
     if (epi == EPI_BIAS_GELU && !a.A_lo && (a.ldc2 % 8)) return V1T_ERR_ARG;
+    if (epi == EPI_DGELU && (a.ldc % 8)) return V1T_ERR_ARG;
     if (a.N % 160 == 0) return launch_nt_n<5>(a, epi, s);
     if (a.N % 128 == 0) return launch_nt_n<4>(a, epi, s);
     if (a.N % 64 == 0) return launch_nt_n<2>(a, epi, s);
