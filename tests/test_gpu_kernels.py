@@ -311,8 +311,8 @@ def test_readout_grid_backward_paths(ctx, B, N, gd, sample):
             check_rel(f"test_readout_grid_backward_paths:" + str(tag), o["dmu"].cpu(), lmu.grad, 2e-5)
 
 
-def test_attention_forward_pipelined_variant_subprocess():
-    """The software-pipelined forward (attn_fwd2_kernel, opt-in through V1T_ATTN_FWD_V2: the switch is read once per process)
+def test_attention_forward_role_variant_subprocess():
+    """The 16-wave S-wave / PV-wave forward (attn_fwd3_kernel, opt-in through V1T_ATTN_FWD_V3: the switch is read once per process)
     against the default forward kernel on the same inputs, dropout on: same masks, same math, other summation order."""
     import os
     import subprocess
@@ -339,15 +339,15 @@ torch.save({"o": o.float().cpu(), "lse": lse.cpu()}, sys.argv[1])
     for v2 in (False, True):
         path = f"/tmp/v1t_fwd_{int(v2)}.pt"
         env = dict(os.environ)
-        env.pop("V1T_ATTN_FWD_V2", None)
+        env.pop("V1T_ATTN_FWD_V3", None)
         if v2:
-            env["V1T_ATTN_FWD_V2"] = "1"
+            env["V1T_ATTN_FWD_V3"] = "1"
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(path))
     a, b = outs
     assert bool(torch.isfinite(b["o"]).all())
-    check_rel("test_attention_forward_pipelined_variant_subprocess:34", b["o"], a["o"], 1e-2)
+    check_rel("test_attention_forward_role_variant_subprocess:34", b["o"], a["o"], 1e-2)
     assert float((b["lse"] - a["lse"]).abs().max()) < 2e-2
 
 
@@ -394,6 +394,62 @@ torch.save({"u": u.detach().cpu(), "g": model.core._arena.grad.cpu()}, sys.argv[
     # same arithmetic up to the summation order of the row statistics (a rounding flip of a 16-bit operand now and then)
     check_rel("test_fused_layernorm_gemm_equals_two_kernels:35", b["u"], a["u"], 1e-3)
     check_rel("test_fused_layernorm_gemm_equals_two_kernels:36", b["g"], a["g"], 5e-3)
+
+
+@pytest.mark.parametrize("switch,tol_g", [("V1T_LNBWD_UNFUSED", 2e-4), ("V1T_KEEP_BF16_PLANES", 2e-3)])
+@pytest.mark.parametrize("emb,images,beh", [(155, 2, 3), (64, 3, 0), (96, 5, 3)])
+def test_backward_fusions_equal_their_unfused_forms(switch, tol_g, emb, images, beh):
+    """Round-3 backward fusions against the kernels they replace, same process image apart from one dev switch (read once per
+    process: two subprocesses), training mode (dropout masks are counter-based: identical in both runs), ragged row counts:
+      V1T_LNBWD_UNFUSED    - gemm_lnbwd_kernel (dX GEMM + LayerNorm backward on the accumulators) vs gemm_nt<EPI_F32> + ln_bwd_kernel:
+                             same arithmetic, other summation order of the row / column sums (fp32);
+      V1T_KEEP_BF16_PLANES - weight-gradient GEMM and row constants reading the forward's fp16 planes of the attention output / GELU
+                             output (converted to bf16 fragment by fragment) vs the bf16 planes: the X operand is bf16(fp16(x))
+                             instead of bf16(x), a second rounding of at most half a bf16 ulp on some elements.
+    Compared: every core gradient (one flat arena) and the loss value."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from oracle import v1t_oracle as O
+from oracle import weights as W
+from tests.helpers import build_native_model
+emb, images, beh = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+dev = torch.device("cuda:0")
+cfg = O.Config(num_blocks=2, emb_dim=emb, mlp_dim=(488 if emb == 155 else 2 * emb + 24), num_heads=4, behavior_mode=beh, mouse_ids=("A",), num_neurons={"A": 40},
+               p_dropout=0.1, t_dropout=0.2)
+sd = W.make_state_dict(cfg, 5)
+model, _ = build_native_model(cfg, sd, dev)
+model.train(True)
+b = {k: v.to(dev) for k, v in W.make_batch(cfg, "A", images, 5).items()}
+model.core.prepare()
+model.core._arena.attach_grads()
+model.core._arena.grad.zero_()
+torch.manual_seed(11)
+u = model(inputs=b["image"], mouse_id="A", behaviors=b["behavior"], pupil_centers=b["pupil_center"], activate=False)[0]
+loss = (u * torch.linspace(-1, 1, u.numel(), device=dev).view_as(u)).sum()
+loss.backward()
+torch.cuda.synchronize()
+torch.save({"u": u.detach().cpu(), "g": model.core._arena.grad.cpu()}, sys.argv[1])
+'''
+    outs = []
+    for on in (False, True):
+        path = f"/tmp/v1t_{switch}_{int(on)}.pt"
+        env = dict(os.environ)
+        env.pop(switch, None)
+        if on:
+            env[switch] = "1"
+        r = subprocess.run([sys.executable, "-c", code, path, str(emb), str(images), str(beh)], env=env, capture_output=True, text=True,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(path))
+    a, b = outs
+    assert bool(torch.isfinite(a["u"]).all()) and bool(torch.isfinite(a["g"]).all()) and float(a["g"].abs().max()) > 0
+    assert torch.equal(a["u"], b["u"])  # neither switch touches the forward's values
+    check_rel(f"test_backward_fusions_equal_their_unfused_forms:{switch}:{emb}", a["g"], b["g"], tol_g)
 
 
 @pytest.mark.parametrize("B,T", [(2, 70), (1, 300), (3, 129)])
