@@ -437,9 +437,11 @@ int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
 // tiles + 614 KB of weights x 1448 row tiles through L2 - per CU that is its ~11.7 B / cycle fetch limit (outstanding misses x
 // latency), i.e. the old kernel was bound by its re-reads; here a workgroup fetches 160 KB of x and 614 KB of W.
 // Epilogues: EPI_BF16 (QKV) and EPI_BIAS_GELU (FC1; gelu' in the fragment order of 128-row tiles, as gemm_nt writes it).
-template <int DP, int EPI, int NW, int NBLK>
+template <int DP, int EPI, int NW, int NBLK, int RPW = 1>
 __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNTArgs g, int nsplit) {
-    constexpr int KS = DP / 16, BN = 32 * NBLK, LS = DP + 8, NTH = 64 * NW, KC = DP / 8, BM = 32 * NW;
+    // RPW = 32-row sets per wave: set u of wave w covers rows m0 + 32 NW u + 32 w ..., so a workgroup spans RPW consecutive (32 NW)-row tiles
+    constexpr int KS = DP / 16, BN = 32 * NBLK, LS = DP + 8, NTH = 64 * NW, KC = DP / 8, BM = 32 * NW * RPW, BMS = 32 * NW;
+    static_assert(RPW == 1 || NW == 4, "row sets are whole 128-row tiles");
     constexpr int B_CHUNKS = BN * KC, B_ITERS = (B_CHUNKS + NTH - 1) / NTH;
     constexpr int CS = BN + 8;
     __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LS];
@@ -451,9 +453,6 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
     // over nsplit workgroups; each normalises the rows for itself, the first one writes the LayerNorm outputs
     const int sp = blockIdx.x % nsplit;
     const int m0 = (blockIdx.x / nsplit) * BM;
-    const int row = m0 + 32 * wave + r31;
-    const bool rok = row < l.rows, wln = rok && sp == 0;
-    const int rr = rok ? row : l.rows - 1;
     const int ntn = g.N / BN;
 
     u32x4 rb[B_ITERS];
@@ -477,7 +476,18 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
         sgb[1][tid] = tid < l.D ? l.beta[tid] : 0.f;
     }
 
-    // ---- LayerNorm of this lane's half row (columns 16 ks + 8 h2 + e)
+    // ---- LayerNorm of this lane's half row (columns 16 ks + 8 h2 + e), one row set after the other
+    bf16x8 afrag[RPW][KS];
+    bool staged = false;
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+    if (u) {  // keep the row sets' prologues apart (their 80 fp32 values each would be live together)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int row = m0 + BMS * u + 32 * wave + r31;
+    const bool rok = row < l.rows, wln = rok && sp == 0;
+    const int rr = rok ? row : l.rows - 1;
     float xv[KS][8];
     {
         const float* xp = l.x + (size_t)rr * DP + 8 * h2;
@@ -533,8 +543,8 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
         l.mean[row] = mean;
         l.rstd[row] = rstd;
     }
-    __syncthreads();  // gamma / beta staged
-    bf16x8 afrag[KS];
+    if (!staged) __syncthreads();  // gamma / beta staged
+    staged = true;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int c0 = 16 * ks + 8 * h2;
@@ -548,15 +558,16 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
             float z = (xv[ks][e] - mean) * rstd * ga + be;
             if (ks >= KS - 2 && cc >= l.D) z = (cc == l.ones_col) ? 1.f : 0.f;
             zh[e] = (bf16_t)z;
-            afrag[ks][e] = aux_plane(z, zh[e], 1);
+            afrag[u][ks][e] = aux_plane(z, zh[e], 1);
         }
         if (wln) *(bf16x8*)(l.z + (size_t)row * DP + c0) = zh;
     }
+    }  // row sets
 
     // ---- all column tiles of the weight against the resident A fragments
-    const int m0p = m0 + 128 * (wave >> 2), wv = wave & 3;  // the epilogue helpers think in 128-row tiles of 4 waves (NW = 4 or 8)
+    const int wv = wave & 3;  // the epilogue helpers think in 128-row tiles of 4 waves (NW = 4 or 8)
     bf16_t* st = stg[wave];
-    auto staged_store = [&](f32x16 (&acc)[NBLK], bf16_t* dst, int ld, int n0, auto conv) {
+    auto staged_store = [&](int u, f32x16 (&acc)[NBLK], bf16_t* dst, int ld, int n0, auto conv) {
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
@@ -565,7 +576,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
 #pragma unroll
         for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
             const int c = c0 + lane, crow = c / CPR, ch = c % CPR;
-            const int grow = m0 + 32 * wave + crow;
+            const int grow = m0 + BMS * u + 32 * wave + crow;
             if (grow < g.M) *(u32x4*)(dst + (size_t)grow * ld + n0 + 8 * ch) = *(const u32x4*)(st + crow * CS + 8 * ch);
         }
     };
@@ -575,28 +586,39 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
     for (int tn = sp, it = 0; tn < ntn; tn += nsplit, ++it) {
         const int buf = it & 1, n0 = tn * BN;
         if (tn + nsplit < ntn) gload(tn + nsplit);
-        f32x16 acc[NBLK];
+        f32x16 acc[RPW][NBLK];
 #pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb)
+        for (int u = 0; u < RPW; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+            for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][nb][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int nb = 0; nb < NBLK; ++nb) {
-                const bf16x8 b = *(const bf16x8*)(&sB[buf][32 * nb * LS + boff + 16 * ks]);
-                acc[nb] = mfma32h(afrag[ks], b, acc[nb]);
+                const bf16x8 b = *(const bf16x8*)(&sB[buf][32 * nb * LS + boff + 16 * ks]);  // one LDS read feeds every row set
+#pragma unroll
+                for (int u = 0; u < RPW; ++u) acc[u][nb] = mfma32h(afrag[u][ks], b, acc[u][nb]);
             }
-        if (m0p >= g.M) {
-            // a 128-row tile wholly beyond M (second half of the last workgroup): nothing to store, and the gelu' fragment buffer
-            // is only allocated for ceil(M / 128) tiles
-        } else if constexpr (EPI == EPI_BF16) {
-            staged_store(acc, (bf16_t*)g.C, g.ldc, n0, [](float v) { return (bf16_t)v; });
-        } else {
-            f32x16 resv[NBLK];
-            gemm_epilogue<NBLK, EPI_BIAS_GELU, true>(g, acc, resv, m0p, n0, wv, lane);  // gelu' written (fragment order), activation left in acc
-            if (g.C2) staged_store(acc, g.C2, g.ldc2, n0, [](float v) { return (bf16_t)v; });
-            if (g.C2_lo) staged_store(acc, g.C2_lo, g.ldc2, n0, [](float v) { return aux_plane(v, (bf16_t)v, 1); });
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            if (u) {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int m0p = m0 + BMS * u + 128 * (wave >> 2);
+            if (m0p >= g.M) {
+                // a 128-row tile wholly beyond M (second half of the last workgroup): nothing to store, and the gelu' fragment buffer
+                // is only allocated for ceil(M / 128) tiles
+            } else if constexpr (EPI == EPI_BF16) {
+                staged_store(u, acc[u], (bf16_t*)g.C, g.ldc, n0, [](float v) { return (bf16_t)v; });
+            } else {
+                f32x16 resv[NBLK];
+                gemm_epilogue<NBLK, EPI_BIAS_GELU, true>(g, acc[u], resv, m0p, n0, wv, lane);  // gelu' written (fragment order), activation left in acc
+                if (g.C2) staged_store(u, acc[u], g.C2, g.ldc2, n0, [](float v) { return (bf16_t)v; });
+                if (g.C2_lo) staged_store(u, acc[u], g.C2_lo, g.ldc2, n0, [](float v) { return aux_plane(v, (bf16_t)v, 1); });
+            }
         }
         if (tn + nsplit < ntn) swrite(buf ^ 1);
         __syncthreads();
@@ -1122,8 +1144,14 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
     // workgroups: row tiles x nsplit, one workgroup per CU (a rank of an 8-GPU step has 91 row tiles, the single-GPU batch 724)
     // two shapes: 8 waves x 256 rows x 128-column tiles, one workgroup per CU (LDS 157 KB), or 4 waves x 128 rows x 64-column
     // tiles, two independent workgroups per CU (62 KB each) whose MFMA / epilogue / store phases drift apart and overlap
-    static const int shape = std::getenv("V1T_LNG_SHAPE") ? atoi(std::getenv("V1T_LNG_SHAPE")) : 1;  // dev switch: 0 = 8 waves
-    const int BMr = shape ? 128 : 256, BNr = shape ? 64 : 128;
+    // 0: 8 waves x 256 rows x 128-column tiles; 1: 4 waves x 128 rows x 64 columns; 2: 4 waves x 2 row sets (256 rows) x 64 columns:
+    // a weight tile is fetched and read from LDS once per 256 rows (its fetches through L2 cost the QKV launch 58 of 258 us with one
+    // row set: ablation in profiles/r03_gemm_experiments.txt). QKV at full-size launches: 265 -> 250 us; not for the GELU epilogue
+    // (its live values + the second row set's accumulators and A fragments do not fit 256 registers: 183 -> 283 us) nor for small
+    // launches (fewer, longer workgroups)
+    static const int force_shape = std::getenv("V1T_LNG_SHAPE") ? atoi(std::getenv("V1T_LNG_SHAPE")) : -1;  // dev switch
+    const int shape = force_shape >= 0 ? force_shape : ((epi == EPI_BF16 && l.rows >= 512 * 256) ? 2 : 1);
+    const int BMr = shape == 1 ? 128 : 256, BNr = shape ? 64 : 128;
     if (g.N % BNr != 0) return V1T_ERR_UNSUPPORTED;
     const int rt = (l.rows + BMr - 1) / BMr, ntn = g.N / BNr;
     static const int force_split = std::getenv("V1T_LNG_SPLIT") ? atoi(std::getenv("V1T_LNG_SPLIT")) : 0;  // dev switch
@@ -1133,14 +1161,18 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
     float best = 1e30f;
     for (int ns = 1; ns <= ntn; ++ns) {
         const int slots = shape ? 512 : 256;  // resident workgroups
-        const float cost = (float)((rt * ns + slots - 1) / slots) * ((shape ? 3.0f : 1.5f) + (float)((ntn + ns - 1) / ns));
+        const float unit = shape == 2 ? 2.0f : 1.0f;  // row sets per workgroup: prologue and column tiles cost twice
+        const float cost = (float)((rt * ns + slots - 1) / slots) * unit * ((shape ? 3.0f : 1.5f) + (float)((ntn + ns - 1) / ns));
         if (cost < best - 1e-3f) { best = cost; nsplit = ns; }
     }
     if (force_split > 0) nsplit = std::min(force_split, ntn);
     const dim3 grid(rt * nsplit), blk(shape ? 256 : 512);
 #define LNG_CASE(DPV)                                                                                                       \
     case DPV:                                                                                                               \
-        if (shape) {                                                                                                        \
+        if (shape == 2) {                                                                                                   \
+            if (epi == EPI_BF16) hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BF16, 4, 2, 2>), grid, blk, 0, s, l, g, nsplit); \
+            else hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BIAS_GELU, 4, 2, 2>), grid, blk, 0, s, l, g, nsplit);           \
+        } else if (shape) {                                                                                                 \
             if (epi == EPI_BF16) hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BF16, 4, 2>), grid, blk, 0, s, l, g, nsplit);   \
             else hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BIAS_GELU, 4, 2>), grid, blk, 0, s, l, g, nsplit);              \
         } else {                                                                                                            \
