@@ -396,7 +396,7 @@ torch.save({"u": u.detach().cpu(), "g": model.core._arena.grad.cpu()}, sys.argv[
     check_rel("test_fused_layernorm_gemm_equals_two_kernels:36", b["g"], a["g"], 5e-3)
 
 
-@pytest.mark.parametrize("switch,tol_g", [("V1T_LNBWD_UNFUSED", 2e-4), ("V1T_KEEP_BF16_PLANES", 2e-3)])
+@pytest.mark.parametrize("switch,tol_g", [("V1T_LNBWD_UNFUSED", 2e-4), ("V1T_KEEP_BF16_PLANES", 2e-3), ("V1T_DELTA_UNFUSED", 2e-4)])
 @pytest.mark.parametrize("emb,images,beh", [(155, 2, 3), (64, 3, 0), (96, 5, 3)])
 def test_backward_fusions_equal_their_unfused_forms(switch, tol_g, emb, images, beh):
     """Round-3 backward fusions against the kernels they replace, same process image apart from one dev switch (read once per
@@ -406,6 +406,8 @@ def test_backward_fusions_equal_their_unfused_forms(switch, tol_g, emb, images, 
       V1T_KEEP_BF16_PLANES - weight-gradient GEMM and row constants reading the forward's fp16 planes of the attention output / GELU
                              output (converted to bf16 fragment by fragment) vs the bf16 planes: the X operand is bf16(fp16(x))
                              instead of bf16(x), a second rounding of at most half a bf16 ulp on some elements.
+      V1T_DELTA_UNFUSED    - the attention backward's row constants (delta = rowsum(dO * O) per head, -lse) out of the dO GEMM's epilogue
+                             (gemm.h RowDotArgs) vs attn_delta2_kernel: same bf16-rounded dO, other summation order.
     Compared: every core gradient (one flat arena) and the loss value."""
     import os
     import subprocess

@@ -760,6 +760,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
 // dz = dY . W (fp32, g.C) followed by the backward of the LayerNorm in front of that linear layer: one kernel where the shape allows
 // (gemm.h, launch_gemm_ln_bwd: dz stays in the accumulators), else the GEMM and ln_bwd_kernel. V1T_LNBWD_UNFUSED=1 (dev, A/B): always two.
 static const bool g_lnbwd_unfused = std::getenv("V1T_LNBWD_UNFUSED") != nullptr;
+static const bool g_delta_unfused = std::getenv("V1T_DELTA_UNFUSED") != nullptr;  // dev (A/B): attn_delta2_kernel instead of the dO GEMM's row-dot epilogue
 static int dx_then_ln_bwd(const GemmNTArgs& g, const LnBwdArgs& lb, hipStream_t s) {
     if (!g_lnbwd_unfused) {
         const int rc = launch_gemm_ln_bwd(g, lb, s);
@@ -871,7 +872,6 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         // dO = dy . Wo
         g = GemmNTArgs{};
         g.A = dy; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_proj_t); g.ldb = DP; g.M = R; g.N = HDP; g.K = DP; g.C = dO; g.ldc = HDP;
-        CHECK(launch_gemm_nt(g, EPI_BF16, s));
         AttnArgs at{};
         at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = x16o ? (bf16_t*)(wb + w.o_lo) : (bf16_t*)o; at.o_f16 = x16o; at.ldo = HDP; at.lse2 = (float*)(wb + w.lse2);
         at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
@@ -879,7 +879,19 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         at.dO = dO; at.lddo = HDP; at.delta = delta; at.dqkv = dqkv; at.lddqkv = 3 * HDP;
         at.dscale = h->c.use_lsa ? grads + b.scale : nullptr;
         if (g_attn_ds && !h->c.use_lsa) { at.ds = (bf16_t*)(sc + sl.ds); at.ldds = attn_ds_ld(h->T); }
-        CHECK(launch_attn_delta(at, h->HEP, delta, s));
+        // the row constants of the producer / consumer backward (delta = rowsum(dO * O) per head, -lse) leave the dO GEMM's epilogue where its
+        // column tile is one head (RowDotArgs, gemm.h); else the separate pass over dO and O
+        bool rowdot = false;
+        if (at.ds && h->HEP == 160 && !g_delta_unfused) {
+            float* nlse = (float*)(at.ds + attn_ds_elems(B, h->H, h->T));
+            g.rd.o = at.o; g.rd.ldo = HDP; g.rd.o_f16 = at.o_f16; g.rd.lse2 = at.lse2; g.rd.nlse = nlse; g.rd.ndelta = nlse + attn_rc_floats(B, h->H, h->T);
+            g.rd.T = h->T; g.rd.TPQ = attn_ds_tpq(h->T); g.rd.H = h->H; g.rd.keep = at.adrop.keep_prob;
+            rowdot = gemm_nt_takes_row_dot(g, EPI_BF16);
+            if (!rowdot) g.rd = RowDotArgs{};
+        }
+        CHECK(launch_gemm_nt(g, EPI_BF16, s));
+        if (!rowdot) CHECK(launch_attn_delta(at, h->HEP, delta, s));
+        else if (k == h->NB - 1) CHECK(launch_attn_rc_pad(at, s));  // the pad rows are constants and only this call writes them: once per backward
         CHECK(launch_attn_bwd(at, h->HEP, s));
         // dWqkv += dqkv^T z1
         t = GemmTNArgs{};

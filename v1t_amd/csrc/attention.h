@@ -40,6 +40,9 @@ inline size_t attn_ds_bytes(int B, int H, int T) { return attn_ds_elems(B, H, T)
 
 int launch_attn_fwd(const AttnArgs& a, int DP, hipStream_t s);
 int launch_attn_delta(const AttnArgs& a, int DP, float* delta, hipStream_t s);
+// pad rows (t >= T) of the row-constant arrays behind a.ds only (nlse = -1e30: P = 0 there; ndelta = 0): for callers that get the real rows
+// from the dO GEMM's epilogue (gemm.h, RowDotArgs) instead of launch_attn_delta
+int launch_attn_rc_pad(const AttnArgs& a, hipStream_t s);
 int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s);  // dq + dkv kernels
 
 // attention rollout building blocks (reference utils/attention_rollout.py:92-122)

@@ -1332,6 +1332,15 @@ __global__ __launch_bounds__(256) void attn_delta2_kernel(AttnArgs a, float* nls
     }
 }
 
+__global__ __launch_bounds__(256) void attn_rc_pad_kernel(float* nlse, float* ndelta, int BH, int T, int TPQ) {
+    const int npad = TPQ - T;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= BH * npad) return;
+    const size_t o = (size_t)(i / npad) * TPQ + T + i % npad;
+    nlse[o] = NEG_BIG;
+    ndelta[o] = 0.f;
+}
+
 DEVFN int b2_slot(int t) { return (t + 3) - B2_SLOTS * ((t + 3) / B2_SLOTS); }  // tiles 0, 1 in slots 3, 4: slots 0-2 hold K / V images during the prologue
 
 #ifdef V1T_KCLK
@@ -2263,6 +2272,14 @@ int launch_headmax_t(const AttnArgs& a, float* A, int TP, float* rowsum, hipStre
 
 int launch_attn_fwd(const AttnArgs& a, int DP, hipStream_t s) { DP_DISPATCH(fwd_flags, a, s) }
 int launch_attn_delta(const AttnArgs& a, int DP, float* delta, hipStream_t s) { DP_DISPATCH(launch_delta_t, a, delta, s) }
+int launch_attn_rc_pad(const AttnArgs& a, hipStream_t s) {
+    if (!a.ds) return V1T_ERR_ARG;
+    const int TPQ = attn_ds_tpq(a.T), n = a.B * a.H * (TPQ - a.T);
+    if (n <= 0) return V1T_OK;
+    float* nlse = (float*)(a.ds + attn_ds_elems(a.B, a.H, a.T));
+    hipLaunchKernelGGL(attn_rc_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, nlse, nlse + attn_rc_floats(a.B, a.H, a.T), a.B * a.H, a.T, TPQ);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
 int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s) { DP_DISPATCH(bwd_flags, a, s) }
 
 int launch_rollout_headmax(const AttnArgs& a, int DP, float* A, int TP, float* rowsum, hipStream_t s) {

@@ -20,6 +20,18 @@ enum GemmEpi {
     // scattered 2-byte accesses (the 2-byte loads alone cost 34 us of that 86 us kernel).
 };
 
+// EPI_BF16 with 160-column tiles only: the dot product of every (row, column tile) of the bf16-ROUNDED output with the same segment of a second
+// 16-bit matrix, i.e. the attention backward's row constants delta = rowsum(dO * O) per head while dO = dy . Wo leaves the GEMM (the separate
+// pass re-read dO and O: 0.47 GB per 112-image launch). Written negated / scaled, next to the negated log-sum-exp, into the padded row-constant
+// arrays the dK/dV kernel reads (attention.h): index (b * H + column tile) * TPQ + t for row b * T + t. Pad rows (t >= T) are not touched.
+struct RowDotArgs {
+    const bf16_t* o; int ldo; int o_f16;  // [M][N]: bf16, or fp16 when o_f16; nullptr = off
+    const float* lse2;                    // [B][H][T]
+    float* nlse; float* ndelta;           // [B * H][TPQ]
+    int T, TPQ, H;
+    float keep;                           // ndelta = -keep * dot
+};
+
 struct GemmNTArgs {
     const bf16_t* A; int lda;
     const bf16_t* B; int ldb;
@@ -40,7 +52,9 @@ struct GemmNTArgs {
     DropCfg drop;
     const float* pos; const float* cls; int T;  // EPI_PATCH: natural [T][n_valid] position table, [n_valid] class token
     const float* row_scale;       // EPI_BIAS_RES: per-image factor on the branch (stochastic depth), index row / T, or nullptr
+    RowDotArgs rd;                // EPI_BF16, N % 160 == 0: see RowDotArgs
 };
+bool gemm_nt_takes_row_dot(const GemmNTArgs& a, int epi);
 
 struct GemmTNArgs {
     const bf16_t* Y; int ldy;  // [M][NY]

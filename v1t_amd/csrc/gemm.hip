@@ -115,8 +115,9 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
 
 // NW waves per workgroup = 32*NW rows (only 4 is launched: 64-row workgroups measured the same time on the
 // single-column-tile GEMMs, which are bound by how they read A, not by workgroups in flight).
-template <int NBLK, int EPI, int NW, int BK, bool F16 = false>
+template <int NBLK, int EPI, int NW, int BK, bool F16 = false, bool RD = false>
 __global__ __launch_bounds__(64 * NW, (EPI == EPI_BIAS_GELU && BK == 32 && NBLK <= 4) ? 3 : 1) void gemm_nt_kernel(GemmNTArgs g) {
+    static_assert(!RD || (EPI == EPI_BF16 && NBLK == 5), "row dot: bf16 output, one 160-column tile per head");
     constexpr int BM = 32 * NW, NT = 64 * NW;
     constexpr int LS = BK + 8, KC = BK / 8;  // LDS row stride (16-B pad: 80 / 144 B), 16-B chunks per row
     constexpr int A_ITERS = BM * KC / NT;
@@ -246,7 +247,68 @@ __global__ __launch_bounds__(64 * NW, (EPI == EPI_BIAS_GELU && BK == 32 && NBLK 
             }
         }
     };
-    if constexpr (EPI == EPI_BF16) {
+    if constexpr (EPI == EPI_BF16 && RD) {
+        // staged store + row dot (RowDotArgs): the second matrix's chunks are fetched first (10 x 16 B per lane, in flight while the tile is
+        // staged), every 16-B chunk of the rounded output meets its partner on the way out, the 20 chunk sums of a row meet in LDS (float atomics
+        // of this wave only), lanes 0-31 write the row constants of the wave's 32 rows
+        constexpr int CPR = BN / 8, NIT = (32 * CPR + 63) / 64;
+        static_assert(32 * (CPR + 1) * 4 <= 32 * CS * 2, "the chunk sums fit the wave's staging region");
+        u32x4 ov[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = 64 * it + lane, row = c / CPR, ch = c % CPR;
+            const int grow = m0 + 32 * wave + row;
+            ov[it] = (c < 32 * CPR && grow < g.M) ? *(const u32x4*)(g.rd.o + (size_t)grow * g.rd.ldo + n0 + 8 * ch) : u32x4{0, 0, 0, 0};
+        }
+        __syncthreads();  // every wave is done with the operand tiles
+        bf16_t* st = smem + wave * 32 * CS;
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[acc_row(r, lane) * CS + 32 * nb + (lane & 31)] = (bf16_t)acc[nb][r];
+        float parts[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            parts[it] = 0.f;
+            const int c = 64 * it + lane;
+            if (c < 32 * CPR) {
+                const int row = c / CPR, ch = c % CPR;
+                const int grow = m0 + 32 * wave + row;
+                const u32x4 dv = *(const u32x4*)(st + row * CS + 8 * ch);
+                if (grow < g.M) *(u32x4*)((bf16_t*)g.C + (size_t)grow * g.ldc + n0 + 8 * ch) = dv;
+                const bf16x8 d8 = __builtin_bit_cast(bf16x8, dv), o8 = __builtin_bit_cast(bf16x8, ov[it]);
+                float part = 0.f;
+                if (g.rd.o_f16) {  // kernel-uniform
+                    const f16x8 oh = __builtin_bit_cast(f16x8, ov[it]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) part = fmaf((float)d8[j], (float)oh[j], part);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) part = fmaf((float)d8[j], (float)o8[j], part);
+                }
+                parts[it] = part;
+            }
+        }
+        // the chunk sums go where the tile was staged (every read of it is behind this wave: its LDS operations execute in order), as
+        // [32 rows][CPR + 1] floats: chunk c of the wave sits at c + c / CPR, a row's CPR sums are read by one lane, both without bank conflicts
+        float* sp = (float*)st;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = 64 * it + lane;
+            if (c < 32 * CPR) sp[c + c / CPR] = parts[it];
+        }
+        if (lane < 32) {
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < CPR; ++j) dot += sp[lane * (CPR + 1) + j];
+            const int grow = m0 + 32 * wave + lane;
+            if (grow < g.M) {
+                const int bi = grow / g.rd.T, t = grow - bi * g.rd.T, bh = bi * g.rd.H + tile_n;
+                g.rd.ndelta[(size_t)bh * g.rd.TPQ + t] = -dot * g.rd.keep;
+                g.rd.nlse[(size_t)bh * g.rd.TPQ + t] = -g.rd.lse2[(size_t)bh * g.rd.T + t];
+            }
+        }
+    } else if constexpr (EPI == EPI_BF16) {
         __syncthreads();  // every wave is done with the operand tiles
         staged_store((bf16_t*)g.C, g.ldc, [](float v) { return (bf16_t)v; });
     } else if constexpr (EPI == EPI_BIAS_GELU) {
@@ -399,6 +461,15 @@ int launch_nt_nw(const GemmNTArgs& a, int epi, hipStream_t s) {
             default: return V1T_ERR_ARG;
         }
         return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    }
+    if (a.rd.o) {
+        if constexpr (NBLK == 5) {
+            if (epi == EPI_BF16) {
+                hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BF16, NW, BK, false, true>), dim3(grid), blk, 0, s, a);
+                return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+            }
+        }
+        return V1T_ERR_UNSUPPORTED;
     }
     switch (epi) {
         case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BF16, NW, BK>), dim3(grid), blk, 0, s, a); break;
@@ -1206,8 +1277,14 @@ int launch_gemm_ln_bwd(const GemmNTArgs& g, const LnBwdArgs& l, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 
+bool gemm_nt_takes_row_dot(const GemmNTArgs& a, int epi) {
+    return epi == EPI_BF16 && a.N % 160 == 0 && !a.f16 && !a.A_lo && !a.B_lo && (a.ldc % 8) == 0 && (a.rd.ldo % 8) == 0 && a.rd.H == a.N / 160;
+}
+
 int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 != 0 || a.N % 32 != 0 || (a.lda % 8) || (a.ldb % 8)) return V1T_ERR_ARG;
+    if (a.rd.o && !gemm_nt_takes_row_dot(a, epi)) return V1T_ERR_UNSUPPORTED;
+    if ((a.f16 || a.A_lo) && a.rd.o) return V1T_ERR_UNSUPPORTED;
     if (epi == EPI_BF16 && !a.A_lo && (a.ldc % 8)) return V1T_ERR_ARG;  // 16-B output chunks
     if (epi == EPI_BIAS_GELU && !a.A_lo && (a.ldc2 % 8)) return V1T_ERR_ARG;
     if (epi == EPI_DGELU && (a.ldc % 8)) return V1T_ERR_ARG;
