@@ -814,8 +814,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs g) {
     __shared__ __attribute__((aligned(16))) bf16_t sX[2][TN2_ROWS * TN2_STR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = (WY == 4) ? wave : 0, wx = (WX == 4) ? wave : 0;
-    const int n0 = blockIdx.x * YW, x0 = blockIdx.y * XW;
-    const int mb = blockIdx.z * g.m_chunk;
+    // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs in linear (x, y, z) order; after the remap the tiles of
+    // one m-chunk - which all read the same rows of the narrow operand - are neighbours inside ONE XCD's share and find those rows in its L2
+    // (dWo: the 59 MB of dy were fetched once per X tile, 5 times)
+#ifndef V1T_TN2_NOREMAP
+    const int nwg = gridDim.x * gridDim.y * gridDim.z;
+    const int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nwg);
+    const int bx = lid % gridDim.x, by = (lid / gridDim.x) % gridDim.y, bz = lid / (gridDim.x * gridDim.y);
+#else
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#endif
+    const int n0 = bx * YW, x0 = by * XW;
+    const int mb = bz * g.m_chunk;
     const int me = min(g.M, mb + g.m_chunk);
     const int nt = (me - mb + TN2_ROWS - 1) / TN2_ROWS;
     const int yw0 = n0 + 32 * YB * wy, xw0 = x0 + 32 * XB * wx;
@@ -891,7 +901,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs g) {
     if (g.slab) {
         // partial tile -> slab in accumulator-fragment order (16 floats per lane per block, plain 16-B stores);
         // tn_reduce_kernel sums the chunks and applies the index maps. ~3x cheaper than 41 MB of fp32 atomics.
-        float* sl = g.slab + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * (YB * XB * 1024) + lane * 16;
+        float* sl = g.slab + ((((size_t)bz * gridDim.y + by) * gridDim.x + bx) * 4 + wave) * (YB * XB * 1024) + lane * 16;
 #pragma unroll
         for (int i = 0; i < YB * XB; ++i)
 #pragma unroll
