@@ -33,6 +33,37 @@ def run():
                                            dbias.data_ptr(), ws.data_ptr() if use_ws else None, nb if use_ws else 0, L.stream()))
 
 
+out = torch.empty(B, N, device=dev)
+bias = torch.zeros(N, device=dev)
+
+
+def fwd():
+    L.check(lib.v1t_gaussian2d_forward(z.data_ptr() + 4 * DP, (H * W + 1) * DP, DP, B, C, H, W, N, grid.data_ptr(), feat.data_ptr(), DP, bias.data_ptr(), out.data_ptr(), L.stream()))
+
+
+def part(p):
+    def f():
+        L.check(lib.v1t_gaussian2d_backward_parts(z.data_ptr() + 4 * DP, (H * W + 1) * DP, DP, B, C, H, W, N, grid.data_ptr(), feat.data_ptr(), DP, gout.data_ptr(),
+                                                  dz.data_ptr() + 4 * DP, (H * W + 1) * DP, DP, dgrid.data_ptr(), dfeat.data_ptr(), dbias.data_ptr(), ws.data_ptr(), nb, p, L.stream()))
+    return f
+
+
+def timeit(name, fn, reps=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    print(f"{name}: {(time.perf_counter() - t0) / reps * 1e6:.1f} us per call")
+
+
+timeit("readout forward", fwd)
+if use_ws:
+    timeit("backward: tap sort", part(1))
+    timeit("backward: parameter gradients", part(2))
+    timeit("backward: dz gather", part(4))
 for _ in range(5):
     run()
 torch.cuda.synchronize()
