@@ -116,7 +116,7 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
 // NW waves per workgroup = 32*NW rows (only 4 is launched: 64-row workgroups measured the same time on the
 // single-column-tile GEMMs, which are bound by how they read A, not by workgroups in flight).
 template <int NBLK, int EPI, int NW, int BK, bool F16 = false, bool RD = false>
-__global__ __launch_bounds__(64 * NW, (EPI == EPI_BIAS_GELU && BK == 32 && NBLK <= 4) ? 3 : 1) void gemm_nt_kernel(GemmNTArgs g) {
+__global__ __launch_bounds__(64 * NW, ((EPI == EPI_BIAS_GELU && BK == 32 && NBLK <= 4) || (EPI == EPI_BIAS_RES && BK == 32 && NW == 4)) ? 3 : 1) void gemm_nt_kernel(GemmNTArgs g) {
     static_assert(!RD || (EPI == EPI_BF16 && NBLK == 5), "row dot: bf16 output, one 160-column tile per head");
     constexpr int BM = 32 * NW, NT = 64 * NW;
     constexpr int LS = BK + 8, KC = BK / 8;  // LDS row stride (16-B pad: 80 / 144 B), 16-B chunks per row
@@ -144,15 +144,7 @@ __global__ __launch_bounds__(64 * NW, (EPI == EPI_BIAS_GELU && BK == 32 && NBLK 
     // their latency hides under that tile's MFMAs without the 16*NBLK registers being live through the whole K loop next to
     // the staging registers (held from the prologue they pushed the proj / FC2 kernels to 284 VGPRs = one workgroup per CU)
     f32x16 resv[NBLK];
-    auto load_res = [&]() {
-#pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 32 * wave + acc_row(r, lane);
-                resv[nb][r] = (g.res && row < g.M) ? g.res[(size_t)row * g.ldres + n0 + 32 * nb + (lane & 31)] : 0.f;
-            }
-    };
+    auto load_res = [&]() {};  // EPI_BIAS_RES fetches the residual block by block in its epilogue (below)
     u32x4 ra[A_ITERS], rb[B_ITERS];
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
@@ -325,6 +317,51 @@ __global__ __launch_bounds__(64 * NW, (EPI == EPI_BIAS_GELU && BK == 32 && NBLK 
         gemm_epilogue<NBLK, EPI, true>(g, acc, resv, m0, n0, wave, lane);
         __syncthreads();
         staged_store((bf16_t*)g.C, g.ldc, [](float v) { return (bf16_t)v; });
+    } else if constexpr (EPI == EPI_BIAS_RES) {
+        // C = res + dropout(acc + bias) * row_scale with the accumulator layout's 4-B accesses through buffer resources over this workgroup's
+        // rows: scalar base, ONE per-lane offset register (row 32 wave + 4 (lane >> 5), column lane & 31), the accumulator row (r & 3) + 8 (r >> 2)
+        // and the column block in the scalar offset - no 64-bit address pair per access, the residual of one column block (16 loads) in flight
+        // at a time instead of all 16 NBLK values held through the last K tile (152 VGPRs -> two workgroups per CU)
+        const int rows_here = min(BM, g.M - m0);  // < BM in the last row tile only: rows past M then get an out-of-range offset (reads 0, stores dropped)
+        const __amdgpu_buffer_rsrc_t rr = buf_rsrc(g.res ? g.res + (size_t)m0 * g.ldres + n0 : nullptr, g.res ? (uint32_t)rows_here * (uint32_t)g.ldres * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t cr = buf_rsrc((float*)g.C + (size_t)m0 * g.ldc + n0, (uint32_t)rows_here * (uint32_t)g.ldc * 4u);
+        const uint32_t lrow = (uint32_t)(32 * wave + 4 * (lane >> 5));
+        const uint32_t dthr = g.drop.thresh;  // 0 keeps everything (hash >= 0)
+        const float dinv = g.drop.thresh ? g.drop.inv_keep : 1.0f;
+        const uint32_t vres = (lrow * (uint32_t)g.ldres + (uint32_t)(lane & 31)) * 4u, vout = (lrow * (uint32_t)g.ldc + (uint32_t)(lane & 31)) * 4u;
+        auto body = [&](auto ragged_c) __attribute__((always_inline)) {
+            constexpr bool RAGGED = decltype(ragged_c)::value;
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) {
+                if (nb) {  // one column block at a time
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int col = n0 + 32 * nb + (lane & 31);
+                const float bias = g.bias ? g.bias[col] : 0.f;
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ar = (r & 3) + 8 * (r >> 2);
+                    uint32_t vo = vres;
+                    if (RAGGED && (int)lrow + ar >= rows_here) vo |= BUF_OOB;
+                    rv[r] = buf_load_f32(rr, vo, (ar * g.ldres + 32 * nb) * 4);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ar = (r & 3) + 8 * (r >> 2);
+                    const uint32_t grow = (uint32_t)m0 + lrow + (uint32_t)ar;
+                    const bool keep = drop_hash(g.drop.key, grow, col) >= dthr;
+                    float v = keep ? (acc[nb][r] + bias) * dinv : 0.f;
+                    if (g.row_scale) v *= g.row_scale[min((int)grow, g.M - 1) / g.T];
+                    uint32_t vo = vout;
+                    if (RAGGED && (int)lrow + ar >= rows_here) vo |= BUF_OOB;
+                    buf_store_f32(cr, vo, (ar * g.ldc + 32 * nb) * 4, rv[r] + v);
+                }
+            }
+        };
+        if (rows_here == BM) body(std::false_type{});  // workgroup-uniform
+        else body(std::true_type{});
     } else {
         gemm_epilogue<NBLK, EPI>(g, acc, resv, m0, n0, wave, lane);
     }
