@@ -609,10 +609,15 @@ __global__ __launch_bounds__(256) void drop_cast_kernel(CastArgs a) {
     __shared__ float sred[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 7, slot = lane >> 3;
-    const int r0 = blockIdx.x * LNB_ROWS;
     f32x4 acc[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // a workgroup walks several 128-row tiles with its column sums in registers: the bias gradient is ONE atomic per column and workgroup,
+    // and with a workgroup per tile (1447 at 112 images) the 1447 atomics on each of 155 addresses were a serial chain longer than the
+    // kernel's memory time (107 us for 177 MB)
+    const int ntiles = (a.rows + LNB_ROWS - 1) / LNB_ROWS;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int r0 = tile * LNB_ROWS;
     f32x4 g[LNB_ROWS / 32][CPL];
 #pragma unroll
     for (int it = 0; it < LNB_ROWS / 32; ++it) {
@@ -639,6 +644,7 @@ __global__ __launch_bounds__(256) void drop_cast_kernel(CastArgs a) {
             *(bf16x4_t*)(a.dy + (size_t)row * a.DP + c) = vb;
         }
     }
+    }  // tiles
     // EXEC is whole again here
 #pragma unroll
     for (int k = 0; k < CPL; ++k)
@@ -936,7 +942,7 @@ int launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
 
 int launch_drop_cast(const CastArgs& a, hipStream_t s) {
     if (a.DP > 256 || a.DP % 32) return V1T_ERR_UNSUPPORTED;
-    const dim3 grid((a.rows + LNB_ROWS - 1) / LNB_ROWS);
+    const dim3 grid(std::min((a.rows + LNB_ROWS - 1) / LNB_ROWS, 512));  // <= two workgroups per CU, each over several tiles
     switch (a.DP / 32) {
 #define V1T_DC(C) case C: hipLaunchKernelGGL(drop_cast_kernel<C>, grid, dim3(256), 0, s, a); break;
         V1T_DC(1) V1T_DC(2) V1T_DC(3) V1T_DC(4) V1T_DC(5) V1T_DC(6) V1T_DC(7) V1T_DC(8)
