@@ -968,11 +968,11 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         CHECK(launch_gemm_nt(g, EPI_F32, s));
         CHECK(launch_ln_param_grad(du, h->PD, (const float*)(ws + w.u32), h->PDX, (const float*)(ws + w.pmean1), (const float*)(ws + w.prstd1), R, h->PD,
                                    grads + h->o_pln_w, grads + h->o_pln_b, s));
-    } else if (h->s_pw >= 0) {  // dpos / dcls + bf16 gradient, U recomputed from the images, then dW (+ dbias through the ones column)
+    } else if (h->s_pw >= 0) {  // dpos / dcls + bf16 gradient, then dW (+ dbias through the ones column) against the unfolded patches the forward left
+        // in the workspace (its bf16 plane; round 2 unfolded the images a second time here: 65 us per step)
         bf16_t* gd = (bf16_t*)(sc + sl.pgd);
-        bf16_t* u = (bf16_t*)(sc + sl.pu);
+        const bf16_t* u = (const bf16_t*)((const char*)workspace + w.u_hi);
         CHECK(launch_patch_bwd_pos_cast(pa, gd, s));
-        CHECK(launch_patch_unfold(pa, u, nullptr, 0, h->PDX, s));
         GemmTNArgs t{};
         t.Y = gd; t.ldy = DP; t.X = u; t.ldx = h->PDX; t.M = R; t.NY = DP; t.NX = h->PDX; t.dW = grads + h->o_pw; t.ldw = h->PD;
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->PDX; t.xseg_valid = h->PD; t.alpha = 1.f;
