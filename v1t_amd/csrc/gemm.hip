@@ -116,7 +116,7 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
 // NW waves per workgroup = 32*NW rows (only 4 is launched: 64-row workgroups measured the same time on the
 // single-column-tile GEMMs, which are bound by how they read A, not by workgroups in flight).
 template <int NBLK, int EPI, int NW, int BK, bool F16 = false, bool RD = false>
-__global__ __launch_bounds__(64 * NW, ((EPI == EPI_BIAS_GELU && BK == 32 && NBLK <= 4) || ((EPI == EPI_BIAS_RES || EPI == EPI_DGELU || EPI == EPI_BF16) && BK == 32 && NW == 4)) ? 3 : 1) void gemm_nt_kernel(GemmNTArgs g) {
+__global__ __launch_bounds__(64 * NW, ((EPI == EPI_BIAS_GELU && BK == 32 && NBLK <= 4) || ((EPI == EPI_BIAS_RES || EPI == EPI_DGELU || EPI == EPI_BF16 || EPI == EPI_PATCH) && BK == 32 && NW == 4)) ? 3 : 1) void gemm_nt_kernel(GemmNTArgs g) {
     static_assert(!RD || (EPI == EPI_BF16 && NBLK == 5), "row dot: bf16 output, one 160-column tile per head");
     constexpr int BM = 32 * NW, NT = 64 * NW;
     constexpr int LS = BK + 8, KC = BK / 8;  // LDS row stride (16-B pad: 80 / 144 B), 16-B chunks per row
