@@ -34,3 +34,27 @@ def test_gpus_without_enough_devices_fails_loudly():
 def test_world_size_mismatch_is_an_error():
     r = _run("--gpus", "1", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert r.returncode != 0
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_on_the_gpu():
+    """One short run of the headline configuration: exactly one JSON line, the keys the driver reads, numbers consistent with each
+    other (value = images of a step / its time, the dominant kernel's launches inside the timed region, fraction = achieved / peak)."""
+    r = _run("--steps", "3", "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "images/s" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] / d["ms_per_step"] * 1e3) <= 1e-3 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] in ("TFLOP/s", "GB/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.05 < rf["frac"] < 1.0
+    assert rf["launches"] >= 3 * 4  # four blocks per step, every launch of the timed steps measured (hipEvents on the kernel's stream)
+    assert 5.0 < d["ms_per_step"] < 200.0
