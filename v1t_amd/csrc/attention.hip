@@ -1380,40 +1380,47 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         const int r = min(perm_row(min(p / Dma::CPR, 31)), max_row), cc = min(p % Dma::CPR, DP / 8 - 1);  // LDS position -> the row it holds
         return (unsigned)((r * ld + 8 * cc) * 2);
     };
-    auto dma16 = [&](const void* gbase, unsigned voff, const void* lds_dst) {  // scalar base + lane offset, 16 B per lane
-        unsigned keep;
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_dst);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(gbase) : "memory");
-    };
-    auto dma4 = [&](const void* gbase, unsigned voff, const void* lds_dst) {  // 4 B per lane (row constants)
-        unsigned keep;
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_dst);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(gbase) : "memory");
-    };
     const bf16_t* const img = wave < 4 ? a.dO + (size_t)b * a.T * a.lddo + h * DP : qkv_b + h * DP;  // this wave's tile source
     const int ld = wave < 4 ? a.lddo : a.ldqkv;
-    unsigned voff[3];
+    unsigned voff[3];  // (biased: see stage())
 #pragma unroll
-    for (int i = 0; i < 3; ++i) voff[i] = lane_off(i, ld, 31);
+    for (int i = 0; i < 3; ++i) voff[i] = lane_off(i, ld, 31) + 2048u - 1024u * i;
     const float* rcg = (const float*)(a.ds + attn_ds_elems(a.B, a.H, a.T)) + bh * TPQ;  // nlse; ndelta B*H*TPQ floats behind it
     const unsigned rc_voff = (unsigned)(((lane & 31) + (h2 ? attn_rc_floats(a.B, a.H, a.T) : 0)) * 4);
+    // LDS destinations as 32-bit byte addresses computed from one base (a generic-pointer form costs a null check and 64-bit arithmetic per
+    // operation - for lds.rc[slot] even a 64-bit division - in scalar instructions, which take the wave's issue slots like vector ones); the
+    // two or three pieces of a tile share ONE M0 set-up: the instruction offset advances the LDS and the global address alike, so piece i
+    // carries offset 1024 i and a lane offset of (its own) - 1024 i + DBIAS against a base lowered by DBIAS
+    constexpr unsigned DBIAS = 2048, SLOT_BYTES = Dma::LDS_ELEMS * 2;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&lds);
+    const unsigned tile0 = lds_base + (unsigned)(wave < 4 ? offsetof(Bwd2Lds<DP>, d) : offsetof(Bwd2Lds<DP>, q)) + 1024u * (3 * pw);  // slot 0, this wave's first piece
+    const unsigned rc0 = lds_base + (unsigned)offsetof(Bwd2Lds<DP>, rc);
     auto stage = [&](int t) {  // this wave's three operations of tile t
-        const int slot = b2_slot(t);
-        bf16_t* tile = wave < 4 ? lds.d[slot] : lds.q[slot];
-        const bf16_t* src = img + (size_t)32 * t * ld;
+        const unsigned slot = (unsigned)b2_slot(t);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(tile0 + slot * SLOT_BYTES);
+        const char* src = (const char*)(img + (size_t)32 * t * ld) - DBIAS;
         unsigned v[3] = {voff[0], voff[1], voff[2]};
         if (32 * t + 32 > a.T) {
             asm volatile("; ragged tile: rows beyond T are clamped to T - 1 (finite data; P = 0 there)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 3; ++i) v[i] = lane_off(i, ld, a.T - 1 - 32 * t);
+            for (int i = 0; i < 3; ++i) v[i] = lane_off(i, ld, a.T - 1 - 32 * t) + DBIAS - 1024u * i;
         }
-        dma16(src, v[0], tile + 512 * (3 * pw));
-        dma16(src, v[1], tile + 512 * (3 * pw + 1));
-        if (!last) dma16(src, v[2], tile + 512 * (3 * pw + 2));
-        else if (wave < 4) dma16(src, v[1], tile + 512 * (3 * pw + 1));
-        else dma4(rcg + 32 * t, rc_voff, lds.rc[slot]);  // lanes 0-31: -lse2/c -> rc[0..31], lanes 32-63: -keep_prob delta -> rc[32..63]
+        unsigned keep;
+        if (!last) {
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\tglobal_load_lds_dwordx4 %3, %5 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %4, %5 offset:2048\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(src) : "memory");
+        } else if (wave < 4) {  // pair 3 has no third piece: its producer repeats piece 1 (every wave issues exactly three operations per tile)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %3, %4 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %3, %4 offset:1024\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v[0]), "v"(v[1]), "s"(src) : "memory");
+        } else {  // ... its consumer stages the row constants: lanes 0-31: -lse2 -> rc[0..31], lanes 32-63: -keep_prob delta -> rc[32..63]
+            const unsigned rcv = __builtin_amdgcn_readfirstlane(rc0 + slot * 256u);
+            const float* rsrc = rcg + 32 * t;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %3, %4 offset:1024\n\t"
+                         "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %6, %7\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v[0]), "v"(v[1]), "s"(src), "s"(rcv), "v"(rc_voff), "s"(rsrc) : "memory");
+        }
     };
 
     // ---- prologue: the workgroup's K / V rows (128 keys) as eight 32-row tile images in ring slots 0-2 and the hand-off
