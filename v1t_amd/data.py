@@ -187,6 +187,13 @@ class MiceDataset:
     def __len__(self):
         return len(self.indexes)
 
+    def compute_response_precision(self):
+        """Re-derive the response standardisation from `response_stats` (data.py:394-404; public there, called by its constructor):
+        refreshes the `response` row of the transform table, which the device gather and the host methods read."""
+        self.transforms["response"] = _standardisation(self.stats)["response"]
+        self._response_precision = self.transforms["response"].mul
+        self._dev = None  # packed device copies carry the old precision
+
     image_stats = property(lambda self: self.stats["image"])
     response_stats = property(lambda self: self.stats["response"])
     behavior_stats = property(lambda self: self.stats["behavior"])

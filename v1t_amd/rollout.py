@@ -36,6 +36,11 @@ def attention_probabilities(core: ViTCore, images: torch.Tensor, behaviors: torc
     """Per-head softmax probabilities of every block, (B, blocks, heads, T, T) fp32 - the tensor the reference's Recorder returns
     (attention_rollout.py:31-36, 76) - recomputed block by block from the saved q / k and log-sum-exp (`v1t_attention_probs`).
     175 MB per image at the default size, like the reference's: meant for a handful of images."""
+    if not getattr(core, "cls_tokens", 1):
+        # (the CCT plan's qkv rows are 3 * H * round_up(D / H^2, 32) wide, not 3 * H * padded_dim: reading them with the ViT geometry would
+        # run past the plane)
+        raise NotImplementedError("per-head attention probabilities are exposed for the ViT core only; the reference's Recorder does not find "
+                                  "cct.py's Attention modules either (attention_rollout.py:31-36)")
     was_training = core.training
     core.train(False)
     try:

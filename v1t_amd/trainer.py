@@ -151,9 +151,14 @@ class _NativeStep:
             return None
         if crop.image_shifter is not None or crop.crop_scale < 1 or crop.behavior_mode == 1:
             return None
-        for m, _, _ in units:
+        gh, gw = core.output_shape[1:]
+        if gh * gw > 4096:
+            return None  # the split (sort / dz / parameter) readout backward needs the sorted form: LDS histogram of <= 4096 cells (readout.hip)
+        for m, b_, _ in units:
             ro = model.readouts[m]
             if type(ro) is not Gaussian2DReadout or "forward" in ro.__dict__:
+                return None
+            if int(L.load().v1t_gaussian2d_backward_ws_bytes(int(b_["image"].shape[0]), gh, gw, ro.num_neurons)) <= 0:
                 return None
             if model.core_shifter is not None and len(model.core_shifter[m].mlp) != 6:
                 return None
@@ -262,17 +267,18 @@ class _NativeStep:
         # the shared buffers of this step (previous step's readers are behind us on this stream or were awaited at its end)
         self.zeros.zero_()  # per-unit loss scalars, d shift accumulators
         self.gout.zero_()
+        # dtype / layout conversions of the per-mouse inputs run HERE, on the main stream in front of `start`: the side streams read them
+        # behind that event (no-ops for fp32 contiguous batches; an fp64 or strided batch would otherwise race with the shifter forward)
+        pups = [b["pupil_center"].to(torch.float32).contiguous() for _, b, _ in units]
+        ys = [b["response"].to(torch.float32).contiguous() for _, b, _ in units]
         start = torch.cuda.Event()
         start.record(main)
         trainer._eps_state = (trainer._eps_state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         side = lambda i: (torch.cuda.stream(streams[i]) if streams else contextlib.nullcontext())  # noqa: E731
         # ---- per mouse, core-independent part
-        pups, ys = [], []
         for i, ((m, b, full), t_) in enumerate(zip(units, self.tails)):
             n, N, ro = t_["n"], t_["N"], t_["ro"]
-            pup = b["pupil_center"].to(torch.float32).contiguous()
-            pups.append(pup)
-            ys.append(b["response"].to(torch.float32).contiguous())
+            pup = pups[i]
             if streams:
                 streams[i].wait_event(start)  # parameters of the previous optimizer step, inputs
             with side(i):
@@ -349,7 +355,7 @@ class _NativeStep:
                                             self.ws.data_ptr(), self.scratch.data_ptr(), self.sb, 1, seed, None, self.gout.data_ptr(), core._arena.grad.data_ptr(),
                                             ev_arr, st), "vit_backward")
         # second pass over the mice: what the core's backward does not wait for. Issued AFTER every mouse's dz chain and after
-        # the core's backward (V1T_TAIL_ORDER=0: before it) because the streams share four in-order hardware queues: work enqueued
+        # the core's backward because the streams share four in-order hardware queues: work enqueued
         # earlier would sit in front of another mouse's dz chain, or of the backward itself
         off = 0
         for i, ((m, b, full), t_) in enumerate(zip(units, self.tails)):
