@@ -51,6 +51,21 @@ def algorithmic_flops(args, n_neurons: int) -> dict:
     return {"T": T, "fwd_per_image": fwd, "train_per_image": 3 * fwd, "attn_fwd_per_image_block": 4 * H * T * T * D}
 
 
+def measured_peak(lib, L) -> dict:
+    """The bf16 MFMA rate THIS device sustains (the roofline fraction against the datasheet AND the measured peak):
+    `v1t_mfma_peak_probe` runs v_mfma_f32_32x32x16_bf16 back to back on every CU (register operands, random data) in the un-timed
+    set-up. MI355X is power-limited under matrix load: the shader clock falls from 2.4 GHz to ~1.5 GHz, so the sustained peak is
+    ~1.7 PFLOP/s, not the nominal 2.5 (profiles/r04_lds_peak.txt has the same loop with operands streamed from LDS: ~1.4-1.55)."""
+    best = None
+    for wps in (1, 2):
+        tf, ghz, cpm = C.c_double(), C.c_double(), C.c_double()
+        L.check(lib.v1t_mfma_peak_probe(4000, wps, C.byref(tf), C.byref(ghz), C.byref(cpm), L.stream()), "mfma_peak_probe")
+        r = {"tflops": round(tf.value, 1), "clock_ghz": round(ghz.value, 3), "cycles_per_mfma_per_simd": round(cpm.value, 2), "waves_per_simd": wps}
+        if best is None or r["tflops"] > best["tflops"]:
+            best = r
+    return best
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -410,6 +425,8 @@ def main():
     for _ in range(a.warmup):
         trainer.train_step(batches)
     torch.cuda.synchronize()
+    peak_m = measured_peak(lib, L) if rank == 0 else None  # un-timed set-up, on a warm chip (the clock it reports is the loaded one)
+    torch.cuda.synchronize()
     n_local_launches = 16 * a.steps * len(sharding.local_units()) * args.num_blocks  # up to 15 windows + margin
     L.check(lib.v1t_profile_enable(a.profile_class, n_local_launches + 8))
     def window():
@@ -481,8 +498,12 @@ def main():
             "model_frac_of_bf16_peak": round(fl["train_per_image"] * images / dt / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": {"kernel": label, "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": None if traffic is None else "measured offline: " + os.path.relpath(PMC_FILE, ROOT),
-                         "launches": launches.value, "avg_ms": round(avg_ms, 4), "flops_per_launch": per_launch},
+                         "launches": launches.value, "avg_ms": round(avg_ms, 4), "flops_per_launch": per_launch,
+                         "peak_measured": peak_m["tflops"], "frac_of_measured": round(achieved / peak_m["tflops"], 4), "peak_measured_clock_ghz": peak_m["clock_ghz"],
+                         "peak_measured_how": f"v1t_mfma_peak_probe: v_mfma_f32_32x32x16_bf16 back to back on all CUs, register operands, random data, "
+                                              f"{peak_m['waves_per_simd']} wave(s) per SIMD, {peak_m['cycles_per_mfma_per_simd']} cycles per MFMA and SIMD; nominal clock 2.4 GHz"},
         }
+        line["model_frac_of_measured_peak"] = round(fl["train_per_image"] * images / dt / 1e12 / (peak_m["tflops"] * world), 4)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

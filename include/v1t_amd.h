@@ -307,6 +307,12 @@ int v1t_rollout_matmul(const float* A, const float* rowsum, const float* Xin, fl
 int v1t_profile_enable(int kernel_class, int max_launches);   /* kernel_class < 0 disables */
 int v1t_profile_read(int* launches, double* total_ms);        /* synchronises the recorded events */
 
+/* Measurement aid (no reference counterpart; SURVEY.md 8d asks for the roofline fraction against the datasheet AND the measured peak):
+ * runs v_mfma_f32_32x32x16_bf16 back to back on every CU (register operands, random data, `waves_per_simd` 1 or 2, 16 * iters MFMAs
+ * per wave) and returns the TFLOP/s from the wall time of the launch, the shader clock it held (s_memtime / s_memrealtime) and the
+ * cycles per MFMA and SIMD. Allocates and frees its own few KB; synchronises `stream`. */
+int v1t_mfma_peak_probe(int iters, int waves_per_simd, double* tflops, double* ghz, double* cycles_per_mfma, void* stream);
+
 /* LayerNorm (vit.py:220,145) forward: z bf16 (rows, DP) = LN(x (+ inject[b])) ; backward: see
  * csrc/elementwise.h LnBwdArgs (gout = gin + dLN; optional token-sum, next-branch cast + bias colsum) */
 int v1t_layernorm_forward(const float* x, const float* inject, float* xout, const float* gamma,

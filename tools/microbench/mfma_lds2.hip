@@ -137,13 +137,15 @@ void run(const char* name, int lds_bytes_per_mfma, unsigned long long* d, float*
                 }
             cyc /= n; rt /= n;
             const double mf = 20.0 * iters, wps = waves / 4.0;
-            const double cpm_simd = cyc / mf / wps;               // cycles per MFMA per SIMD
+            // per SIMD: the LAST wave to finish bounds the pipe's busy time (with two waves the older one is served first and finishes at
+            // half time, so the mean over waves would read 24 cycles per MFMA on a 32-cycle pipe)
+            const double cpm_simd = cmax / mf / wps;               // cycles per MFMA per SIMD
             const double bclk = lds_bytes_per_mfma * 4.0 / cpm_simd;  // 4 SIMDs
             const double ghz = cyc / (rt * 10.0) ;                 // realtime ticks are 10 ns
             const double tflops = (double)grid * waves * mf * 32768.0 / (best * 1e-3) * 1e-12;
             snprintf(line, sizeof line,
-                     "%-34s %3d CU %d w/SIMD: %6.2f cyc/MFMA/SIMD (max wave %6.2f)  LDS %6.1f B/clk/CU  clock %.3f GHz  %8.1f TFLOP/s wall (%.3f ms)\n",
-                     name, grid, waves / 4, cpm_simd, cmax / mf / wps, bclk, ghz, tflops, best);
+                     "%-34s %3d CU %d w/SIMD: %6.2f cyc/MFMA/SIMD (mean wave %6.2f)  LDS %6.1f B/clk/CU  clock %.3f GHz  %8.1f TFLOP/s wall (%.3f ms)\n",
+                     name, grid, waves / 4, cpm_simd, cyc / mf / wps, bclk, ghz, tflops, best);
             emit(line);
         }
     }

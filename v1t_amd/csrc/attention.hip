@@ -1729,8 +1729,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
             }
         }
 #ifndef V1T_B2_NOSTORE
-        *(u32x4*)dst = m0;
-        *(u32x4*)(dst + 512) = m1;
+        // non-temporal: 2.5 GB per launch, written once and read by the NEXT kernel - keeping the lines in L2 only evicts the K / V / Q / dO
+        // rows the workgroups of this XCD re-read (round 4 A/B, tools/ab_many.py: backward 2557 -> 2514 us per 112-image launch, same checksum)
+        __builtin_nontemporal_store(m0, (u32x4*)dst);
+        __builtin_nontemporal_store(m1, (u32x4*)(dst + 512));
 #else
         asm volatile("" ::"v"(m0), "v"(m1), "v"(dst));
 #endif

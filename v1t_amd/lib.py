@@ -32,6 +32,7 @@ class VitConfig(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/v1t_amd.h
 SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_abi_version": (c_int, []),
+    "v1t_mfma_peak_probe": (c_int, [c_int, c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), c_void_p]),
     "v1t_error_string": (C.c_char_p, [c_int]),
     "v1t_vit_create": (c_int, [C.POINTER(VitConfig), C.POINTER(c_void_p)]),
     "v1t_vit_destroy": (None, [c_void_p]),
