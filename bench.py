@@ -59,7 +59,7 @@ def measured_peak(lib, L) -> dict:
     best = None
     for wps in (1, 2):
         tf, ghz, cpm = C.c_double(), C.c_double(), C.c_double()
-        L.check(lib.v1t_mfma_peak_probe(4000, wps, C.byref(tf), C.byref(ghz), C.byref(cpm), L.stream()), "mfma_peak_probe")
+        L.check(lib.v1t_mfma_peak_probe(30000 // wps, wps, C.byref(tf), C.byref(ghz), C.byref(cpm), L.stream()), "mfma_peak_probe")
         r = {"tflops": round(tf.value, 1), "clock_ghz": round(ghz.value, 3), "cycles_per_mfma_per_simd": round(cpm.value, 2), "waves_per_simd": wps}
         if best is None or r["tflops"] > best["tflops"]:
             best = r

@@ -307,10 +307,67 @@ int v1t_rollout_matmul(const float* A, const float* rowsum, const float* Xin, fl
 int v1t_profile_enable(int kernel_class, int max_launches);   /* kernel_class < 0 disables */
 int v1t_profile_read(int* launches, double* total_ms);        /* synchronises the recorded events */
 
+/* ------------------------------------------------------------------ the per-mouse tails of a training step, one launch per stage
+ * The reference's step loops over mice (train.py:97-111): per mouse the core shifter MLP (core_shifter.py:24-40, model.py:86-92), the
+ * readout's sample positions mu / sigma . eps / clamp / + shift (gaussian2d.py:188-235, 265-268), the Gaussian2d readout
+ * (gaussian2d.py:270-276), ELU + 1 (models/utils.py:109-118), the Poisson loss with its sqrt(ds_size / batch) scale (losses.py:141-166,
+ * train.py:64-72) and their backward. A `v1t_tail_unit` names one local mouse-batch ("unit"): its n_images images sit at image_offset in
+ * the shared token buffer of the core (one core pass over all local mice). Each entry point below runs ONE launch per kernel stage over
+ * all units (tables of <= 8 units per launch) instead of one chain of ~11 small launches per mouse; the arithmetic per unit is that of
+ * v1t_core_shifter_*, v1t_normal_fill, v1t_readout_grid_*, v1t_gaussian2d_*_parts and v1t_elu1_poisson. */
+typedef struct v1t_tail_unit {
+    int n_images, n_neurons;      /* images of this unit, neurons of its mouse */
+    int image_offset;             /* first image of the unit in the shared (B, T, DP) token / token-gradient buffers */
+    int grid_dim;                 /* grid predictor input dim 2 / 3; 0: free parameter `mu` */
+    unsigned int eps_stream;      /* Philox stream id of this unit's position noise (v1t_normal_fill) */
+    int fill_eps;                 /* 1: draw eps in v1t_tails_prepare; 0: `eps` already holds the noise to use (replayed draws) */
+    float loss_scale;             /* sqrt(ds_size / batch size) */
+    int feat_stride;              /* floats per neuron row of the neuron-major feature storage */
+    const float* pupil;           /* (n, 2) pupil centres: the core shifter's input (NULL without a shifter) */
+    const float* response;        /* (n, N) targets */
+    const float* sp[6];           /* core shifter W0, b0, W2, b2, W4, b4 */
+    float* dsp[6];                /* ... their gradients (+=) */
+    const float* src;             /* (N, grid_dim) normalised cortical coordinates */
+    const float* gp[4];           /* grid predictor W0, b0, W2, b2 */
+    float* dgp[4];                /* ... their gradients (+=) */
+    const float* mu;  float* dmu; /* free-parameter positions (grid_dim == 0) and gradient */
+    const float* sigma; float* dsigma;
+    const float* feat; float* dfeat;   /* [N][feat_stride] features and gradient (+=) */
+    const float* bias; float* dbias;   /* [N] or NULL */
+    float* shift; float* dshift;  /* (n, 2) scratch: shifter output / its gradient (dshift zero on entry of v1t_tails_backward); NULL: no shifter */
+    float* eps; float* grid; float* dgrid;   /* (n, N, 2) scratch */
+    float* u; float* yhat; float* du;        /* (n, N) scratch: readout pre-activation, prediction (may be NULL), dLoss/du */
+    float* loss;                  /* this unit's loss accumulator (+=, atomic: zero it per step) */
+    void* rws; long long rws_bytes;   /* v1t_gaussian2d_backward_ws_bytes(n, gh, gw, N) */
+    void* gws; long long gws_bytes;   /* v1t_readout_grid_backward_ws_bytes(n, N) */
+} v1t_tail_unit;
+/* stage 1, needs nothing from the core: shifter forward, position noise (units with fill_eps), sample positions, tap sort */
+int v1t_tails_prepare(const v1t_tail_unit* units, int n_units, unsigned long long eps_seed, int gh, int gw, void* stream);
+/* stage 2, behind the core forward: readout -> ELU1 + Poisson (du, per-unit loss, loss_total += every unit's loss; NULL: skip) ->
+ * dz gathered into dtokens (+=, zero it per step: v1t_fill_zero). tokens / dtokens: element (image b, cell, channel c) at
+ * [b * zsb + cell * zsc + c], pointing at the first cell (class-token row skipped). */
+int v1t_tails_forward(const v1t_tail_unit* units, int n_units, const float* tokens, float* dtokens, long long zsb, long long zsc, int C, int gh,
+                      int gw, float* loss_total, void* stream);
+/* stage 3, may overlap the core backward: d features / d bias / d grid, grid-predictor (or mu) and sigma gradients, d shift, shifter gradients */
+int v1t_tails_backward(const v1t_tail_unit* units, int n_units, const float* tokens, long long zsb, long long zsc, int C, int gh, int gw,
+                       void* stream);
+/* AdamW (+ folded L1) over several arena ranges in one launch per 24 ranges: what v1t_adamw_step does per range */
+typedef struct v1t_adam_range {
+    float* p; float* g; float* m; float* v;
+    long long n;
+    float lr, l1;
+    int step;   /* 1-based step count of the arena the range belongs to */
+    int pad_;
+} v1t_adam_range;
+int v1t_adamw_multi(const v1t_adam_range* ranges, int n, float beta1, float beta2, float eps, float weight_decay, int zero_grad, void* stream);
+/* zero `bytes` bytes at a 16-byte aligned device address (the step's token-gradient buffer and loss / d shift accumulators) */
+int v1t_fill_zero(void* p, long long bytes, void* stream);
+
 /* Measurement aid (no reference counterpart; SURVEY.md 8d asks for the roofline fraction against the datasheet AND the measured peak):
  * runs v_mfma_f32_32x32x16_bf16 back to back on every CU (register operands, random data, `waves_per_simd` 1 or 2, 16 * iters MFMAs
- * per wave) and returns the TFLOP/s from the wall time of the launch, the shader clock it held (s_memtime / s_memrealtime) and the
- * cycles per MFMA and SIMD. Allocates and frees its own few KB; synchronises `stream`. */
+ * per wave), four launches back to back, and returns for the LAST one (the sustained rate - the chip's power management needs some
+ * milliseconds of load to settle: pass iters for >= 10 ms per launch) the TFLOP/s from its wall time, the shader clock it held
+ * (s_memtime / s_memrealtime) and the cycles per MFMA and SIMD. Allocates and frees its own few KB; synchronises `stream`. */
 int v1t_mfma_peak_probe(int iters, int waves_per_simd, double* tflops, double* ghz, double* cycles_per_mfma, void* stream);
 
 /* LayerNorm (vit.py:220,145) forward: z bf16 (rows, DP) = LN(x (+ inject[b])) ; backward: see

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libv1t_amd.so")
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "readout.hip", "gridprep.hip", "metrics.hip", "data.hip", "probe.hip"]
+SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "readout.hip", "gridprep.hip", "metrics.hip", "data.hip", "probe.hip", "tails.hip"]
 HEADERS = ["common.h", "gemm.h", "attention.h", "elementwise.h", "readout.h", "gridprep.h", os.path.join("..", "..", "include", "v1t_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 EXTRA = os.environ.get("V1T_HIPCC_EXTRA", "").split()  # dev: extra compiler flags (ablations)

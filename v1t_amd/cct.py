@@ -61,6 +61,7 @@ class CCTCore(ViTCore):
         assert 0.0 <= self.drop_path_rate < 1.0
         rates64 = np.linspace(0, self.drop_path_rate, args.num_blocks)  # float64, as cct.py:209 keeps them
         self.drop_path_rates = torch.from_numpy(rates64).to(torch.float32)
+        self._drop_path_rates64 = rates64
         self.pos_emb = pos
         c, h, w = input_shape
         self.mouse_ids = list(args.output_shapes.keys())
@@ -101,7 +102,7 @@ class CCTCore(ViTCore):
             mha.qkv = lin(D, 3 * inner, False)
             mha.projection = _seq(lin(inner, D), nn.Identity())
             dp = _ParamBag()
-            dp.register_buffer("keep_prop", torch.tensor(1 - rates64[k]))  # float64 buffer: torch.tensor(1 - np.float64), as the reference's DropPath
+            dp.register_buffer("keep_prop", torch.tensor(1 - self._drop_path_rates64[k]))  # float64 buffer: torch.tensor(1 - np.float64), as the reference's DropPath
             block = nn.ModuleDict({"mha": mha, "mlp": _seq(nn.LayerNorm(D), lin(D, M), nn.Identity(), nn.Identity(), lin(M, D), nn.Identity()), "drop_path": dp})
             if self.behavior_mode in (3, 4):
                 bm = _ParamBag()

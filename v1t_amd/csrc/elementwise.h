@@ -157,11 +157,16 @@ struct LossArgs {
     float* yhat;         // [B][N] or nullptr
     float* du;           // [B][N] or nullptr: dLoss/du * gscale
     float* loss;         // scalar accumulator (atomic) or nullptr
+    float* loss_total;   // second accumulator shared by several units (atomic) or nullptr
     long long n;
     float loss_scale;    // sqrt(ds_size / batch)
     float gscale;        // upstream gradient of the loss (1 for plain training)
 };
 int launch_elu1_poisson(const LossArgs& a, hipStream_t s);
+constexpr int LOSS_MAX_UNITS = 8, ADAM_MAX_RANGES = 24;
+int launch_elu1_poisson_multi(const LossArgs* a, int n, hipStream_t s);  // n <= LOSS_MAX_UNITS units in one launch
+int launch_adamw_multi(const AdamArgs* a, int n, hipStream_t s);         // any n: one launch per ADAM_MAX_RANGES pieces
+int launch_fill_zero(void* p, long long bytes, hipStream_t s);
 
 int launch_dropout_mask(uint8_t* out, long long rows, long long cols, DropCfg d, hipStream_t s);
 int launch_attn_dropout_mask(uint8_t* out, long long rows, long long T, AttnDrop d, hipStream_t s);

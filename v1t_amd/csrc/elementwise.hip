@@ -748,10 +748,10 @@ __global__ __launch_bounds__(256) void bmlp_bwd_kernel(BmlpBatch bb) {
 
 // ------------------------------------------------------------------------------------------
 // Fused L1-sign + AdamW (torch.optim.AdamW semantics, train.py:216-223) over a flat fp32 arena.
-__global__ void adamw_kernel(AdamArgs a) {
+DEVFN void adamw_body(const AdamArgs& a, int bx, int nbx) {
     const float step_size = a.lr / a.bc1;
     const float inv_sqrt_bc2 = rsqrtf(a.bc2);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < a.n; i += (long long)nbx * blockDim.x) {
         float p = a.p[i], g = a.g[i];
         if (a.l1 != 0.f) g += a.l1 * ((p > 0.f) ? 1.f : ((p < 0.f) ? -1.f : 0.f));
         if (a.weight_decay != 0.f) p *= 1.f - a.lr * a.weight_decay;
@@ -763,6 +763,18 @@ __global__ void adamw_kernel(AdamArgs a) {
         a.v[i] = v;
         if (a.zero_grad) a.g[i] = 0.f;
     }
+}
+__global__ void adamw_kernel(AdamArgs a) { adamw_body(a, blockIdx.x, gridDim.x); }
+// several (arena range, learning rate, L1 coefficient) pieces in one launch: the per-mouse arenas of a training step
+struct AdamMulti {
+    AdamArgs a[ADAM_MAX_RANGES];
+    int start[ADAM_MAX_RANGES + 1];
+    int n;
+};
+__global__ void adamw_multi_kernel(AdamMulti m) {
+    int u = 0;
+    while (u + 1 < m.n && (int)blockIdx.x >= m.start[u + 1]) ++u;
+    adamw_body(m.a[u], blockIdx.x - m.start[u], m.start[u + 1] - m.start[u]);
 }
 
 __global__ void l1_sum_kernel(const float* __restrict__ p, long long n, float scale, float* out) {
@@ -783,11 +795,10 @@ __global__ void l1_grad_kernel(const float* __restrict__ p, float* g, long long 
 }
 
 // ELU1 (models/utils.py:109-118) + Poisson loss (losses.py:153-166) forward and dLoss/du.
-__global__ void elu1_poisson_kernel(LossArgs a) {
-    __shared__ float sred[4];
+DEVFN void elu1_poisson_body(const LossArgs& a, int bx, int nbx, float (&sred)[4]) {
     const float eps = 1.1920928955078125e-07f;
     float ls = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < a.n; i += (long long)nbx * blockDim.x) {
         const float u = a.u[i];
         const float yh = (u > 0.f) ? u + 1.0f : expm1f(u) + 1.0f;
         if (a.yhat) a.yhat[i] = yh;
@@ -804,8 +815,33 @@ __global__ void elu1_poisson_kernel(LossArgs a) {
         ls = wave_sum(ls);
         if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = ls;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(a.loss, (sred[0] + sred[1] + sred[2] + sred[3]) * a.loss_scale);
+        if (threadIdx.x == 0) {
+            const float v = (sred[0] + sred[1] + sred[2] + sred[3]) * a.loss_scale;
+            atomicAdd(a.loss, v);
+            if (a.loss_total) atomicAdd(a.loss_total, v);  // the step's loss over all units (no host-side sum of the per-unit scalars)
+        }
     }
+}
+__global__ void elu1_poisson_kernel(LossArgs a) {
+    __shared__ float sred[4];
+    elu1_poisson_body(a, blockIdx.x, gridDim.x, sred);
+}
+struct LossMulti {
+    LossArgs a[LOSS_MAX_UNITS];
+    int start[LOSS_MAX_UNITS + 1];
+    int n;
+};
+__global__ void elu1_poisson_multi_kernel(LossMulti m) {
+    __shared__ float sred[4];
+    int u = 0;
+    while (u + 1 < m.n && (int)blockIdx.x >= m.start[u + 1]) ++u;
+    elu1_poisson_body(m.a[u], blockIdx.x - m.start[u], m.start[u + 1] - m.start[u], sred);
+}
+// zero fill (the step's token-gradient buffer and small accumulators): 16 B per lane, tail by bytes
+__global__ __launch_bounds__(256) void fill_zero_kernel(char* p, long long bytes) {
+    const long long n16 = bytes >> 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) ((u32x4*)p)[i] = u32x4{0u, 0u, 0u, 0u};
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) p[(n16 << 4) + threadIdx.x] = 0;
 }
 
 __global__ void dropout_mask_kernel(uint8_t* out, long long rows, long long cols, DropCfg d) {
@@ -996,6 +1032,45 @@ int launch_l1_grad(const float* p, float* g, long long n, float scale, hipStream
     if (n <= 0) return V1T_OK;
     hipLaunchKernelGGL(l1_grad_kernel, dim3(nblocks(n, 4096)), dim3(256), 0, s, p, g, n, scale);
     return ok();
+}
+int launch_adamw_multi(const AdamArgs* a, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += ADAM_MAX_RANGES) {
+        AdamMulti m{};
+        int tot = 0, k = 0;
+        for (int i = i0; i < n && i < i0 + ADAM_MAX_RANGES; ++i) {
+            if (a[i].n <= 0) continue;
+            m.a[k] = a[i];
+            m.start[k] = tot;
+            tot += nblocks(a[i].n, 4096);
+            ++k;
+        }
+        m.start[k] = tot;
+        m.n = k;
+        if (tot) hipLaunchKernelGGL(adamw_multi_kernel, dim3(tot), dim3(256), 0, s, m);
+    }
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_elu1_poisson_multi(const LossArgs* a, int n, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    if (n > LOSS_MAX_UNITS) return V1T_ERR_ARG;
+    LossMulti m{};
+    int tot = 0;
+    for (int u = 0; u < n; ++u) {
+        m.a[u] = a[u];
+        m.start[u] = tot;
+        tot += a[u].n > 0 ? nblocks(a[u].n, 1024) : 0;
+    }
+    m.start[n] = tot;
+    m.n = n;
+    if (tot) hipLaunchKernelGGL(elu1_poisson_multi_kernel, dim3(tot), dim3(256), 0, s, m);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_fill_zero(void* p, long long bytes, hipStream_t s) {
+    if (bytes <= 0) return V1T_OK;
+    const long long n16 = bytes >> 4;
+    const int grid = (int)std::min<long long>(std::max<long long>((n16 + 255) / 256, 1), 4096);
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(grid), dim3(256), 0, s, (char*)p, bytes);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 int launch_elu1_poisson(const LossArgs& a, hipStream_t s) {
     if (a.n <= 0) return V1T_OK;

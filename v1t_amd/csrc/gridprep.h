@@ -48,4 +48,10 @@ struct ShifterArgs {
 int launch_shifter_fwd(const ShifterArgs& a, hipStream_t s);
 int launch_shifter_bwd(const ShifterArgs& a, hipStream_t s);
 int launch_normal_fill(float* out, long long n, uint64_t seed, uint32_t stream_id, hipStream_t s);
+// one launch per stage over n <= GP_MAX_UNITS units (the mice of a training step); the backward form needs every unit's workspace
+constexpr int GP_MAX_UNITS = 8;
+int launch_grid_fwd_multi(const GridArgs* a, int n, hipStream_t s);
+int launch_grid_bwd_multi(const GridArgs* a, void* const* ws, const size_t* ws_bytes, int n, hipStream_t s);
+int launch_shifter_multi(const ShifterArgs* a, int n, bool bwd, hipStream_t s);
+int launch_normal_fill_multi(float* const* out, const long long* n, const uint32_t* stream_id, int units, uint64_t seed, hipStream_t s);
 int launch_concat2(const float* a, int na, const float* b, int nb, int rows, float* out, int ldo, hipStream_t s);

@@ -6,9 +6,12 @@ namespace {
 // 64 neurons per workgroup (lane = neuron), four waves: wave w evaluates hidden units j = w, w+4, ... of the predictor,
 // the partial pre-activations of mu meet in LDS, then wave w writes the images b = w, w+4, ... (a latency-bound kernel:
 // the split quarters the per-neuron chain).
-__global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
-    __shared__ float sW0[GRID_HID * 3], sb0[GRID_HID], sW2[2 * GRID_HID], sb2[2];
-    __shared__ float so[4][2][64];
+struct GridFwdLds {
+    float sW0[GRID_HID * 3], sb0[GRID_HID], sW2[2 * GRID_HID], sb2[2];
+    float so[4][2][64];
+};
+DEVFN void grid_fwd_body(const GridArgs& a, int bx, GridFwdLds& L) {
+    auto& sW0 = L.sW0; auto& sb0 = L.sb0; auto& sW2 = L.sW2; auto& sb2 = L.sb2; auto& so = L.so;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.gd > 0) {
         for (int i = tid; i < GRID_HID * a.gd; i += 256) sW0[i] = a.W0[i];
@@ -16,7 +19,7 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
         for (int i = tid; i < 2 * GRID_HID; i += 256) sW2[i] = a.W2[i];
         if (tid < 2) sb2[tid] = a.b2[tid];
     }
-    const int n = blockIdx.x * 64 + lane;
+    const int n = bx * 64 + lane;
     const bool ok = n < a.N;
     float x[3] = {0.f, 0.f, 0.f};
     if (ok) for (int i = 0; i < a.gd; ++i) x[i] = a.src[(size_t)n * a.gd + i];
@@ -59,6 +62,10 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
         *(float2*)(a.grid + ((size_t)b * a.N + n) * 2) = make_float2(g0, g1);
     }
 }
+__global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
+    __shared__ GridFwdLds L;
+    grid_fwd_body(a, blockIdx.x, L);
+}
 
 // Backward of the grid: 64 neurons per workgroup (lane = neuron), the serial work of a neuron split over the four waves
 // so that the kernel's critical path is a quarter of the per-neuron chain (it is a latency-bound kernel: 125 workgroups
@@ -66,11 +73,14 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
 // images b = w, w+4, ...; the pieces meet in LDS twice (mu, then d mu / d sigma).
 constexpr int GB_WAVES = 4;
 constexpr int GB_SHIFT0 = 192;  // partial row: [0,2) db2, 2 + 6j + {dW2[0][j], dW2[1][j], db0[j], dW0[j][0..2]}, [192, 192 + 2B) d shift
-__global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
-    float* prow = a.part ? a.part + (size_t)blockIdx.x * a.part_stride : nullptr;
-    __shared__ float sW0[GRID_HID * 3], sb0[GRID_HID], sW2[2 * GRID_HID], sb2[2];
-    __shared__ float so[GB_WAVES][2][64];  // partial pre-tanh mu per wave
-    __shared__ float sd[GB_WAVES][6][64];  // partial d mu (2), d sigma (4) per wave
+struct GridBwdLds {
+    float sW0[GRID_HID * 3], sb0[GRID_HID], sW2[2 * GRID_HID], sb2[2];
+    float so[GB_WAVES][2][64];  // partial pre-tanh mu per wave
+    float sd[GB_WAVES][6][64];  // partial d mu (2), d sigma (4) per wave
+};
+DEVFN void grid_bwd_body(const GridArgs& a, int bx, GridBwdLds& L) {
+    float* prow = a.part ? a.part + (size_t)bx * a.part_stride : nullptr;
+    auto& sW0 = L.sW0; auto& sb0 = L.sb0; auto& sW2 = L.sW2; auto& sb2 = L.sb2; auto& so = L.so; auto& sd = L.sd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.gd > 0) {
         for (int i = tid; i < GRID_HID * a.gd; i += 256) sW0[i] = a.W0[i];
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
         for (int i = tid; i < 2 * GRID_HID; i += 256) sW2[i] = a.W2[i];
         if (tid < 2) sb2[tid] = a.b2[tid];
     }
-    const int n = blockIdx.x * 64 + lane;
+    const int n = bx * 64 + lane;
     const bool ok = n < a.N;
     // this wave's images: issue the loads first, they are consumed after the mu exchange
     constexpr int MAXI = 8;  // images per wave per pass
@@ -205,11 +215,15 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void grid_bwd_kernel(GridArgs a) {
+    __shared__ GridBwdLds L;
+    grid_bwd_body(a, blockIdx.x, L);
+}
+
 // Second stage: column sums of the per-workgroup partial rows, added into the gradients (one writer per element).
-__global__ __launch_bounds__(256) void grid_bwd_reduce_kernel(GridArgs a, int nrows) {
-    __shared__ float sp[4][64];
+DEVFN void grid_bwd_reduce_body(const GridArgs& a, int nrows, int bx, float (&sp)[4][64]) {
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = bx * 64 + lane;
     const int ncols = GB_SHIFT0 + (a.dshift ? 2 * a.B : 0);
     const bool live = c < ncols && !(c >= 2 + 6 * GRID_HID && c < GB_SHIFT0);
     float s0 = 0.f, s1 = 0.f;
@@ -234,9 +248,13 @@ __global__ __launch_bounds__(256) void grid_bwd_reduce_kernel(GridArgs a, int nr
     else if (k == 2) a.db0[j] += v;
     else if (k - 3 < a.gd) a.dW0[j * a.gd + k - 3] += v;
 }
+__global__ __launch_bounds__(256) void grid_bwd_reduce_kernel(GridArgs a, int nrows) {
+    __shared__ float sp[4][64];
+    grid_bwd_reduce_body(a, nrows, blockIdx.x, sp);
+}
 
 // shifter: one workgroup; thread b handles sample b (B <= 1024 -> loop)
-__global__ __launch_bounds__(256) void shifter_fwd_kernel(ShifterArgs a) {
+DEVFN void shifter_fwd_body(const ShifterArgs& a) {
     for (int b = threadIdx.x; b < a.B; b += 256) {
         const float x0 = a.pupil[2 * b], x1 = a.pupil[2 * b + 1];
         float h1[5], h2[5];
@@ -258,12 +276,12 @@ __global__ __launch_bounds__(256) void shifter_fwd_kernel(ShifterArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(256) void shifter_fwd_kernel(ShifterArgs a) { shifter_fwd_body(a); }
 
 // Per-thread partial sums of the 57 parameter gradients (dW0 10, db0 5, dW2 25, db2 5, dW4 10, db4 2) over the thread's
 // samples, one DPP wave reduction per gradient, one LDS add per wave: no same-address atomic chains (the previous version
 // issued 57 LDS atomics per sample, all lanes on the same words, and took 33 us for 16 samples).
-__global__ __launch_bounds__(256) void shifter_bwd_kernel(ShifterArgs a) {
-    __shared__ float acc[4][64];
+DEVFN void shifter_bwd_body(const ShifterArgs& a, float (&acc)[4][64]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float g[57];
 #pragma unroll
@@ -335,6 +353,50 @@ __global__ __launch_bounds__(256) void shifter_bwd_kernel(ShifterArgs a) {
     else if (t < 45) a.db2[t - 40] += v;
     else if (t < 55) a.dW4[t - 45] += v;
     else a.db4[t - 55] += v;
+}
+__global__ __launch_bounds__(256) void shifter_bwd_kernel(ShifterArgs a) {
+    __shared__ float acc[4][64];
+    shifter_bwd_body(a, acc);
+}
+
+// ---- several units (mice) per launch (v1t_tails_*, see readout.hip): unit tables by value in the kernel arguments
+DEVFN int multi_unit(const int* start, int n, int bid, int& local) {
+    int u = 0;
+    while (u + 1 < n && bid >= start[u + 1]) ++u;
+    local = bid - start[u];
+    return u;
+}
+struct GridMulti {
+    GridArgs a[GP_MAX_UNITS];
+    int start[GP_MAX_UNITS + 1];
+    int n;
+};
+struct ShifterMulti {
+    ShifterArgs a[GP_MAX_UNITS];
+    int n;
+};
+__global__ __launch_bounds__(256) void grid_fwd_multi_kernel(GridMulti m) {
+    __shared__ GridFwdLds L;
+    int bx;
+    const int u = multi_unit(m.start, m.n, blockIdx.x, bx);
+    grid_fwd_body(m.a[u], bx, L);
+}
+__global__ __launch_bounds__(256) void grid_bwd_multi_kernel(GridMulti m) {
+    __shared__ GridBwdLds L;
+    int bx;
+    const int u = multi_unit(m.start, m.n, blockIdx.x, bx);
+    grid_bwd_body(m.a[u], bx, L);
+}
+__global__ __launch_bounds__(256) void grid_bwd_reduce_multi_kernel(GridMulti m) {
+    __shared__ float sp[4][64];
+    int bx;
+    const int u = multi_unit(m.start, m.n, blockIdx.x, bx);
+    grid_bwd_reduce_body(m.a[u], (m.a[u].N + 63) / 64, bx, sp);
+}
+__global__ __launch_bounds__(256) void shifter_fwd_multi_kernel(ShifterMulti m) { shifter_fwd_body(m.a[blockIdx.x]); }
+__global__ __launch_bounds__(256) void shifter_bwd_multi_kernel(ShifterMulti m) {
+    __shared__ float acc[4][64];
+    shifter_bwd_body(m.a[blockIdx.x], acc);
 }
 
 inline int ok() { return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH; }
@@ -415,6 +477,53 @@ __global__ __launch_bounds__(256) void normal_fill_kernel(float* out, long long 
     for (int e = 0; e < 4; ++e)
         if (4 * i + e < n) out[4 * i + e] = z[e];
 }
+struct NormalMulti {
+    float* out[GP_MAX_UNITS];
+    long long n[GP_MAX_UNITS];
+    uint32_t stream_id[GP_MAX_UNITS];
+    int start[GP_MAX_UNITS + 1];
+    int units;
+};
+__global__ __launch_bounds__(256) void normal_fill_multi_kernel(NormalMulti m, uint32_t k0, uint32_t k1) {
+    int u = 0;
+    while (u + 1 < m.units && (int)blockIdx.x >= m.start[u + 1]) ++u;
+    const long long n = m.n[u];
+    float* out = m.out[u];
+    const long long i = (long long)(blockIdx.x - m.start[u]) * 256 + threadIdx.x;  // quad index inside the unit: the same draws as a launch of its own
+    if (4 * i >= n) return;
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)((unsigned long long)i >> 32), m.stream_id[u], 0u};
+    philox4x32_10(c, k0, k1);
+    float z[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)(c[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+        const float u2 = (float)(c[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * __logf(u1));
+        float sn, cs;
+        __sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[2 * p] = r * cs;
+        z[2 * p + 1] = r * sn;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (4 * i + e < n) out[4 * i + e] = z[e];
+}
+int launch_normal_fill_multi(float* const* out, const long long* n, const uint32_t* stream_id, int units, uint64_t seed, hipStream_t s) {
+    if (units <= 0) return V1T_OK;
+    if (units > GP_MAX_UNITS) return V1T_ERR_ARG;
+    NormalMulti m{};
+    int tot = 0;
+    for (int u = 0; u < units; ++u) {
+        m.out[u] = out[u]; m.n[u] = n[u]; m.stream_id[u] = stream_id[u];
+        m.start[u] = tot;
+        tot += (int)(((n[u] + 3) / 4 + 255) / 256);
+    }
+    m.start[units] = tot;
+    m.units = units;
+    if (tot == 0) return V1T_OK;
+    hipLaunchKernelGGL(normal_fill_multi_kernel, dim3(tot), dim3(256), 0, s, m, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return ok();
+}
 int launch_normal_fill(float* out, long long n, uint64_t seed, uint32_t stream_id, hipStream_t s) {
     if (n <= 0) return V1T_OK;
     const long long quads = (n + 3) / 4;
@@ -434,5 +543,59 @@ int launch_concat2(const float* a, int na, const float* b, int nb, int rows, flo
     const int n = rows * (na + nb);
     if (n <= 0) return V1T_OK;
     hipLaunchKernelGGL(concat2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, na, b, nb, rows, out, ldo);
+    return ok();
+}
+
+// ---- multi-unit launchers (one launch per stage over the mice of a training step)
+int launch_grid_fwd_multi(const GridArgs* a, int n, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    if (n > GP_MAX_UNITS) return V1T_ERR_ARG;
+    GridMulti m{};
+    int tot = 0;
+    for (int u = 0; u < n; ++u) {
+        if (a[u].gd < 0 || a[u].gd > 3) return V1T_ERR_UNSUPPORTED;
+        m.a[u] = a[u];
+        m.start[u] = tot;
+        tot += (a[u].N + 63) / 64;
+    }
+    m.start[n] = tot;
+    m.n = n;
+    if (tot == 0) return V1T_OK;
+    hipLaunchKernelGGL(grid_fwd_multi_kernel, dim3(tot), dim3(256), 0, s, m);
+    return ok();
+}
+int launch_grid_bwd_multi(const GridArgs* a0, void* const* ws, const size_t* ws_bytes, int n, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    if (n > GP_MAX_UNITS) return V1T_ERR_ARG;
+    GridMulti m{}, r{};
+    int tot = 0, rtot = 0;
+    for (int u = 0; u < n; ++u) {
+        GridArgs a = a0[u];
+        if (a.gd < 0 || a.gd > 3) return V1T_ERR_UNSUPPORTED;
+        if (!ws[u] || ws_bytes[u] < grid_bwd_ws_bytes(a.B, a.N)) return V1T_ERR_WORKSPACE;  // the multi form is the two-stage form
+        a.part = (float*)ws[u];
+        a.part_stride = gb_stride(a.B);
+        m.a[u] = a;
+        m.start[u] = tot;
+        tot += (a.N + 63) / 64;
+        r.a[u] = a;
+        r.start[u] = rtot;
+        const int ncols = GB_SHIFT0 + (a.dshift ? 2 * a.B : 0);
+        rtot += (a.gd > 0 || a.dshift) ? (ncols + 63) / 64 : 0;
+    }
+    m.start[n] = tot; m.n = n;
+    r.start[n] = rtot; r.n = n;
+    if (tot) hipLaunchKernelGGL(grid_bwd_multi_kernel, dim3(tot), dim3(256), 0, s, m);
+    if (rtot) hipLaunchKernelGGL(grid_bwd_reduce_multi_kernel, dim3(rtot), dim3(256), 0, s, r);
+    return ok();
+}
+int launch_shifter_multi(const ShifterArgs* a, int n, bool bwd, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    if (n > GP_MAX_UNITS) return V1T_ERR_ARG;
+    ShifterMulti m{};
+    for (int u = 0; u < n; ++u) m.a[u] = a[u];
+    m.n = n;
+    if (bwd) hipLaunchKernelGGL(shifter_bwd_multi_kernel, dim3(n), dim3(256), 0, s, m);
+    else hipLaunchKernelGGL(shifter_fwd_multi_kernel, dim3(n), dim3(256), 0, s, m);
     return ok();
 }

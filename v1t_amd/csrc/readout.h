@@ -27,3 +27,7 @@ int launch_readout_bwd(const ReadoutArgs& a, void* ws, size_t ws_bytes, hipStrea
 // the sorted form's kernels one by one: parts = bit mask of the values below (SORT needs grid only; DZ needs SORT's scratch and gout)
 enum { READOUT_BWD_SORT = 1, READOUT_BWD_PARAMS = 2, READOUT_BWD_DZ = 4, READOUT_BWD_ALL = 7 };
 int launch_readout_bwd_parts(const ReadoutArgs& a, void* ws, size_t ws_bytes, int parts, hipStream_t s);
+// one launch over n <= TAILS_MAX_UNITS units (the mice of a training step): stage = forward, tap sort, dz gather or parameter gradients
+constexpr int TAILS_MAX_UNITS = 8;
+enum { TAILS_FWD = 0, TAILS_SORT = 1, TAILS_DZ = 2, TAILS_PARAMS = 3 };
+int launch_readout_multi(const ReadoutArgs* a, void* const* ws, const size_t* ws_bytes, int n, int stage, hipStream_t s);

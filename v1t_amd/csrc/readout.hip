@@ -38,9 +38,9 @@ DEVFN Taps make_taps(float gx, float gy, int W, int H) {
 }
 
 template <int NE>
-__global__ __launch_bounds__(256) void readout_fwd_kernel(ReadoutArgs a) {
+DEVFN void readout_fwd_body(const ReadoutArgs& a, int bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 4 + wave;
+    const int n = bx * 4 + wave;
     if (n >= a.N) return;
     float f[NE];
 #pragma unroll
@@ -70,13 +70,16 @@ __global__ __launch_bounds__(256) void readout_fwd_kernel(ReadoutArgs a) {
     }
 }
 
+template <int NE>
+__global__ __launch_bounds__(256) void readout_fwd_kernel(ReadoutArgs a) { readout_fwd_body<NE>(a, blockIdx.x); }
+
 // Backward: G = dL/du (B,N).  dbias[n] += sum_b G;  dfeat[n][c] += sum_b G * S[b][c]   (owned by the
 // wave: plain +=);  dz[b][tap][c] += G * w_tap * F[n][c]  (fp32 atomics, 256-B contiguous runs);
 // dgrid[b][n] = (dL/dgx, dL/dgy) through the bilinear weights.
 template <int NE>
-__global__ __launch_bounds__(256) void readout_bwd_kernel(ReadoutArgs a) {
+DEVFN void readout_bwd_body(const ReadoutArgs& a, int bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 4 + wave;
+    const int n = bx * 4 + wave;
     if (n >= a.N) return;
     float f[NE], df[NE];
 #pragma unroll
@@ -128,6 +131,9 @@ __global__ __launch_bounds__(256) void readout_bwd_kernel(ReadoutArgs a) {
     if (a.dbias && lane == 0) a.dbias[n] += gsum;
 }
 
+template <int NE>
+__global__ __launch_bounds__(256) void readout_bwd_kernel(ReadoutArgs a) { readout_bwd_body<NE>(a, blockIdx.x); }
+
 // dz without a flood of global float atomics (4 x C x N x B adds = 317 MB at N = 8000, B = 16: ~250 us at the chip-wide
 // 1.3 TB/s atomic rate; LDS float atomics are slower still, ~1 lane per clock per CU): invert the sampling.
 //   sort  : workgroup (slice s of the neurons, image b) counting-sorts its taps by cell in LDS (histogram, scan,
@@ -146,10 +152,8 @@ struct DzSort {
     int ns, R;       // neurons per slice, region stride (multiple of 64)
 };
 
-__global__ __launch_bounds__(1024) void readout_sort_kernel(ReadoutArgs a, DzSort ix) {
-    __shared__ int hist[DZ_MAX_CELLS + 1];
-    __shared__ int wsum[16];
-    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+DEVFN void readout_sort_body(const ReadoutArgs& a, const DzSort& ix, int s, int b, int* hist, int* wsum) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cells = a.H * a.W;
     const int n0 = s * ix.ns, n1 = min(a.N, n0 + ix.ns);
     for (int i = tid; i <= cells; i += 1024) hist[i] = 0;
@@ -205,11 +209,16 @@ __global__ __launch_bounds__(1024) void readout_sort_kernel(ReadoutArgs a, DzSor
     }
     for (int p = 4 * (n1 - n0) + tid; p < ix.R; p += 1024) ix.cell[reg + p] = (unsigned)cells;  // padding
 }
+__global__ __launch_bounds__(1024) void readout_sort_kernel(ReadoutArgs a, DzSort ix) {
+    __shared__ int hist[DZ_MAX_CELLS + 1];
+    __shared__ int wsum[16];
+    readout_sort_body(a, ix, blockIdx.x, blockIdx.y, hist, wsum);
+}
 
 template <int NE>
-__global__ __launch_bounds__(256) void readout_dz_gather_kernel(ReadoutArgs a, DzSort ix) {
+DEVFN void readout_dz_gather_body(const ReadoutArgs& a, const DzSort& ix, int bx) {
     const int lane = threadIdx.x & 63;
-    const size_t chunk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t chunk = (size_t)bx * 4 + (threadIdx.x >> 6);
     const size_t total = (size_t)a.B * DZ_SLICES * ix.R;
     if (chunk * 64 >= total) return;
     const unsigned cells = a.H * a.W;
@@ -265,6 +274,49 @@ __global__ __launch_bounds__(256) void readout_dz_gather_kernel(ReadoutArgs a, D
     }
     if (cur < rows) flush(cur);
 }
+template <int NE>
+__global__ __launch_bounds__(256) void readout_dz_gather_kernel(ReadoutArgs a, DzSort ix) { readout_dz_gather_body<NE>(a, ix, blockIdx.x); }
+
+// ---- the same four kernels over SEVERAL units (mice) in one launch each: a training step runs the tails of all local mice as one launch
+// per stage instead of one chain of small launches per mouse (v1t_tails_*). The unit table travels by value in the kernel arguments;
+// a workgroup finds its unit from the prefix sums of the units' workgroup counts (wave-uniform scalar loads).
+struct ReadoutMulti {
+    ReadoutArgs a[TAILS_MAX_UNITS];
+    DzSort ix[TAILS_MAX_UNITS];
+    int start[TAILS_MAX_UNITS + 1];
+    int n;
+};
+DEVFN int multi_unit(const int* start, int n, int bid, int& local) {
+    int u = 0;
+    while (u + 1 < n && bid >= start[u + 1]) ++u;
+    local = bid - start[u];
+    return u;
+}
+template <int NE>
+__global__ __launch_bounds__(256) void readout_fwd_multi_kernel(ReadoutMulti m) {
+    int bx;
+    const int u = multi_unit(m.start, m.n, blockIdx.x, bx);
+    readout_fwd_body<NE>(m.a[u], bx);
+}
+template <int NE>
+__global__ __launch_bounds__(256) void readout_bwd_multi_kernel(ReadoutMulti m) {
+    int bx;
+    const int u = multi_unit(m.start, m.n, blockIdx.x, bx);
+    readout_bwd_body<NE>(m.a[u], bx);
+}
+__global__ __launch_bounds__(1024) void readout_sort_multi_kernel(ReadoutMulti m) {
+    __shared__ int hist[DZ_MAX_CELLS + 1];
+    __shared__ int wsum[16];
+    int bx;
+    const int u = multi_unit(m.start, m.n, blockIdx.x, bx);
+    readout_sort_body(m.a[u], m.ix[u], bx % DZ_SLICES, bx / DZ_SLICES, hist, wsum);
+}
+template <int NE>
+__global__ __launch_bounds__(256) void readout_dz_gather_multi_kernel(ReadoutMulti m) {
+    int bx;
+    const int u = multi_unit(m.start, m.n, blockIdx.x, bx);
+    readout_dz_gather_body<NE>(m.a[u], m.ix[u], bx);
+}
 
 DzSort sort_plan(void* ws, int B, int N) {
     DzSort d;
@@ -314,7 +366,51 @@ int dispatch(const ReadoutArgs& a, bool bwd, void* ws, size_t ws_bytes, hipStrea
     }
 }
 
+template <int NE>
+int launch_multi_t(ReadoutMulti& m, int stage, hipStream_t s) {
+    int tot = 0;
+    for (int u = 0; u < m.n; ++u) {
+        const ReadoutArgs& a = m.a[u];
+        m.start[u] = tot;
+        if (stage == TAILS_SORT) tot += DZ_SLICES * a.B;
+        else if (stage == TAILS_DZ) tot += (int)(((size_t)a.B * DZ_SLICES * m.ix[u].R / 64 + 3) / 4);
+        else tot += (a.N + 3) / 4;
+    }
+    m.start[m.n] = tot;
+    if (tot == 0) return V1T_OK;
+    switch (stage) {
+        case TAILS_FWD: hipLaunchKernelGGL(readout_fwd_multi_kernel<NE>, dim3(tot), dim3(256), 0, s, m); break;
+        case TAILS_PARAMS: hipLaunchKernelGGL(readout_bwd_multi_kernel<NE>, dim3(tot), dim3(256), 0, s, m); break;
+        case TAILS_SORT: hipLaunchKernelGGL(readout_sort_multi_kernel, dim3(tot), dim3(1024), 0, s, m); break;
+        case TAILS_DZ: hipLaunchKernelGGL(readout_dz_gather_multi_kernel<NE>, dim3(tot), dim3(256), 0, s, m); break;
+        default: return V1T_ERR_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+
 }  // namespace
+
+int launch_readout_multi(const ReadoutArgs* a, void* const* ws, const size_t* ws_bytes, int n, int stage, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    if (n > TAILS_MAX_UNITS) return V1T_ERR_ARG;
+    ReadoutMulti m{};
+    m.n = n;
+    for (int u = 0; u < n; ++u) {
+        m.a[u] = a[u];
+        if (a[u].C != a[0].C || a[u].C > 256 || a[u].N <= 0) return V1T_ERR_UNSUPPORTED;
+        if (stage == TAILS_PARAMS) m.a[u].dz = nullptr;
+        if (stage == TAILS_SORT || stage == TAILS_DZ) {
+            if (!ws[u] || a[u].H * a[u].W > DZ_MAX_CELLS || ws_bytes[u] < readout_bwd_ws_bytes(a[u].B, a[u].H, a[u].W, a[u].N)) return V1T_ERR_WORKSPACE;
+            m.ix[u] = sort_plan(ws[u], a[u].B, a[u].N);
+        }
+    }
+    switch ((a[0].C + 63) / 64) {
+        case 1: return launch_multi_t<1>(m, stage, s);
+        case 2: return launch_multi_t<2>(m, stage, s);
+        case 3: return launch_multi_t<3>(m, stage, s);
+        default: return launch_multi_t<4>(m, stage, s);
+    }
+}
 
 size_t readout_bwd_ws_bytes(int B, int H, int W, int N) {
     (void)H; (void)W;

@@ -29,9 +29,36 @@ class VitConfig(C.Structure):
     ]
 
 
+class TailUnit(C.Structure):
+    """`v1t_tail_unit` (include/v1t_amd.h): one local mouse-batch of a training step's readout tail."""
+    _fields_ = [
+        ("n_images", c_int), ("n_neurons", c_int), ("image_offset", c_int), ("grid_dim", c_int),
+        ("eps_stream", c_u32), ("fill_eps", c_int), ("loss_scale", c_float), ("feat_stride", c_int),
+        ("pupil", c_void_p), ("response", c_void_p),
+        ("sp", c_void_p * 6), ("dsp", c_void_p * 6),
+        ("src", c_void_p), ("gp", c_void_p * 4), ("dgp", c_void_p * 4),
+        ("mu", c_void_p), ("dmu", c_void_p), ("sigma", c_void_p), ("dsigma", c_void_p),
+        ("feat", c_void_p), ("dfeat", c_void_p), ("bias", c_void_p), ("dbias", c_void_p),
+        ("shift", c_void_p), ("dshift", c_void_p),
+        ("eps", c_void_p), ("grid", c_void_p), ("dgrid", c_void_p),
+        ("u", c_void_p), ("yhat", c_void_p), ("du", c_void_p), ("loss", c_void_p),
+        ("rws", c_void_p), ("rws_bytes", c_ll), ("gws", c_void_p), ("gws_bytes", c_ll),
+    ]
+
+
+class AdamRange(C.Structure):
+    """`v1t_adam_range`: one (arena range, learning rate, L1 coefficient) piece of `v1t_adamw_multi`."""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_ll), ("lr", c_float), ("l1", c_float), ("step", c_int), ("pad_", c_int)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/v1t_amd.h
 SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_abi_version": (c_int, []),
+    "v1t_tails_prepare": (c_int, [C.POINTER(TailUnit), c_int, c_u64, c_int, c_int, c_void_p]),
+    "v1t_tails_forward": (c_int, [C.POINTER(TailUnit), c_int, c_void_p, c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "v1t_tails_backward": (c_int, [C.POINTER(TailUnit), c_int, c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_void_p]),
+    "v1t_adamw_multi": (c_int, [C.POINTER(AdamRange), c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
+    "v1t_fill_zero": (c_int, [c_void_p, c_ll, c_void_p]),
     "v1t_mfma_peak_probe": (c_int, [c_int, c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), c_void_p]),
     "v1t_error_string": (C.c_char_p, [c_int]),
     "v1t_vit_create": (c_int, [C.POINTER(VitConfig), C.POINTER(c_void_p)]),

@@ -129,6 +129,26 @@ class FusedAdamW:
                     "adamw_step")
 
 
+    def step_arenas(self, items: t.Sequence[t.Tuple[t.Any, t.Sequence[t.Tuple[int, int, float, float]]]], zero_grad: bool = True) -> None:
+        """`step_arena` for several arenas in ONE launch (`v1t_adamw_multi`: the seven mice of a step are 21 small ranges). An instance that
+        overrides `step_arena` (tests intercept the gradients there) gets one call per arena instead."""
+        if "step_arena" in self.__dict__:
+            for arena, ranges in items:
+                self.step_arena(arena, ranges, zero_grad)
+            return
+        rs = []
+        for arena, ranges in items:
+            arena.step += 1
+            m, v = arena.moments()
+            for start, n, l1, lr in ranges:
+                if n > 0:
+                    o = 4 * start
+                    rs.append(L.AdamRange(arena.data.data_ptr() + o, arena.grad.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, n, lr, l1, arena.step, 0))
+        if rs:
+            arr = (L.AdamRange * len(rs))(*rs)
+            L.check(L.load().v1t_adamw_multi(arr, len(rs), self.betas[0], self.betas[1], self.eps, self.weight_decay, int(zero_grad), L.stream()), "adamw_multi")
+
+
 class _NativeStep:
     """One optimizer step's forward + backward for a fixed list of (mouse, n images) units WITHOUT torch autograd or ATen
     kernels on the way: every buffer is allocated once, the C-ABI entry points are called directly in the order autograd would
@@ -184,17 +204,18 @@ class _NativeStep:
         self.sb = int(lib.v1t_vit_scratch_bytes(core._plan, B))
         self.scratch = torch.empty(self.sb, dtype=torch.uint8, device=dev)
         # zeroed once per step: the per-unit loss scalars and the d shift accumulators
-        nz = len(units) + sum(2 * n for _, n in self.sig)
+        nz = len(units) + 1 + sum(2 * n for _, n in self.sig)  # + the step's total loss (summed in the loss kernel, not on the host)
         self.zeros = torch.zeros(nz, **f32)
         self.tails = []
-        zo = len(units)
-        self._dz_events = None
+        zo = len(units) + 1
+        self.loss_total = self.zeros[len(units):len(units) + 1]
+        self.units_c = None  # ctypes table of v1t_tail_unit, rebuilt with the pointers
         self.mice_stepped = False
         C_, gh, gw = core.output_shape
         for i, (m, n) in enumerate(self.sig):
             ro = model.readouts[m]
             N = ro.num_neurons
-            t_ = dict(m=m, n=n, N=N, ro=ro, loss=self.zeros[i:i + 1], dshift=self.zeros[zo:zo + 2 * n].view(n, 2))
+            t_ = dict(m=m, n=n, N=N, ro=ro, loss=self.zeros[i:i + 1], dshift=self.zeros[zo:zo + 2 * n].view(n, 2), off=sum(k for _, k in self.sig[:i]))
             zo += 2 * n
             t_["shift"] = torch.empty((n, 2), **f32) if model.core_shifter is not None else None
             t_["eps"] = torch.empty((n, N, 2), **f32)
@@ -239,65 +260,77 @@ class _NativeStep:
                 ps = [ml[0].weight, ml[0].bias, ml[2].weight, ml[2].bias, ml[4].weight, ml[4].bias]
                 t_["sp"], t_["dsp"] = [p.data_ptr() for p in ps], [gptr(p) for p in ps]
         self.generation = gen
+        P = lambda x: C.c_void_p(x) if x else C.c_void_p(None)  # noqa: E731
+        us = []
+        for t_ in self.tails:
+            u = L.TailUnit()
+            u.n_images, u.n_neurons, u.image_offset, u.grid_dim = t_["n"], t_["N"], t_["off"], t_["gd"]
+            u.eps_stream = ((1 + trainer.mouse_ids.index(t_["m"])) << 16) | (trainer.sharding.rank & 0xFFFF)
+            u.fill_eps, u.loss_scale, u.feat_stride = 1, 1.0, t_["FS"]
+            if t_["shift"] is not None:
+                for k in range(6):
+                    u.sp[k], u.dsp[k] = t_["sp"][k], t_["dsp"][k]
+                u.shift, u.dshift = t_["shift"].data_ptr(), t_["dshift"].data_ptr()
+            u.src = P(t_["src"])
+            for k in range(4):
+                u.gp[k], u.dgp[k] = P(t_["gp"][k]), P(t_["dgp"][k])
+            u.mu, u.dmu, u.sigma, u.dsigma = P(t_["mu"]), P(t_["dmu"]), t_["sigma"], t_["dsigma"]
+            u.feat, u.dfeat, u.bias, u.dbias = t_["feat"], t_["dfeat"], P(t_["bias"]), P(t_["dbias"])
+            u.eps, u.grid, u.dgrid = t_["eps"].data_ptr(), t_["grid"].data_ptr(), t_["dgrid"].data_ptr()
+            u.u, u.yhat, u.du, u.loss = t_["u"].data_ptr(), t_["yhat"].data_ptr(), t_["du"].data_ptr(), t_["loss"].data_ptr()
+            u.rws, u.rws_bytes, u.gws, u.gws_bytes = t_["rws"].data_ptr(), t_["rws"].numel(), t_["gws"].data_ptr(), t_["gws"].numel()
+            us.append(u)
+        self.units_c = (L.TailUnit * len(us))(*us)
 
     def run(self, trainer: "Trainer", units) -> torch.Tensor:
-        """One step's forward + backward. Stream plan (kernel trace of round 2: the per-mouse tails were a 0.8 ms hole between the
-        core's forward and backward - chains of ~11 small dependent kernels, four chains at a time (hardware queues)):
-          side stream of mouse m, BEFORE the core forward is enqueued: everything that does not need the core's output - shifter
-              forward, position noise, sample positions, and the counting sort of the taps the dz gather reads;
-          main: resize / concat -> v1t_vit_forward;
-          side stream, behind the forward: readout forward -> ELU1 + Poisson -> dz gather -> [event: dz of mouse m complete] ->
-              parameter gradients of the readout, sample positions and shifter -> (single-GPU: this mouse's AdamW);
-          main: waits for the seven dz events only -> v1t_vit_backward -> ... The rest of the tails overlaps the core backward."""
+        """One step's forward + backward. The per-mouse tails run as ONE launch per stage over all units (`v1t_tails_*`, csrc/tails.hip;
+        rounds 2-3 ran a chain of ~11 small launches per mouse over three side streams - 260 launches per step, 57 of them ATen / runtime
+        fills and copies):
+          side stream, before the core forward is enqueued: zero fills of the step's accumulators and of the token-gradient buffer,
+              `v1t_tails_prepare` (shifter forward, position noise, sample positions, counting sort of the taps: nothing of it needs the core);
+          main: resize / concat -> v1t_vit_forward -> `v1t_tails_forward` (readout, ELU1 + Poisson with the step's total loss, dz gather)
+              -> v1t_vit_backward;
+          side stream, beside the core backward: `v1t_tails_backward` (readout / position / shifter parameter gradients) and, on one GPU,
+              the mice's AdamW as one launch."""
         model = trainer.model
         core, crop = model.core, model.image_cropper
         lib = L.load()
         self._pointers(trainer)
         C_, gh, gw, T, DP = self.geom
+        nu = len(units)
         main = torch.cuda.current_stream()
         st = main.cuda_stream
-        streams = None
-        if model.readout_streams and len(units) > 1:
-            # V1T_TAIL_STREAMS side streams, the mice dealt over them round-robin (default 3: with the main stream that is the four
-            # hardware queues HIP multiplexes streams onto - a fifth stream would share the main stream's in-order queue)
-            pool = model._side_streams(max(1, min(len(units), trainer.tail_streams)))
-            streams = [pool[i % len(pool)] for i in range(len(units))]
-        if self._dz_events is None:
-            self._dz_events = [torch.cuda.Event() for _ in units]
-        # the shared buffers of this step (previous step's readers are behind us on this stream or were awaited at its end)
-        self.zeros.zero_()  # per-unit loss scalars, d shift accumulators
-        self.gout.zero_()
-        # dtype / layout conversions of the per-mouse inputs run HERE, on the main stream in front of `start`: the side streams read them
+        side = model._side_streams(1)[0] if (model.readout_streams and nu > 1) else None
+        # dtype / layout conversions of the per-mouse inputs run HERE, on the main stream in front of `start`: the side stream reads them
         # behind that event (no-ops for fp32 contiguous batches; an fp64 or strided batch would otherwise race with the shifter forward)
         pups = [b["pupil_center"].to(torch.float32).contiguous() for _, b, _ in units]
         ys = [b["response"].to(torch.float32).contiguous() for _, b, _ in units]
-        start = torch.cuda.Event()
-        start.record(main)
         trainer._eps_state = (trainer._eps_state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
-        side = lambda i: (torch.cuda.stream(streams[i]) if streams else contextlib.nullcontext())  # noqa: E731
-        # ---- per mouse, core-independent part
         for i, ((m, b, full), t_) in enumerate(zip(units, self.tails)):
-            n, N, ro = t_["n"], t_["N"], t_["ro"]
-            pup = pups[i]
-            if streams:
-                streams[i].wait_event(start)  # parameters of the previous optimizer step, inputs
-            with side(i):
-                s_ = torch.cuda.current_stream().cuda_stream
-                if t_["shift"] is not None:
-                    L.check(lib.v1t_core_shifter_forward(n, pup.data_ptr(), *t_["sp"], t_["shift"].data_ptr(), s_), "core_shifter_forward")
+            u = self.units_c[i]
+            u.pupil, u.response = pups[i].data_ptr(), ys[i].data_ptr()
+            u.loss_scale = math.sqrt(trainer.ds_sizes[m] / full)
+            u.fill_eps = 0 if (trainer.eps_override and trainer.eps_override.get(m) is not None) else 1
+        on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
+        if side is not None:
+            start = torch.cuda.Event()
+            start.record(main)
+            side.wait_event(start)  # the previous step's readers of the shared buffers, this step's inputs
+        with on_side():
+            s_ = torch.cuda.current_stream().cuda_stream
+            L.check(lib.v1t_fill_zero(self.zeros.data_ptr(), 4 * self.zeros.numel(), s_), "fill_zero")  # per-unit losses, total loss, d shift
+            L.check(lib.v1t_fill_zero(self.gout.data_ptr(), 4 * self.gout.numel(), s_), "fill_zero")
+            for (m, _, _), t_ in zip(units, self.tails):
                 ov = trainer.eps_override.get(m) if trainer.eps_override else None
                 if ov is not None:
-                    t_["eps"].copy_(ov.reshape(n, N, 2))
-                else:
-                    L.check(lib.v1t_normal_fill(t_["eps"].data_ptr(), n * N * 2, trainer._eps_state, ((1 + trainer.mouse_ids.index(m)) << 16) | (trainer.sharding.rank & 0xFFFF), s_),
-                            "normal_fill")
+                    t_["eps"].copy_(ov.reshape(t_["n"], t_["N"], 2))  # (tests replay the reference's draws)
                 if t_["mu"] is not None:
                     with torch.no_grad():
-                        ro._mu.clamp_(min=-1, max=1)  # gaussian2d.py:212-215 (acts on the free parameter only)
-                L.check(lib.v1t_readout_grid_forward(n, N, t_["gd"], t_["src"], *t_["gp"], t_["mu"], t_["sigma"], t_["eps"].data_ptr(), L.ptr(t_["shift"]),
-                                                     t_["grid"].data_ptr(), s_), "readout_grid_forward")
-                L.check(lib.v1t_gaussian2d_backward_parts(None, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), None, t_["FS"], None, None, T * DP, DP,
-                                                          None, None, None, t_["rws"].data_ptr(), t_["rws"].numel(), 1, s_), "gaussian2d_sort")
+                        t_["ro"]._mu.clamp_(min=-1, max=1)  # gaussian2d.py:212-215 (acts on the free parameter only)
+            L.check(lib.v1t_tails_prepare(self.units_c, nu, trainer._eps_state, gh, gw, s_), "tails_prepare")
+            if side is not None:
+                prepared = torch.cuda.Event()
+                prepared.record(side)
         # ---- inputs straight into the shared batch buffers
         off = 0
         for (m, b, _), (_, n) in zip(units, self.sig):
@@ -320,33 +353,15 @@ class _NativeStep:
         L.check(lib.v1t_vit_forward(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), self.img.data_ptr(), L.ptr(self.beh), 0, self.B,
                                     self.ws.data_ptr(), self.ws_bytes, 1, 1, seed, None, self.tokens.data_ptr(), st), "vit_forward")
         core._last_ws = (self.ws, self.B, True)
-        fwd_done = torch.cuda.Event()
-        fwd_done.record(main)
-        # ---- per mouse, behind the core: readout, loss, dz (-> event), then the parameter gradients (and this mouse's optimizer)
-        own_opt = trainer.sharding.world == 1 and streams is not None
-        off = 0
-        for i, ((m, b, full), t_) in enumerate(zip(units, self.tails)):
-            n, N = t_["n"], t_["N"]
-            if streams:
-                streams[i].wait_event(fwd_done)
-            with side(i):
-                s_ = torch.cuda.current_stream().cuda_stream
-                zptr = self.tokens.data_ptr() + 4 * (off * T * DP + core.cls_tokens * DP)  # this unit's images, class-token row skipped
-                gptr = self.gout.data_ptr() + 4 * (off * T * DP + core.cls_tokens * DP)
-                L.check(lib.v1t_gaussian2d_forward(zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["bias"], t_["u"].data_ptr(), s_),
-                        "gaussian2d_forward")
-                scale = math.sqrt(trainer.ds_sizes[m] / full)
-                L.check(lib.v1t_elu1_poisson(t_["u"].data_ptr(), ys[i].data_ptr(), n * N, scale, 1.0, t_["yhat"].data_ptr(), t_["du"].data_ptr(), t_["loss"].data_ptr(), s_),
-                        "elu1_poisson")
-                bw = lambda parts: L.check(lib.v1t_gaussian2d_backward_parts(  # noqa: E731
-                    zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["du"].data_ptr(), gptr, T * DP, DP, t_["dgrid"].data_ptr(),
-                    t_["dfeat"], t_["dbias"], t_["rws"].data_ptr(), t_["rws"].numel(), parts, s_), "gaussian2d_backward")
-                bw(4)  # dz of this mouse's images, from the taps sorted before the forward
-                self._dz_events[i].record(torch.cuda.current_stream())
-            off += n
-        if streams:
-            for ev in self._dz_events:
-                main.wait_event(ev)
+        # ---- every unit's readout, loss and dz, one launch each (class-token row skipped)
+        if side is not None:
+            main.wait_event(prepared)
+        zptr = self.tokens.data_ptr() + 4 * core.cls_tokens * DP
+        gptr = self.gout.data_ptr() + 4 * core.cls_tokens * DP
+        L.check(lib.v1t_tails_forward(self.units_c, nu, zptr, gptr, T * DP, DP, C_, gh, gw, self.loss_total.data_ptr(), st), "tails_forward")
+        if side is not None:
+            dz_done = torch.cuda.Event()
+            dz_done.record(main)
         # ---- shared core backward (gradients accumulate into the core arena; per-block events for the data-parallel exchange)
         core._arena.attach_grads()
         evs = core._block_events
@@ -354,32 +369,19 @@ class _NativeStep:
         L.check(lib.v1t_vit_backward_events(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), self.img.data_ptr(), L.ptr(self.beh), 0, self.B,
                                             self.ws.data_ptr(), self.scratch.data_ptr(), self.sb, 1, seed, None, self.gout.data_ptr(), core._arena.grad.data_ptr(),
                                             ev_arr, st), "vit_backward")
-        # second pass over the mice: what the core's backward does not wait for. Issued AFTER every mouse's dz chain and after
-        # the core's backward because the streams share four in-order hardware queues: work enqueued
-        # earlier would sit in front of another mouse's dz chain, or of the backward itself
-        off = 0
-        for i, ((m, b, full), t_) in enumerate(zip(units, self.tails)):
-            n, N = t_["n"], t_["N"]
-            with side(i):
-                s_ = torch.cuda.current_stream().cuda_stream
-                zptr = self.tokens.data_ptr() + 4 * (off * T * DP + core.cls_tokens * DP)
-                gptr = self.gout.data_ptr() + 4 * (off * T * DP + core.cls_tokens * DP)
-                L.check(lib.v1t_gaussian2d_backward_parts(zptr, T * DP, DP, n, C_, gh, gw, N, t_["grid"].data_ptr(), t_["feat"], t_["FS"], t_["du"].data_ptr(), gptr, T * DP, DP,
-                                                          t_["dgrid"].data_ptr(), t_["dfeat"], t_["dbias"], t_["rws"].data_ptr(), t_["rws"].numel(), 2, s_),
-                        "gaussian2d_backward")  # d grid, d features, d bias
-                L.check(lib.v1t_readout_grid_backward_ws(n, N, t_["gd"], t_["src"], *t_["gp"], t_["mu"], t_["sigma"], t_["eps"].data_ptr(), t_["dgrid"].data_ptr(),
-                                                         *t_["dgp"], t_["dmu"], t_["dsigma"], t_["dshift"].data_ptr() if t_["shift"] is not None else None,
-                                                         t_["gws"].data_ptr(), t_["gws"].numel(), s_), "readout_grid_backward")
-                if t_["shift"] is not None:
-                    L.check(lib.v1t_core_shifter_backward(n, pups[i].data_ptr(), *t_["sp"], t_["dshift"].data_ptr(), *t_["dsp"], s_), "core_shifter_backward")
-                if own_opt:
-                    trainer.step_mouse(m)  # this mouse's arena is complete: its AdamW runs here, beside the core's backward
-            off += n
-        if streams:
-            for s_i in dict.fromkeys(streams):
-                main.wait_stream(s_i)  # the tails' parameter gradients (and optimizer steps); long done by now
+        # ---- what the core's backward does not wait for: the tails' parameter gradients (and, on one GPU, the mice's optimizer step)
+        own_opt = trainer.sharding.world == 1 and side is not None
+        if side is not None:
+            side.wait_event(dz_done)
+        with on_side():
+            s_ = torch.cuda.current_stream().cuda_stream
+            L.check(lib.v1t_tails_backward(self.units_c, nu, zptr, T * DP, DP, C_, gh, gw, s_), "tails_backward")
+            if own_opt:
+                trainer.step_mice([m for m, _, _ in units])
+        if side is not None:
+            main.wait_stream(side)
         self.mice_stepped = own_opt
-        return self.zeros[:len(units)]
+        return self.loss_total.reshape(())
 
 
 class Trainer:
@@ -408,7 +410,6 @@ class Trainer:
             model.core.fold_rank(self.sharding.rank)
         # V1T_NATIVE_STEP=0 (dev): forward / backward through the nn.Module + autograd path instead of the direct C-ABI sequence
         self.native = os.environ.get("V1T_NATIVE_STEP", "1") != "0"
-        self.tail_streams = int(os.environ.get("V1T_TAIL_STREAMS", "3"))
         self._native_cache: t.Dict[t.Any, t.Optional[_NativeStep]] = {}
         self._eps_state = (int(getattr(args, "seed", 1234)) * 2654435761 + 97) & 0xFFFFFFFFFFFFFFFF
         self.eps_override: t.Optional[t.Dict[str, torch.Tensor]] = None  # tests: mouse -> (n, N, 2) position noise to replay
@@ -486,12 +487,15 @@ class Trainer:
                 self._core_l1 = float(core.reg_scale) * len(self.mouse_ids)
             self.opt.step_arena(ca, [(0, ca.param_floats, self._core_l1, self.opt.group_lr("core"))])
             core.mark_updated()
-        if not (native is not None and native.mice_stepped):  # (the native single-GPU step ran them on the mice's own streams)
-            for mouse_id in self.sharding.local_mice():
-                self.step_mouse(mouse_id)
+        if not (native is not None and native.mice_stepped):  # (the native single-GPU step ran them beside the core's backward)
+            self.step_mice(list(self.sharding.local_mice()))
         if native is not None:
-            return {"loss": losses[0].sum()}
+            return {"loss": losses[0]}  # the step's total, summed by the loss kernel
         return {"loss": torch.stack(losses).sum() if losses else torch.zeros((), device=core._arena.data.device)}
+
+    def step_mice(self, mouse_ids: t.Sequence[str]) -> None:
+        """`step_mouse` for several mice in one launch (each arena keeps its own step counter and its ranges' learning rates)."""
+        self.opt.step_arenas([(self.model.mouse_arena(m), [(o, n, c, self.opt.group_lr(g)) for o, n, c, g in self.model.mouse_step_ranges(m)]) for m in mouse_ids])
 
     def step_mouse(self, mouse_id: str) -> None:
         """AdamW (+ L1) over one mouse's arena on the CURRENT stream: one launch per (L1 coefficient, optimizer group) run -
