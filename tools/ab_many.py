@@ -23,7 +23,7 @@ P = C.c_void_p
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for lb in libs:
     lb.v1t_attention_backward_ws_bytes.restype = C.c_longlong
-nb = int(libs[0].v1t_attention_backward_ws_bytes(B, H, T))
+nb = max(int(lb.v1t_attention_backward_ws_bytes(B, H, T)) for lb in libs)  # (builds may lay the scratch out differently)
 ws = torch.empty(nb, dtype=torch.uint8, device=dev)
 
 

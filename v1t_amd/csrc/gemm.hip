@@ -694,36 +694,6 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
     for (int tn = sp, it = 0; tn < ntn; tn += nsplit, ++it) {
         const int buf = it & 1, n0 = tn * BN;
         if (tn + nsplit < ntn) gload(tn + nsplit);
-        if constexpr (EPI == EPI_BF16 && RPW >= 3) {
-            // Three row sets per wave (384 rows per workgroup: the 185 k rows of a 112-image launch are 483 workgroups = ONE round of the 512
-            // resident ones; two row sets are 724 = 1.41 rounds, run as 2). 120 A-fragment registers leave no room for RPW x NBLK accumulator
-            // tiles, so one 32 x 32 block at a time: its 10 MFMAs, then straight into the staging tile. Every B fragment is read from LDS once
-            // per row set instead of once per tile - the LDS has the bandwidth (256 B/clk/CU, profiles/r04_lds_peak.txt), the MFMAs are hidden.
-#pragma unroll
-            for (int u = 0; u < RPW; ++u) {
-                if (m0 + BMS * u >= g.M) break;  // workgroup-uniform
-#pragma unroll
-                for (int nb = 0; nb < NBLK; ++nb) {
-                    f32x16 a1;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a1[r] = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) a1 = mfma32h(afrag[u][ks], *(const bf16x8*)(&sB[buf][32 * nb * LS + boff + 16 * ks]), a1);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st[acc_row(r, lane) * CS + 32 * nb + r31] = (bf16_t)a1[r];
-                }
-                constexpr int CPR = BN / 8;
-#pragma unroll
-                for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
-                    const int c = c0 + lane, crow = c / CPR, ch = c % CPR;
-                    const int grow = m0 + BMS * u + 32 * wave + crow;
-                    if (grow < g.M) *(u32x4*)((bf16_t*)g.C + (size_t)grow * g.ldc + n0 + 8 * ch) = *(const u32x4*)(st + crow * CS + 8 * ch);
-                }
-            }
-            if (tn + nsplit < ntn) swrite(buf ^ 1);
-            __syncthreads();
-            continue;
-        }
         f32x16 acc[RPW][NBLK];
 #pragma unroll
         for (int u = 0; u < RPW; ++u)
@@ -1298,9 +1268,8 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
     // (its live values + the second row set's accumulators and A fragments do not fit 256 registers: 183 -> 283 us) nor for small
     // launches (fewer, longer workgroups)
     static const int force_shape = std::getenv("V1T_LNG_SHAPE") ? atoi(std::getenv("V1T_LNG_SHAPE")) : -1;  // dev switch
-    const int dflt = (epi == EPI_BF16 && l.rows >= 512 * 256) ? 2 : 1;
-    const int shape = (force_shape >= 0 && !(force_shape == 3 && epi != EPI_BF16)) ? force_shape : dflt;
-    const int BMr = shape == 1 ? 128 : (shape == 3 ? 384 : 256), BNr = shape ? 64 : 128;
+    const int shape = force_shape >= 0 ? force_shape : ((epi == EPI_BF16 && l.rows >= 512 * 256) ? 2 : 1);
+    const int BMr = shape == 1 ? 128 : 256, BNr = shape ? 64 : 128;
     if (g.N % BNr != 0) return V1T_ERR_UNSUPPORTED;
     const int rt = (l.rows + BMr - 1) / BMr, ntn = g.N / BNr;
     static const int force_split = std::getenv("V1T_LNG_SPLIT") ? atoi(std::getenv("V1T_LNG_SPLIT")) : 0;  // dev switch
@@ -1310,7 +1279,7 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
     float best = 1e30f;
     for (int ns = 1; ns <= ntn; ++ns) {
         const int slots = shape ? 512 : 256;  // resident workgroups
-        const float unit = shape == 2 ? 2.0f : (shape == 3 ? 3.0f : 1.0f);  // row sets per workgroup: prologue and column tiles cost twice
+        const float unit = shape == 2 ? 2.0f : 1.0f;  // row sets per workgroup: prologue and column tiles cost twice
         const float cost = (float)((rt * ns + slots - 1) / slots) * unit * ((shape ? 3.0f : 1.5f) + (float)((ntn + ns - 1) / ns));
         if (cost < best - 1e-3f) { best = cost; nsplit = ns; }
     }
@@ -1318,10 +1287,7 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
     const dim3 grid(rt * nsplit), blk(shape ? 256 : 512);
 #define LNG_CASE(DPV)                                                                                                       \
     case DPV:                                                                                                               \
-        if (shape == 3) {                                                                                                   \
-            if (epi != EPI_BF16) return V1T_ERR_UNSUPPORTED;                                                                \
-            hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BF16, 4, 2, 3>), grid, blk, 0, s, l, g, nsplit);                     \
-        } else if (shape == 2) {                                                                                            \
+        if (shape == 2) {                                                                                            \
             if (epi == EPI_BF16) hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BF16, 4, 2, 2>), grid, blk, 0, s, l, g, nsplit); \
             else hipLaunchKernelGGL((ln_gemm_kernel<DPV, EPI_BIAS_GELU, 4, 2, 2>), grid, blk, 0, s, l, g, nsplit);           \
         } else if (shape) {                                                                                                 \
