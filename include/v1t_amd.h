@@ -363,6 +363,13 @@ int v1t_adamw_multi(const v1t_adam_range* ranges, int n, float beta1, float beta
 /* zero `bytes` bytes at a 16-byte aligned device address (the step's token-gradient buffer and loss / d shift accumulators) */
 int v1t_fill_zero(void* p, long long bytes, void* stream);
 
+/* The step's inputs in one launch: unit i's n_images[i] images (C, IH, IW) -> ImageCropper's bilinear resize to (OH, OW) (image_cropper.py:96-99; a plain
+ * copy when the sizes are equal) into consecutive slices of `out`, and - when beh_out is given - the BehaviorMLP input rows cat(behaviors (na),
+ * pupil_centers (nb)) (vit.py:431-432) into consecutive rows of beh_out (row stride na + nb; nb = 0: behaviours only). What v1t_resize_bilinear and
+ * v1t_concat2 do per mouse. */
+int v1t_inputs_multi(const float* const* images, const float* const* behaviors, const float* const* pupil_centers, const int* n_images, int n_units,
+                     int C, int IH, int IW, float* out, int OH, int OW, float* beh_out, int na, int nb, void* stream);
+
 /* Measurement aid (no reference counterpart; SURVEY.md 8d asks for the roofline fraction against the datasheet AND the measured peak):
  * runs v_mfma_f32_32x32x16_bf16 back to back on every CU (register operands, random data, `waves_per_simd` 1 or 2, 16 * iters MFMAs
  * per wave), four launches back to back, and returns for the LAST one (the sustained rate - the chip's power management needs some

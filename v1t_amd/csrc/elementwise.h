@@ -173,3 +173,7 @@ int launch_attn_dropout_mask(uint8_t* out, long long rows, long long T, AttnDrop
 int launch_crop_nearest(const float* in, int B, int C, int IH, int IW, const float* grid, const float* shifts, float* out, int OH, int OW,
                         hipStream_t s);
 int launch_resize_bilinear(const float* in, float* out, int planes, int IH, int IW, int OH, int OW, hipStream_t s);
+constexpr int INPUTS_MAX_UNITS = 8;
+// every unit's images resized / copied into one batch buffer + cat(behaviors, pupil centres) rows, one launch per INPUTS_MAX_UNITS units
+int launch_inputs_multi(const float* const* img, const float* const* beh, const float* const* pup, const int* n_images, int n, int C, int IH, int IW,
+                        float* out, int OH, int OW, float* beh_out, int na, int nb, hipStream_t s);

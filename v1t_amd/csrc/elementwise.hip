@@ -881,6 +881,50 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* in, f
     out[i] = top * (1.f - fy) + bot * fy;
 }
 
+// The step's inputs in ONE launch: every unit's images resized (or copied when IH == OH and IW == OW) into its slice of the shared batch buffer,
+// and its BehaviorMLP input cat(behaviors, pupil_centers) (vit.py:431-432) into the shared (B, nb) buffer - what v1t_resize_bilinear + v1t_concat2
+// do per mouse (14 launches of ~7 us per step on the main stream). The same arithmetic per pixel as resize_bilinear_kernel.
+struct InputsMulti {
+    const float* img[INPUTS_MAX_UNITS];
+    const float* beh[INPUTS_MAX_UNITS];
+    const float* pup[INPUTS_MAX_UNITS];
+    int planes0[INPUTS_MAX_UNITS + 1];  // first output plane (image x channel) of each unit
+    int img0[INPUTS_MAX_UNITS + 1];     // first image of each unit
+    int n;
+};
+__global__ __launch_bounds__(256) void inputs_multi_kernel(InputsMulti m, float* out, int IH, int IW, int OH, int OW, float* beh_out, int na, int nb) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long npix = (long long)m.planes0[m.n] * OH * OW;
+    if (i < npix) {
+        const int x = (int)(i % OW), y = (int)((i / OW) % OH);
+        const int pl = (int)(i / ((long long)OW * OH));
+        int u = 0;
+        while (u + 1 < m.n && pl >= m.planes0[u + 1]) ++u;
+        const float* p = m.img[u] + (size_t)(pl - m.planes0[u]) * IH * IW;
+        if (IH == OH && IW == OW) {
+            out[i] = p[(size_t)y * IW + x];
+        } else {
+            const float sy = fmaxf(((float)y + 0.5f) * ((float)IH / (float)OH) - 0.5f, 0.f);
+            const float sx = fmaxf(((float)x + 0.5f) * ((float)IW / (float)OW) - 0.5f, 0.f);
+            const int y0 = min((int)sy, IH - 1), x0 = min((int)sx, IW - 1);
+            const int y1 = min(y0 + 1, IH - 1), x1 = min(x0 + 1, IW - 1);
+            const float fy = sy - (float)y0, fx = sx - (float)x0;
+            const float top = p[(size_t)y0 * IW + x0] * (1.f - fx) + p[(size_t)y0 * IW + x1] * fx;
+            const float bot = p[(size_t)y1 * IW + x0] * (1.f - fx) + p[(size_t)y1 * IW + x1] * fx;
+            out[i] = top * (1.f - fy) + bot * fy;
+        }
+        return;
+    }
+    const long long j = i - npix;
+    const int w = na + nb;
+    if (!beh_out || j >= (long long)m.img0[m.n] * w) return;
+    const int r = (int)(j / w), c = (int)(j % w);
+    int u = 0;
+    while (u + 1 < m.n && r >= m.img0[u + 1]) ++u;
+    const int rl = r - m.img0[u];
+    beh_out[j] = c < na ? m.beh[u][(size_t)rl * na + c] : m.pup[u][(size_t)rl * nb + (c - na)];
+}
+
 // ImageCropper's crop (image_cropper.py:101-110,126-133): F.grid_sample(mode="nearest", align_corners=True, zeros
 // padding) over grid[oy][ox] = (x, y) in [-crop, crop] plus an optional per-image (x, y) shift. Source pixel =
 // rint(((g + 1) / 2) * (size - 1)) in fp32 (round half to even, as ATen's nearbyint), outside the image -> 0.
@@ -1117,6 +1161,27 @@ int launch_resize_bilinear(const float* in, float* out, int planes, int IH, int 
     const long long n = (long long)planes * OH * OW;
     if (n <= 0) return V1T_OK;
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, planes, IH, IW, OH, OW);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_inputs_multi(const float* const* img, const float* const* beh, const float* const* pup, const int* n_images, int n, int C, int IH, int IW,
+                        float* out, int OH, int OW, float* beh_out, int na, int nb, hipStream_t s) {
+    int i0 = 0;
+    for (int c0 = 0; c0 < n; c0 += INPUTS_MAX_UNITS) {
+        const int cn = std::min(INPUTS_MAX_UNITS, n - c0);
+        InputsMulti m{};
+        int pl = 0, im = 0;
+        for (int u = 0; u < cn; ++u) {
+            m.img[u] = img[c0 + u]; m.beh[u] = beh ? beh[c0 + u] : nullptr; m.pup[u] = pup ? pup[c0 + u] : nullptr;
+            m.planes0[u] = pl; m.img0[u] = im;
+            pl += n_images[c0 + u] * C; im += n_images[c0 + u];
+        }
+        m.planes0[cn] = pl; m.img0[cn] = im; m.n = cn;
+        const long long tot = (long long)pl * OH * OW + (beh_out ? (long long)im * (na + nb) : 0);
+        if (tot > 0)
+            hipLaunchKernelGGL(inputs_multi_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, m, out + (size_t)i0 * C * OH * OW, IH, IW, OH, OW,
+                               beh_out ? beh_out + (size_t)i0 * (na + nb) : nullptr, na, nb);
+        i0 += im;
+    }
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 int launch_crop_nearest(const float* in, int B, int C, int IH, int IW, const float* grid, const float* shifts, float* out, int OH, int OW,

@@ -165,3 +165,14 @@ extern "C" int v1t_fill_zero(void* p, long long bytes, void* stream) {
     if (bytes < 0 || (bytes && !p) || ((uintptr_t)p & 15)) return V1T_ERR_ARG;
     return launch_fill_zero(p, bytes, (hipStream_t)stream);
 }
+
+extern "C" int v1t_inputs_multi(const float* const* images, const float* const* behaviors, const float* const* pupil_centers, const int* n_images, int n_units,
+                                int C, int IH, int IW, float* out, int OH, int OW, float* beh_out, int na, int nb, void* stream) {
+    if (!images || !n_images || n_units < 0 || !out || C <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || na < 0 || nb < 0) return V1T_ERR_ARG;
+    if (beh_out && ((na && !behaviors) || (nb && !pupil_centers))) return V1T_ERR_ARG;
+    for (int i = 0; i < n_units; ++i) {
+        if (!images[i] || n_images[i] < 0) return V1T_ERR_ARG;
+        if (beh_out && ((na && !behaviors[i]) || (nb && !pupil_centers[i]))) return V1T_ERR_ARG;
+    }
+    return launch_inputs_multi(images, behaviors, pupil_centers, n_images, n_units, C, IH, IW, out, OH, OW, beh_out, na, nb, (hipStream_t)stream);
+}

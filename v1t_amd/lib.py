@@ -59,6 +59,8 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_tails_backward": (c_int, [C.POINTER(TailUnit), c_int, c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_void_p]),
     "v1t_adamw_multi": (c_int, [C.POINTER(AdamRange), c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "v1t_fill_zero": (c_int, [c_void_p, c_ll, c_void_p]),
+    "v1t_inputs_multi": (c_int, [C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int), c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                                 c_void_p, c_int, c_int, c_void_p]),
     "v1t_mfma_peak_probe": (c_int, [c_int, c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), c_void_p]),
     "v1t_error_string": (C.c_char_p, [c_int]),
     "v1t_vit_create": (c_int, [C.POINTER(VitConfig), C.POINTER(c_void_p)]),

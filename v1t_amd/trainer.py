@@ -331,23 +331,16 @@ class _NativeStep:
             if side is not None:
                 prepared = torch.cuda.Event()
                 prepared.record(side)
-        # ---- inputs straight into the shared batch buffers
-        off = 0
-        for (m, b, _), (_, n) in zip(units, self.sig):
-            src = b["image"]
-            if src.dtype != torch.float32 or not src.is_contiguous():
-                src = src.to(torch.float32).contiguous()
-            dst = self.img[off:off + n]
-            if crop.resize is not None:
-                L.check(lib.v1t_resize_bilinear(src.data_ptr(), n * src.shape[1], src.shape[2], src.shape[3], dst.data_ptr(), crop.resize[0], crop.resize[1], st),
-                        "resize_bilinear")
-            else:
-                dst.copy_(src)
-            if self.nbeh:
-                beh, pup = b["behavior"].to(torch.float32).contiguous(), b["pupil_center"].to(torch.float32).contiguous()
-                L.check(lib.v1t_concat2(beh.data_ptr(), 3, pup.data_ptr() if self.nbeh == 5 else None, 2 if self.nbeh == 5 else 0, n,
-                                        self.beh[off:off + n].data_ptr(), self.nbeh, st), "concat2")
-            off += n
+        # ---- inputs straight into the shared batch buffers: every unit's resize (or copy) and behaviour rows in one launch
+        srcs = [b["image"] if (b["image"].dtype == torch.float32 and b["image"].is_contiguous()) else b["image"].to(torch.float32).contiguous() for _, b, _ in units]
+        VP = C.c_void_p * nu
+        behs = [b["behavior"].to(torch.float32).contiguous() for _, b, _ in units] if self.nbeh else None
+        ih, iw = srcs[0].shape[2], srcs[0].shape[3]
+        oh, ow = crop.resize if crop.resize is not None else (ih, iw)
+        L.check(lib.v1t_inputs_multi(VP(*[x.data_ptr() for x in srcs]), VP(*[x.data_ptr() for x in behs]) if behs else None,
+                                     VP(*[x.data_ptr() for x in pups]) if self.nbeh == 5 else None, (C.c_int * nu)(*[n for _, n in self.sig]), nu,
+                                     srcs[0].shape[1], ih, iw, self.img.data_ptr(), oh, ow, L.ptr(self.beh) if self.nbeh else None,
+                                     3 if self.nbeh else 0, 2 if self.nbeh == 5 else 0, st), "inputs_multi")
         # ---- shared core, one pass over all units
         seed = core._next_seed()
         L.check(lib.v1t_vit_forward(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), self.img.data_ptr(), L.ptr(self.beh), 0, self.B,
