@@ -302,6 +302,39 @@ def test_patch_modes_2_3_gradients_vs_oracle(dev, pm):
     assert n >= (6 if pm == 2 else 8)
 
 
+@pytest.mark.parametrize("emb,heads,stride", [(128, 2, 1), (100, 2, 2), (155, 2, 2)])
+def test_other_head_dims_and_token_counts_vs_oracle(dev, emb, heads, stride):
+    """Head dims other than the default 160 (emb_dim 128 -> the 128-wide attention instances, 100 -> 128 padded) and a token count whose last
+    128-key block is mostly padding (patch_stride 2: T = 436): predictions, loss and every core gradient against the oracle's autograd. Round 4
+    found the producer / consumer attention backward wrong at head dim 128 and its dQ GEMM reading out of bounds for T % 128 <= 96 - neither
+    shape had a test."""
+    from v1t_amd.losses import elu1_poisson_loss
+
+    cfg = O.Config(num_blocks=2, emb_dim=emb, mlp_dim=96, num_heads=heads, mouse_ids=("A",), num_neurons={"A": 64}, patch_stride=stride, p_dropout=0.0, t_dropout=0.0)
+    sd = W.make_state_dict(cfg, 77)
+    batch = W.make_batch(cfg, "A", 2, 77)
+    model, _ = build_native_model(cfg, sd, dev)
+    model.train(False)
+    u = _fwd(model, batch, "A", dev, activate=False)
+    loss, _ = elu1_poisson_loss(u, batch["response"].to(dev), 4500.0, 2)
+    loss.backward()
+    sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ol, _, oy = O.total_loss(cfg, sdd, batch, "A", 4500.0)
+    ol.backward()
+    assert abs(float(loss) - float(ol)) <= 1e-4 * abs(float(ol))
+    with torch.no_grad():
+        y = _fwd(model, batch, "A", dev)
+    assert_close(f"emb{emb}.stride{stride}.y", y.cpu().numpy(), oy.detach().numpy(), Y_RTOL, Y_ATOL)
+    n = 0
+    for k, p in model.named_parameters():
+        ref = sdd[k].grad if k in sdd else None
+        if ref is None or p.grad is None or float(ref.abs().max()) == 0.0:
+            continue
+        check_rel(f"emb{emb}.stride{stride}.grad.{k}", p.grad.detach().cpu().reshape(ref.shape), ref, G_TOL)
+        n += 1
+    assert n >= 30
+
+
 def test_train_mode_readout_sampling_vs_reference_golden(golden, dev):
     """G4: train-mode forward with dropout 0 and the reference's eps draws injected: pins
     sigma*eps + mu -> clamp -> + shift ordering (gaussian2d.py:219-235, 265-268)."""

@@ -160,7 +160,11 @@ struct TileDma {
                          : "=&s"(keep) : "s"(m0v), "v"(v0), "s"(base) : "memory");
     }
     // img: element (row 0, col 0) of this (image, head) slice; t0: first row of the tile; lds: tile base (LDS_ELEMS elements)
-    DEVFN void issue(const bf16_t* img, int t0, int T, bf16_t* lds) const {
+    DEVFN void issue(const bf16_t* img, int t0_, int T, bf16_t* lds) const {
+        // a tile that lies WHOLLY beyond T (the dQ GEMM walks the 128-key padded width of dS': up to three such 32-key tiles when T % 128 <= 96 -
+        // first met at T = 34 114, tests/test_gpu_longseq.py; T = 1654 has none) is fetched as T - 1 repeated: without the clamp the row clamp below
+        // turned negative and the 32-bit lane offset, which the hardware zero-extends, pointed 4 GB behind the tile
+        const int t0 = min(t0_, T - 1);
         // (wave-uniform by construction; the explicit readfirstlanes keep the "s" asm operands in SGPRs where hipcc's uniformity
         // analysis gives up - a tile index that comes out of a loop rotated per wave half)
         const unsigned long long bb = (unsigned long long)(uintptr_t)((const char*)(img + (size_t)t0 * ld) - BIAS);
@@ -1350,7 +1354,7 @@ template <int DP, bool DROP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     using G = Geo<DP>;
     using Dma = typename Bwd2Lds<DP>::Dma;
-    static_assert(Dma::PW == 3, "three DMA pieces per wave and tile");
+    static_assert(Dma::PW == 3 && Dma::NINST == 11, "three DMA pieces per wave and tile, the eleventh half empty: head dim 160 (launch_bwd_t routes the others elsewhere)");
     __shared__ __attribute__((aligned(16))) Bwd2Lds<DP> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef V1T_KCLK
@@ -1931,7 +1935,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
 template <int DP, bool DROP, bool DIAG>
 int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
     const int n = ((a.T + 127) / 128) * a.H * a.B;
-    if constexpr (DP >= 128 && !DIAG) {
+    // the producer / consumer pair is laid out for head dim 160 (10.5 DMA pieces per 32-row tile dealt 3 / 3 / 3 / 2 over the wave pairs, the
+    // row constants riding in pair 3's free piece): at head dim 128 pair 3 would issue pieces that do not exist - the first test at that
+    // size (round 4, tools/attn_probe.py) returned garbage gradients - so every other head dim takes the recompute kernels below
+    if constexpr (DP == 160 && !DIAG) {
         if (a.ds) {
             if (a.ldds != attn_ds_ld(a.T)) return V1T_ERR_ARG;
             prof_begin(PROF_ATTN_DKV, s);
@@ -1962,7 +1969,7 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
 }
 template <int DP>
 int launch_delta_t(const AttnArgs& a, float* delta, hipStream_t s) {
-    if (DP >= 128 && !a.mask_diag && a.ds) {  // producer / consumer backward: padded row constants behind dS'
+    if (DP == 160 && !a.mask_diag && a.ds) {  // producer / consumer backward: padded row constants behind dS'
         const int TPQ = attn_ds_tpq(a.T);
         float* nlse = (float*)(a.ds + attn_ds_elems(a.B, a.H, a.T));
         const long long total = (long long)a.B * TPQ * a.H;
