@@ -530,3 +530,52 @@ def test_attention_forward_extreme_scores(ctx):
     check_rel("test_attention_forward_extreme_scores:38", o.float().cpu(), ref.cpu(), 1.5e-2)
     # scores of ~1e3 in log2 units
     assert float(((lse - ref_lse2).abs() / (1.0 + 4e-3 * ref_lse2.abs())).max()) < 1.0
+
+
+def test_multi_unit_entry_points_beyond_one_table(ctx):
+    """The one-launch-per-stage entry points take tables of <= 8 units (24 AdamW ranges) per launch and loop over longer lists: 10 units / 30 ranges
+    against their single-unit counterparts (v1t_resize_bilinear + v1t_concat2, v1t_adamw_step), bit for bit."""
+    import ctypes as C
+
+    lib, L, dev = ctx
+    g = torch.Generator().manual_seed(10)
+    # ---- v1t_inputs_multi: 10 units of 1-3 images, resize 18x32 -> 9x16 and behaviour rows cat(3, 2)
+    ns = [1, 2, 3, 1, 2, 3, 1, 2, 3, 2]
+    imgs = [torch.randn(n, 1, 18, 32, generator=g).to(dev) for n in ns]
+    behs = [torch.randn(n, 3, generator=g).to(dev) for n in ns]
+    pups = [torch.randn(n, 2, generator=g).to(dev) for n in ns]
+    B = sum(ns)
+    out, bout = torch.full((B, 1, 9, 16), float("nan"), device=dev), torch.full((B, 5), float("nan"), device=dev)
+    VP = C.c_void_p * len(ns)
+    L.check(lib.v1t_inputs_multi(VP(*[x.data_ptr() for x in imgs]), VP(*[x.data_ptr() for x in behs]), VP(*[x.data_ptr() for x in pups]), (C.c_int * len(ns))(*ns), len(ns),
+                                 1, 18, 32, out.data_ptr(), 9, 16, bout.data_ptr(), 3, 2, L.stream()))
+    ref, bref = torch.empty_like(out), torch.empty_like(bout)
+    o = 0
+    for n, im, be, pu in zip(ns, imgs, behs, pups):
+        L.check(lib.v1t_resize_bilinear(im.data_ptr(), n, 18, 32, ref[o:o + n].data_ptr(), 9, 16, L.stream()))
+        L.check(lib.v1t_concat2(be.data_ptr(), 3, pu.data_ptr(), 2, n, bref[o:o + n].data_ptr(), 5, L.stream()))
+        o += n
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(bout, bref)
+    # same sizes in and out: a plain copy
+    out2 = torch.empty(B, 1, 18, 32, device=dev)
+    L.check(lib.v1t_inputs_multi(VP(*[x.data_ptr() for x in imgs]), None, None, (C.c_int * len(ns))(*ns), len(ns), 1, 18, 32, out2.data_ptr(), 18, 32, None, 0, 0, L.stream()))
+    assert torch.equal(out2, torch.cat(imgs))
+    # ---- v1t_adamw_multi: 30 ranges of different length / lr / l1 / step against v1t_adamw_step
+    sizes = [17 + 97 * i for i in range(30)]
+    mk = lambda: [torch.randn(n, generator=g).to(dev) for n in sizes]  # noqa: E731
+    p1, g1, m1, v1 = mk(), mk(), mk(), [x.abs() for x in mk()]
+    p2, g2, m2, v2 = ([x.clone() for x in t_] for t_ in (p1, g1, m1, v1))
+    rs = []
+    for i, n in enumerate(sizes):
+        lr, l1, step = 1e-3 * (1 + i % 3), (0.0 if i % 2 else 0.01 * i), 1 + i % 5
+        rs.append(L.AdamRange(p1[i].data_ptr(), g1[i].data_ptr(), m1[i].data_ptr(), v1[i].data_ptr(), n, lr, l1, step, 0))
+        L.check(lib.v1t_adamw_step(p2[i].data_ptr(), g2[i].data_ptr(), m2[i].data_ptr(), v2[i].data_ptr(), n, lr, 0.9, 0.9999, 1e-8, 0.0, step, l1, 1, L.stream()))
+    L.check(lib.v1t_adamw_multi((L.AdamRange * len(rs))(*rs), len(rs), 0.9, 0.9999, 1e-8, 0.0, 1, L.stream()))
+    torch.cuda.synchronize()
+    for a, b in zip(p1 + g1 + m1 + v1, p2 + g2 + m2 + v2):
+        assert torch.equal(a, b)
+    # ---- v1t_fill_zero: any byte count at a 16-byte aligned address
+    buf = torch.full((1000,), 7, dtype=torch.uint8, device=dev)
+    L.check(lib.v1t_fill_zero(buf.data_ptr(), 997, L.stream()))
+    assert int(buf[:997].sum()) == 0 and int(buf[997:].sum()) == 21

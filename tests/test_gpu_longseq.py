@@ -98,3 +98,44 @@ def test_attention_resize_image_0_sequence(ctx):
           f"({2.5 * fl / t_bwd / 1e12:.0f} TFLOP/s), dS' scratch {nb / 2 ** 30:.2f} GB, peak allocated {peak_gb:.1f} GB")
     record_margin("longseq T=34114: forward ms (info)", t_fwd * 1e3, 1e9)
     record_margin("longseq T=34114: backward ms (info)", t_bwd * 1e3, 1e9)
+
+
+def test_model_resize_image_0_vs_oracle_on_gpu():
+    """The whole path at the `--resize_image 0` size (1 x 144 x 256 input -> T = 34 114 tokens, 137 x 249 readout cells, so the readout backward
+    takes its atomic form: more cells than the sorted form's LDS histogram holds), one block, B = 1: predictions, loss and every gradient
+    against the oracle evaluated in fp32 ON THE GPU (its (1, 4, T, T) attention tensors are 18.6 GB each - beyond what the CPU leg should be
+    asked to hold, well within 288 GB of HBM)."""
+    from oracle import v1t_oracle as O
+    from oracle import weights as W
+    from tests.helpers import assert_close, build_native_model
+    from v1t_amd.losses import elu1_poisson_loss
+
+    dev = torch.device("cuda:0")
+    cfg = O.Config(num_blocks=1, input_shape=(1, 144, 256), mouse_ids=("A",), num_neurons={"A": 128}, p_dropout=0.0, t_dropout=0.0)
+    sd = W.make_state_dict(cfg, 144)
+    batch = W.make_batch(cfg, "A", 1, 144)
+    model, _ = build_native_model(cfg, sd, dev)
+    assert model.core.num_tokens == T_FULL
+    model.train(False)
+    bd = {k: v.to(dev) for k, v in batch.items()}
+    u = model(inputs=bd["image"], mouse_id="A", behaviors=bd["behavior"], pupil_centers=bd["pupil_center"], activate=False)[0]
+    loss, _ = elu1_poisson_loss(u, bd["response"], 4500.0, 1)
+    loss.backward()
+    with torch.no_grad():
+        y = model(inputs=bd["image"], mouse_id="A", behaviors=bd["behavior"], pupil_centers=bd["pupil_center"])[0]
+    torch.cuda.synchronize()
+    sdd = {k: (v.to(dev).requires_grad_(True) if v.is_floating_point() else v.to(dev)) for k, v in sd.items()}
+    ol, _, oy = O.total_loss(cfg, sdd, bd, "A", 4500.0)
+    ol.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ol)) <= 1e-4 * abs(float(ol))
+    assert_close("resize_image 0: y vs oracle (fp32 on the GPU)", y.cpu().numpy(), oy.detach().cpu().numpy(), 1e-3, 1e-6)
+    n = 0
+    for k, p in model.named_parameters():
+        ref = sdd[k].grad if k in sdd else None
+        if ref is None or p.grad is None or float(ref.abs().max()) == 0.0:
+            continue
+        assert bool(torch.isfinite(p.grad).all()), k
+        check_rel(f"resize_image 0: grad {k}", p.grad.detach().cpu().reshape(ref.shape), ref.cpu(), 1.2e-2)
+        n += 1
+    assert n >= 25
