@@ -579,3 +579,63 @@ def test_multi_unit_entry_points_beyond_one_table(ctx):
     buf = torch.full((1000,), 7, dtype=torch.uint8, device=dev)
     L.check(lib.v1t_fill_zero(buf.data_ptr(), 997, L.stream()))
     assert int(buf[:997].sum()) == 0 and int(buf[997:].sum()) == 21
+
+
+def test_attention_random_shapes(ctx):
+    """Shape sweep of the attention entry points (forward, recompute backward, materialised-dS' backward) against fp32 torch: token counts of every
+    residue class that matters to the tilings (32-query / 32-key tiles, 64-key stages, 128-key workgroups, 256-query forward workgroups, 512-query
+    dQ workgroups), head dims 32-160, 1-3 heads, 1-2 images, with and without dropout. Round 4's two attention bugs sat at shapes no fixed case hit."""
+    lib, L, dev = ctx
+    rng = torch.Generator().manual_seed(2024)
+    Ts = [1, 2, 31, 32, 33, 63, 64, 65, 95, 97, 127, 128, 129, 159, 161, 191, 193, 255, 256, 257, 300, 384, 385, 449, 511, 512, 513, 577, 640, 641, 700, 769, 897, 1025]
+    worst = 0.0
+    for i, T in enumerate(Ts):
+        DP = (160, 160, 128, 96, 64, 32)[i % 6]
+        H, B = 1 + i % 3, 1 + (i // 3) % 2
+        p = 0.2 if i % 4 == 1 else 0.0
+        qkv = (torch.randn(B * T, 3 * H * DP, generator=rng) * 0.7).to(dev).bfloat16()
+        dO = (torch.randn(B * T, H * DP, generator=rng) * 0.5).to(dev).bfloat16()
+        scale = torch.tensor([DP ** -0.5], device=dev)
+        o = torch.full((B * T, H * DP), float("nan"), device=dev, dtype=torch.bfloat16)
+        lse = torch.full((B, H, T), float("nan"), device=dev)
+        seed, sid = 99 + i, 8
+        L.check(lib.v1t_attention_forward(qkv.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid, o.data_ptr(), lse.data_ptr(), L.stream()))
+        mask, p_eff = None, float(lib.v1t_attention_dropout_rate(p))
+        if p > 0:
+            mask = torch.empty(B * H * T, T, device=dev, dtype=torch.uint8)
+            L.check(lib.v1t_dropout_mask(seed, sid, p, B * H * T, T, mask.data_ptr(), L.stream()))
+        q, k, v = (x.detach().clone().requires_grad_(True) for x in qkv.float().view(B, T, 3, H, DP).permute(2, 0, 3, 1, 4))
+        a = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1)
+        if mask is not None:
+            a = a * mask.view(B, H, T, T).float() / (1 - p_eff)
+        ref = (a @ v).permute(0, 2, 1, 3).reshape(B * T, H * DP)
+        gq, gk, gv = torch.autograd.grad(ref, (q, k, v), dO.float())
+        tag = f"T{T} DP{DP} H{H} B{B} p{p}"
+        assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all()), tag
+        e = rel_to_max(o.float().cpu(), ref.detach().cpu())
+        worst = max(worst, e / 1e-2)
+        assert e < 1e-2, f"{tag}: forward {e:.3e}"
+        delta = torch.empty(B, H, T, device=dev)
+        outs = []
+        d1 = torch.full_like(qkv, float("nan"))
+        L.check(lib.v1t_attention_backward(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid, delta.data_ptr(),
+                                           d1.data_ptr(), None, L.stream()))
+        outs.append(("recompute", d1))
+        nb = int(lib.v1t_attention_backward_ws_bytes(B, H, T))
+        ws = torch.full((nb,), 0xFF, dtype=torch.uint8, device=dev)
+        d2 = torch.full_like(qkv, float("nan"))
+        L.check(lib.v1t_attention_backward_ws(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid, delta.data_ptr(),
+                                              d2.data_ptr(), None, ws.data_ptr(), nb, L.stream()))
+        outs.append(("materialised dS'", d2))
+        for nm, d in outs:
+            dd = d.float().view(B, T, 3, H, DP).permute(2, 0, 3, 1, 4)
+            assert bool(torch.isfinite(dd).all()), f"{tag}: {nm} not finite"
+            for j, (r, c) in enumerate(((gq, "q"), (gk, "k"), (gv, "v"))):
+                if float(r.abs().max()) == 0.0:
+                    continue
+                e = rel_to_max(dd[j].cpu(), r.cpu())
+                worst = max(worst, e / 2e-2)
+                assert e < 2e-2, f"{tag}: {nm} d{c} {e:.3e}"
+    from tests.helpers import record_margin
+
+    record_margin("test_attention_random_shapes: worst error / bound over 34 shapes", worst, 1.0)

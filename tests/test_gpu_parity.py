@@ -302,21 +302,22 @@ def test_patch_modes_2_3_gradients_vs_oracle(dev, pm):
     assert n >= (6 if pm == 2 else 8)
 
 
-@pytest.mark.parametrize("emb,heads,stride", [(128, 2, 1), (100, 2, 2), (155, 2, 2)])
-def test_other_head_dims_and_token_counts_vs_oracle(dev, emb, heads, stride):
+@pytest.mark.parametrize("emb,heads,stride,B,N,mlp", [(128, 2, 1, 2, 64, 96), (100, 2, 2, 2, 64, 96), (155, 2, 2, 2, 64, 96), (96, 3, 2, 1, 7, 70), (64, 1, 3, 5, 129, 33),
+                                                     (160, 4, 2, 3, 300, 488), (33, 1, 2, 2, 50, 64)])
+def test_other_head_dims_and_token_counts_vs_oracle(dev, emb, heads, stride, B, N, mlp):
     """Head dims other than the default 160 (emb_dim 128 -> the 128-wide attention instances, 100 -> 128 padded) and a token count whose last
     128-key block is mostly padding (patch_stride 2: T = 436): predictions, loss and every core gradient against the oracle's autograd. Round 4
     found the producer / consumer attention backward wrong at head dim 128 and its dQ GEMM reading out of bounds for T % 128 <= 96 - neither
     shape had a test."""
     from v1t_amd.losses import elu1_poisson_loss
 
-    cfg = O.Config(num_blocks=2, emb_dim=emb, mlp_dim=96, num_heads=heads, mouse_ids=("A",), num_neurons={"A": 64}, patch_stride=stride, p_dropout=0.0, t_dropout=0.0)
+    cfg = O.Config(num_blocks=2, emb_dim=emb, mlp_dim=mlp, num_heads=heads, mouse_ids=("A",), num_neurons={"A": N}, patch_stride=stride, p_dropout=0.0, t_dropout=0.0)
     sd = W.make_state_dict(cfg, 77)
-    batch = W.make_batch(cfg, "A", 2, 77)
+    batch = W.make_batch(cfg, "A", B, 77)
     model, _ = build_native_model(cfg, sd, dev)
     model.train(False)
     u = _fwd(model, batch, "A", dev, activate=False)
-    loss, _ = elu1_poisson_loss(u, batch["response"].to(dev), 4500.0, 2)
+    loss, _ = elu1_poisson_loss(u, batch["response"].to(dev), 4500.0, B)
     loss.backward()
     sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
     ol, _, oy = O.total_loss(cfg, sdd, batch, "A", 4500.0)
@@ -603,17 +604,19 @@ def test_core_batched_over_mice_equals_per_mouse(dev, variant):
         model.core.forward_many([b["image"] for _, b in pairs], [m for m, _ in pairs], [b["behavior"] for _, b in pairs], [b["pupil_center"] for _, b in pairs])
 
 
-@pytest.mark.parametrize("variant", [{}, {"behavior_mode": 0, "shift_mode": 0}, {"disable_grid_predictor": True, "behavior_mode": 2}, {"input_shape": (2, 36, 64)}])
+@pytest.mark.parametrize("variant", [{}, {"behavior_mode": 0, "shift_mode": 0}, {"disable_grid_predictor": True, "behavior_mode": 2}, {"input_shape": (2, 36, 64)},
+                                     {"_sizes": {"A": 5, "B": 1, "C": 3}}])
 def test_native_step_equals_autograd_step(dev, variant):
     """Trainer's autograd-free step (_NativeStep: the C-ABI entry points called directly, persistent buffers, in-kernel eps) against
     the nn.Module + autograd path on the same model, batches and replayed eps: every gradient arena and the loss."""
     from v1t_amd.synthetic import make_ds
     from v1t_amd.trainer import Trainer
 
+    variant = dict(variant)
+    sizes = variant.pop("_sizes", {"A": 4, "B": 4, "C": 4})  # (uneven mouse-batches: the units of the batched tails differ in size)
     cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B", "C"), num_neurons={"A": 96, "B": 50, "C": 130},
                    p_dropout=0.0, t_dropout=0.0, **variant)
     sd = W.make_state_dict(cfg, 21)
-    sizes = {"A": 4, "B": 4, "C": 4}
     batches = {m: {k: v.to(dev) for k, v in W.make_batch(cfg, m, sizes[m], 21).items()} for m in cfg.mouse_ids}
     eps = {m: W.make_eps(cfg, m, sizes[m], 21).to(dev) for m in cfg.mouse_ids}
     recs = []
