@@ -19,7 +19,7 @@ dropout ON (p=0.0229 / 0.2544, counter-based masks), readout position sampling O
 N > 1: per-mouse data parallelism (config C3): mice are sharded over ranks, the shared core's gradient arena is
 all-reduced (SUM) over RCCL in per-block buckets behind the backward; total work per step is fixed (112 images)
 => "scaling": "strong". Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel timed
-live with hipEvents on its stream; HBM traffic from the tracked PMC summary profiles/r03_pmc_attention.json, which must
+live with hipEvents on its stream; HBM traffic from the tracked PMC summary profiles/r04_pmc_attention.json, which must
 describe the launch shape of this run) and, at N = 1, `cpu_baseline` (the CPU oracle timed on the host).
 """
 from __future__ import annotations
@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_attention.json")  # collected by tools/pmc_bench.sh on the GPU box (separate --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_attention.json")  # collected by tools/pmc_bench.sh on the GPU box (separate --pmc passes)
 
 
 def algorithmic_flops(args, n_neurons: int) -> dict:
@@ -425,8 +425,6 @@ def main():
     for _ in range(a.warmup):
         trainer.train_step(batches)
     torch.cuda.synchronize()
-    peak_m = measured_peak(lib, L) if rank == 0 else None  # un-timed set-up, on a warm chip (the clock it reports is the loaded one)
-    torch.cuda.synchronize()
     n_local_launches = 16 * a.steps * len(sharding.local_units()) * args.num_blocks  # up to 15 windows + margin
     L.check(lib.v1t_profile_enable(a.profile_class, n_local_launches + 8))
     def window():
@@ -461,6 +459,10 @@ def main():
     L.check(lib.v1t_profile_read(C.byref(launches), C.byref(total_ms)))
     L.check(lib.v1t_profile_enable(-1, 0))
     loss = float(out["loss"])
+    # un-timed, BEHIND the timed windows (75 ms of back-to-back MFMAs in front of them would hand the first window a pre-heated chip):
+    # the chip is as warm as the step left it, so the clock the probe reports is the loaded one
+    peak_m = measured_peak(lib, L) if rank == 0 else None
+    torch.cuda.synchronize()
 
     if rank == 0:
         images = sharding.images_per_step() * a.steps

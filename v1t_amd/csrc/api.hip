@@ -801,7 +801,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
     float* delta = (float*)(sc + sl.delta);
     bf16_t* dqkv = (bf16_t*)(sc + sl.dqkv);
     float* dbeta = (float*)(sc + sl.dbeta);
-    if (h->inject && hipMemsetAsync(dbeta, 0, (size_t)h->NB * B * DP * 4, s) != hipSuccess) return V1T_ERR_LAUNCH;
+    if (h->inject) CHECK(launch_fill_zero(dbeta, (long long)h->NB * B * DP * 4, s));  // (a kernel of the library, not a runtime fill: nothing foreign in the step's trace)
     const TnPlan tp = tn_plan(h, R);
     float* slab = tp.slab ? (float*)(sc + sl.slab) : nullptr;
     const bool x16o = x16_attn_out(h, R), x16a = x16_gelu_out(h, R);  // the forward left only the fp16 planes of o / gelu(h)
