@@ -256,16 +256,37 @@ def run_rollout(a, dev):
     }
 
 
+def count_gpus_without_hip() -> int:
+    """GPUs of this node from the KFD topology in sysfs (nodes with simd_count > 0): the launcher must not initialise HIP - a process that has
+    is never re-executed on this pool, and `torch.cuda.device_count()` falls through to hipGetDeviceCount on builds without amdsmi. -1: unknown."""
+    import glob
+
+    n, seen = 0, False
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        seen = True
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n if seen else -1
+
+
 def spawn_ranks(a) -> int:
     """`python bench.py --gpus N` without torchrun: N child processes, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
     torch.distributed.run sets them, rendezvous on 127.0.0.1), rank 0's stdout relayed (its ONE JSON line), the other ranks'
-    output to stderr. The parent never initialises the GPU: torch.cuda.device_count() does not (it reads the driver's list).
-    Exit code: the first non-zero child code; 2 when the node has fewer than N GPUs (never a silent single-GPU line)."""
+    output to stderr. The parent never initialises the GPU (it counts devices in sysfs; unknown -> the children validate) and never re-executes
+    itself: the ranks are fresh children. The children are POLLED: the first non-zero exit terminates the rest (a crashed rank would otherwise
+    leave its siblings in the rendezvous or in a collective until the library's timeout) and becomes the exit code; 2 when the node has fewer
+    than N GPUs (never a silent single-GPU line)."""
     import socket
     import subprocess
 
     if not a.dry_run:
-        n_dev = torch.cuda.device_count()
+        n_dev = count_gpus_without_hip()
+        if n_dev < 0:
+            n_dev = torch.cuda.device_count()  # no KFD topology in sysfs (no driver: the build container): the device list the runtime reports, 0 there
         if n_dev < a.gpus:
             print(f"bench.py: --gpus {a.gpus} but this node has {n_dev} GPU(s)", file=sys.stderr, flush=True)
             return 2
@@ -279,10 +300,18 @@ def spawn_ranks(a) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=None if r == 0 else sys.stderr, stderr=sys.stderr))
-    code = 0
-    for p_ in procs:
-        rc = p_.wait()
-        code = code or rc
+    code, live = 0, list(procs)
+    while live:
+        for p_ in list(live):
+            rc = p_.poll()
+            if rc is None:
+                continue
+            live.remove(p_)
+            if rc != 0 and code == 0:
+                code = rc
+                for q_ in live:  # (exact children of this launcher, by handle)
+                    q_.terminate()
+        time.sleep(0.05)
     return code
 
 
@@ -291,6 +320,8 @@ def dry_run(a) -> int:
     import torch.distributed as dist
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if os.environ.get("V1T_BENCH_FAIL_RANK") == str(rank):  # test hook (tests/test_bench_launch.py): this rank dies before the rendezvous
+        return 3
     if world != a.gpus:
         print(f"--gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
@@ -339,8 +370,9 @@ def main():
     rank, local, world = init_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if torch.cuda.is_available() and world > torch.cuda.device_count() and os.environ.get("V1T_DIST_BACKEND") != "gloo":
-        raise SystemExit(f"--gpus {a.gpus} but this node has {torch.cuda.device_count()} GPU(s)")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))  # ranks on THIS node (a multi-node launch has world > the node's GPUs)
+    if torch.cuda.is_available() and local_world > torch.cuda.device_count() and os.environ.get("V1T_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"--gpus {a.gpus}: {local_world} ranks on this node but it has {torch.cuda.device_count()} GPU(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     local = local % torch.cuda.device_count()  # one rank per GPU under the driver; more ranks than GPUs share (dev runs)

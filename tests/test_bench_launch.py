@@ -36,6 +36,18 @@ def test_world_size_mismatch_is_an_error():
     assert r.returncode != 0
 
 
+def test_a_crashed_rank_ends_the_launch():
+    # rank 1 exits before the rendezvous: the launcher must terminate rank 0 (which would wait for its peer until gloo's timeout) and
+    # return rank 1's code, without a benchmark line
+    import time
+
+    t0 = time.time()
+    r = _run("--gpus", "2", "--dry-run", env={"V1T_BENCH_FAIL_RANK": "1"})
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert time.time() - t0 < 120
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
 import pytest  # noqa: E402
 
 
