@@ -598,7 +598,11 @@ def test_core_batched_over_mice_equals_per_mouse(dev, variant):
     for a, b_ in zip(ys, ys2):
         assert torch.equal(a, b_)  # eval mode: no dropout, rows independent of the rest of the batch
     for k in ref:
-        check_rel(f"test_core_batched_over_mice_equals_per_mouse:" + str(k), got[k], ref[k], 1e-4)  # summation order of float atomics over bf16-rounded intermediates: 1.8e-5 seen
+        # The two paths sum the readouts' dz with float atomics in different orders; where a sum lands within an ulp of a bf16 rounding boundary of the
+        # next GEMM's operand, ONE element of dy rounds the other way in some runs and not in others: 1.8e-5 of the tensor's max usually, 3.2e-4
+        # when it happens (round 4: variant 5 failed 2 of 12 identical runs at a bound of 1e-4, with the weight-gradient stream on or off). The
+        # bound is therefore a few bf16 ulps of one element, not the fp32 noise floor.
+        check_rel(f"test_core_batched_over_mice_equals_per_mouse:" + str(k), got[k], ref[k], 1e-3)
     model.core.behavior_mode = 4
     with pytest.raises(NotImplementedError):
         model.core.forward_many([b["image"] for _, b in pairs], [m for m, _ in pairs], [b["behavior"] for _, b in pairs], [b["pupil_center"] for _, b in pairs])
@@ -642,7 +646,7 @@ def test_native_step_equals_autograd_step(dev, variant):
     assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref)
     assert set(ref) == set(got) == {"core", "A", "B", "C"}
     for k in ref:
-        check_rel(f"test_native_step_equals_autograd_step:" + str(k), got[k], ref[k], 1e-4)  # float atomics in both paths: last bits
+        check_rel(f"test_native_step_equals_autograd_step:" + str(k), got[k], ref[k], 1e-3)  # float atomics in both paths: last bits, or one bf16 rounding flip (see test_core_batched_over_mice_equals_per_mouse)
 
 
 def test_native_step_eps_statistics(dev):

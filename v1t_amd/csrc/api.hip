@@ -67,6 +67,10 @@ struct v1t_vit {
     long long shadow_bytes;
     std::vector<PackDesc> pack;
     mutable PackDesc* d_pack;  // uploaded lazily by the first v1t_vit_pack (create works without a GPU)
+    // backward of SMALL launches (a rank's share of a multi-GPU step): the four weight-gradient GEMMs of a block run on a second stream beside
+    // the dX GEMMs of the same gradients (created by the first such backward)
+    mutable hipStream_t dw_stream = nullptr;
+    mutable hipEvent_t dw_ready[4] = {}, dw_done[4] = {};
 
     long long add(const std::string& name, std::initializer_list<long long> shape, bool is_param, long long& cursor) {
         TensorInfo t;
@@ -219,7 +223,7 @@ ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     s.delta = take((long long)B * h->H * h->T * 4);
     s.dqkv = take(R * 3 * h->HDP * 2);
     s.dbeta = take((long long)h->NB * B * h->DP * 4);
-    s.slab = take((long long)tn_plan(h, R).slab);
+    s.slab = take(4 * (((long long)tn_plan(h, R).slab + 255) / 256 * 256));  // one region per weight-gradient GEMM of a block (they may run beside the dX GEMMs)
     const long long RU = (long long)B * h->RCI;
     s.pu = take(h->s_pw >= 0 ? RU * h->PDX * 2 : 0);
     s.pgd = take(h->s_pw >= 0 ? RU * h->DP * 2 : 0);
@@ -537,6 +541,11 @@ int v1t_vit_create(const v1t_vit_config* cfg, v1t_vit** out) {
 void v1t_vit_destroy(v1t_vit* h) {
     if (!h) return;
     if (h->d_pack) (void)hipFree(h->d_pack);
+    for (int i = 0; i < 4; ++i) {
+        if (h->dw_ready[i]) (void)hipEventDestroy(h->dw_ready[i]);
+        if (h->dw_done[i]) (void)hipEventDestroy(h->dw_done[i]);
+    }
+    if (h->dw_stream) (void)hipStreamDestroy(h->dw_stream);
     delete h;
 }
 
@@ -804,6 +813,31 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
     if (h->inject) CHECK(launch_fill_zero(dbeta, (long long)h->NB * B * DP * 4, s));  // (a kernel of the library, not a runtime fill: nothing foreign in the step's trace)
     const TnPlan tp = tn_plan(h, R);
     float* slab = tp.slab ? (float*)(sc + sl.slab) : nullptr;
+    const size_t slab_stride = ((tp.slab + 255) / 256 * 256) / sizeof(float);
+    // Weight-gradient GEMMs beside the dX GEMMs (second stream): dW = dY^T X and dX = dY W only share their input dY. At full-size launches the
+    // two would fight for HBM (a side-stream experiment with the slab reductions alone lost 0.4 %, profiles/r04_gemm_experiments.txt); at a
+    // rank's share of a multi-GPU step (23 k rows: ~182 workgroups per launch on 256 CUs, latency-bound) the second stream fills idle CUs.
+    // V1T_DW_SIDE=0 / 1 forces it off / on (dev).
+    static const int dw_force = std::getenv("V1T_DW_SIDE") ? atoi(std::getenv("V1T_DW_SIDE")) : -1;
+    const bool dw_side = slab && (dw_force >= 0 ? dw_force > 0 : R < 65536);
+    if (dw_side && !h->dw_stream) {
+        if (hipStreamCreateWithFlags(&h->dw_stream, hipStreamNonBlocking) != hipSuccess) return V1T_ERR_LAUNCH;
+        for (int i = 0; i < 4; ++i)
+            if (hipEventCreateWithFlags(&h->dw_ready[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->dw_done[i], hipEventDisableTiming) != hipSuccess) return V1T_ERR_LAUNCH;
+    }
+    // GEMM j of a block (0 dW2, 1 dW1, 2 dWo, 3 dWqkv): on the second stream behind everything enqueued on `s` so far; join_dw(j) makes `s` wait for it
+    auto launch_dw = [&](GemmTNArgs& t, int j) -> int {
+        t.slab = slab ? slab + (size_t)j * slab_stride : nullptr;
+        if (!dw_side) return launch_gemm_tn(t, s);
+        if (hipEventRecord(h->dw_ready[j], s) != hipSuccess || hipStreamWaitEvent(h->dw_stream, h->dw_ready[j], 0) != hipSuccess) return V1T_ERR_LAUNCH;
+        const int rc = launch_gemm_tn(t, h->dw_stream);
+        if (rc) return rc;
+        return hipEventRecord(h->dw_done[j], h->dw_stream) == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    };
+    bool dw_pending[4] = {false, false, false, false};
+    auto join_dw = [&](int j) {
+        if (dw_side && dw_pending[j]) { (void)hipStreamWaitEvent(s, h->dw_done[j], 0); dw_pending[j] = false; }
+    };
     const bool x16o = x16_attn_out(h, R), x16a = x16_gelu_out(h, R);  // the forward left only the fp16 planes of o / gelu(h)
 
     const float* gin = gout;
@@ -833,8 +867,10 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         GemmTNArgs t{};
         t.Y = dy; t.ldy = DP; t.X = x16a ? (const bf16_t*)(wb + w.hact_lo) : hact; t.x_f16 = x16a; t.ldx = MP; t.M = R; t.NY = DP; t.NX = MP; t.dW = grads + b.fc2; t.ldw = M;
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = MP; t.xseg_valid = M; t.alpha = 1.f;
-        t.m_chunk = tp.mc_fc2; t.slab = slab;
-        CHECK(launch_gemm_tn(t, s));
+        t.m_chunk = tp.mc_fc2;
+        CHECK(launch_dw(t, 0));  // reads dy, hact
+        dw_pending[0] = true;
+        join_dw(1);              // the previous block's dW1 read dhpre, which the next GEMM overwrites
         // d_hpre = (dy . W2) * mask * gelu'(hpre); db1 += colsum
         GemmNTArgs g{};
         g.A = dy; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_fc2_t); g.ldb = DP; g.M = R; g.N = MP; g.K = DP; g.C = dhpre; g.ldc = MP;
@@ -847,8 +883,10 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         t.Y = dhpre; t.ldy = MP; t.X = z2; t.ldx = DP; t.M = R; t.NY = MP; t.NX = DP; t.dW = grads + b.fc1; t.ldw = D;
         t.yseg_pad = MP; t.yseg_valid = M; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
         if (DP > D && b.fc1b >= 0) { t.dbias = grads + b.fc1b; t.ones_col = DP - 1; }  // z2[:, DP-1] == 1 (LN kernel)
-        t.m_chunk = tp.mc_fc1; t.slab = slab;
-        CHECK(launch_gemm_tn(t, s));
+        t.m_chunk = tp.mc_fc1;
+        CHECK(launch_dw(t, 1));  // reads dhpre, z2
+        dw_pending[1] = true;
+        join_dw(0);              // dW2 reads dy, which the LayerNorm backward below overwrites (dy_next)
         // dz2 = d_hpre . W1
         g = GemmNTArgs{};
         g.A = dhpre; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc1_t); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = dz; g.ldc = DP;
@@ -867,8 +905,10 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         t = GemmTNArgs{};
         t.Y = dy; t.ldy = DP; t.X = x16o ? (const bf16_t*)(wb + w.o_lo) : o; t.x_f16 = x16o; t.ldx = HDP; t.M = R; t.NY = DP; t.NX = HDP; t.dW = grads + b.proj; t.ldw = h->HD;
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->HEP; t.xseg_valid = h->HE; t.alpha = 1.f;
-        t.m_chunk = tp.mc_proj; t.slab = slab;
-        CHECK(launch_gemm_tn(t, s));
+        t.m_chunk = tp.mc_proj;
+        CHECK(launch_dw(t, 2));  // reads dy, o
+        dw_pending[2] = true;
+        join_dw(3);              // the previous block's dWqkv read dqkv, which this block's attention backward overwrites
         // dO = dy . Wo
         g = GemmNTArgs{};
         g.A = dy; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_proj_t); g.ldb = DP; g.M = R; g.N = HDP; g.K = DP; g.C = dO; g.ldc = HDP;
@@ -897,8 +937,10 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         t = GemmTNArgs{};
         t.Y = dqkv; t.ldy = 3 * HDP; t.X = z1; t.ldx = DP; t.M = R; t.NY = 3 * HDP; t.NX = DP; t.dW = grads + b.qkv; t.ldw = D;
         t.yseg_pad = h->HEP; t.yseg_valid = h->HE; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
-        t.m_chunk = tp.mc_qkv; t.slab = slab;
-        CHECK(launch_gemm_tn(t, s));
+        t.m_chunk = tp.mc_qkv;
+        CHECK(launch_dw(t, 3));  // reads dqkv, z1
+        dw_pending[3] = true;
+        join_dw(2);              // dWo reads dy, which the LayerNorm backward below overwrites (dy_next of the block before)
         // dz1 = dqkv . Wqkv
         g = GemmNTArgs{};
         g.A = dqkv; g.lda = 3 * HDP; g.B = (const bf16_t*)(sh + b.s_qkv_t); g.ldb = 3 * HDP; g.M = R; g.N = DP; g.K = 3 * HDP; g.C = dz; g.ldc = DP;
@@ -916,8 +958,12 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
         CHECK(dx_then_ln_bwd(g, lb, s));
         // every gradient of block k's attention / MLP parameters is now in `grads` (its BehaviorMLP's follow at the end)
-        if (block_done && block_done[k] && hipEventRecord((hipEvent_t)block_done[k], s) != hipSuccess) return V1T_ERR_LAUNCH;
+        if (block_done && block_done[k]) {  // the block's gradients are complete on `s`: its weight-gradient GEMMs joined
+            for (int j = 0; j < 4; ++j) join_dw(j);
+            if (hipEventRecord((hipEvent_t)block_done[k], s) != hipSuccess) return V1T_ERR_LAUNCH;
+        }
     }
+    for (int j = 0; j < 4; ++j) join_dw(j);  // everything of the second stream is behind `s` from here on (slab region 0 is reused below)
     // ---- patch embedding backward (gin = grad wrt x0)
     PatchArgs pa{};
     pa.img = images; pa.B = B; pa.C = h->C; pa.IH = h->IH; pa.IW = h->IW; pa.P = h->P; pa.stride = h->S; pa.NH = h->NH; pa.NW = h->NW;
