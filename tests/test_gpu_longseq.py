@@ -139,3 +139,31 @@ def test_model_resize_image_0_vs_oracle_on_gpu():
         check_rel(f"resize_image 0: grad {k}", p.grad.detach().cpu().reshape(ref.shape), ref.cpu(), 1.2e-2)
         n += 1
     assert n >= 25
+
+
+def test_trainer_falls_back_for_large_latent_grids():
+    """A latent grid of more than 4096 cells (here 137 x 249) has no sorted readout backward (LDS histogram), which the native step's split
+    sort / dz / parameter launches need: `_NativeStep.build` must decline and the trainer must run the step through the module path instead of
+    raising mid-training."""
+    from oracle import v1t_oracle as O
+    from oracle import weights as W
+    from tests.helpers import build_native_model
+    from v1t_amd.synthetic import make_ds
+    from v1t_amd.trainer import Trainer
+
+    dev = torch.device("cuda:0")
+    cfg = O.Config(num_blocks=1, input_shape=(1, 144, 256), mouse_ids=("A", "B"), num_neurons={"A": 40, "B": 24}, p_dropout=0.0, t_dropout=0.0)
+    sd = W.make_state_dict(cfg, 5)
+    model, args = build_native_model(cfg, sd, dev)
+    args.batch_size = 1
+    tr = Trainer(args, model, make_ds(cfg.num_neurons))
+    before = {k: v.detach().clone() for k, v in model.state_dict().items() if v.is_floating_point()}
+    out = tr.train_step({m: {k: v.to(dev) for k, v in W.make_batch(cfg, m, 1, 5).items()} for m in cfg.mouse_ids})
+    torch.cuda.synchronize()
+    assert tr.native and all(v is None for v in tr._native_cache.values()), "the native step must have declined this geometry"
+    assert bool(torch.isfinite(out["loss"]))
+    moved = sum(int(not torch.equal(v, before[k])) for k, v in model.state_dict().items() if k in before)
+    assert moved >= 20  # the optimizer stepped the core and both mice
+    for k, v in model.state_dict().items():
+        if v.is_floating_point():
+            assert bool(torch.isfinite(v).all()), k
