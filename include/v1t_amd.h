@@ -7,12 +7,15 @@
  * readout/gaussian2d.py:13). The entry points below are what a ctypes binding behind those two
  * registry entries calls (INTEGRATION.md shows the stub); each cites the reference code it replaces.
  *
- * Conventions: every pointer is a DEVICE pointer borrowed for the call (except v1t_vit_config and
- * name/shape out-parameters, which are host memory); nothing is allocated inside a launch function
- * (workspaces are sized by the *_bytes queries and passed in); all work is enqueued asynchronously
- * on `stream` (a hipStream_t passed as void*); return value 0 = ok, negative = error code below
- * (the Python shim raises RuntimeError, which the reference's OOM probe utils/utils.py:460 relies on).
- * Thread-safe for distinct handles / distinct streams.
+ * Conventions: every pointer is a DEVICE pointer borrowed for the call, except v1t_vit_config, name/shape out-parameters and the TABLES of the
+ * multi-unit entry points (v1t_tail_unit / v1t_adam_range arrays, the pointer and count arrays of v1t_inputs_multi), which are host memory read
+ * during the call (their contents travel in the kernel arguments; the device pointers inside them are borrowed like any other). No device
+ * memory is allocated inside a launch function (workspaces are sized by the *_bytes queries and passed in; the measurement aid
+ * v1t_mfma_peak_probe is the one exception); all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
+ * v1t_vit_backward(_events) additionally owns one internal stream per plan (created by its first small launch, destroyed with the plan) on which
+ * the weight-gradient GEMMs of launches below 65 536 rows run, joined to `stream` by events before the call returns its last launch.
+ * Return value 0 = ok, negative = error code below (the Python shim raises RuntimeError, which the reference's OOM probe utils/utils.py:460
+ * relies on). Thread-safe for distinct handles / distinct streams.
  */
 #ifndef V1T_AMD_H
 #define V1T_AMD_H
