@@ -167,3 +167,74 @@ def test_trainer_falls_back_for_large_latent_grids():
     for k, v in model.state_dict().items():
         if v.is_floating_point():
             assert bool(torch.isfinite(v).all()), k
+
+
+def test_eval_forward_batch_1024_beyond_2_31_elements():
+    """One forward over B = 1024 images of the default V1T: 1.69 M rows, the qkv plane alone is 3.25e9 elements - past every 32-bit element index
+    (the hot path's kernels index with size_t; nothing smaller than B = 256 had run). Rows do not depend on the rest of the batch, so the
+    predictions must agree with the same images run 64 at a time."""
+    from oracle import weights as W
+    from tests.helpers import assert_close, build_native_model
+
+    dev = torch.device("cuda:0")
+    cfg = W.config_c2({"A": 200})
+    sd = W.make_state_dict(cfg, 1234)
+    model, _ = build_native_model(cfg, sd, dev)
+    model.train(False)
+    B = 1024
+    assert B * model.core.num_tokens * 3 * 4 * 160 > 2 ** 31
+    b = {k: v.to(dev) for k, v in W.make_batch(cfg, "A", B, 1024).items()}
+    with torch.no_grad():
+        y = model(inputs=b["image"], mouse_id="A", behaviors=b["behavior"], pupil_centers=b["pupil_center"])[0]
+        torch.cuda.synchronize()
+        assert y.shape == (B, 200) and bool(torch.isfinite(y).all())
+        parts = [model(inputs=b["image"][i:i + 64], mouse_id="A", behaviors=b["behavior"][i:i + 64], pupil_centers=b["pupil_center"][i:i + 64])[0] for i in range(0, B, 64)]
+    assert_close("eval B=1024 vs 16 x 64", y.cpu().numpy(), torch.cat(parts).cpu().numpy(), 1e-3, 1e-6)
+
+
+def test_training_step_batch_512_equals_four_of_128():
+    """The native training step over ONE mouse-batch of 512 images (dS' scratch 11.4 GB: 5.7e9 elements, past 2^32) against the summed gradients of
+    four steps of 128 images (dropout 0, replayed position noise, optimizer intercepted): loss and every gradient arena."""
+    from oracle import weights as W
+    from tests.helpers import build_native_model
+    from v1t_amd.synthetic import make_ds
+    from v1t_amd.trainer import Trainer
+
+    dev = torch.device("cuda:0")
+    cfg = W.config_c2({"A": 500})
+    cfg.p_dropout = cfg.t_dropout = 0.0
+    sd = W.make_state_dict(cfg, 1234)
+    B = 512
+    batch = {k: v.to(dev) for k, v in W.make_batch(cfg, "A", B, 512).items()}
+    eps = W.make_eps(cfg, "A", B, 512).to(dev)
+
+    def run(chunks):
+        model, args = build_native_model(cfg, sd, dev)
+        args.batch_size = B // chunks
+        tr = Trainer(args, model, make_ds(cfg.num_neurons))
+        # every call's gradients are taken where the optimizer would read them and the arenas zeroed, as the optimizer leaves them (the step
+        # OVERWRITES d sigma - one unit per mouse and step - so the calls are summed here, not left to accumulate in the arena)
+        sums = {}
+
+        def take(arena, ranges, zero_grad=True):
+            key = "core" if arena is model.core._arena else "A"
+            sums[key] = sums.get(key, 0) + arena.grad.detach().clone()
+            arena.grad.zero_()
+
+        tr.opt.step_arena = take
+        loss, n = 0.0, B // chunks
+        for c in range(chunks):
+            sl = slice(c * n, (c + 1) * n)
+            tr.eps_override = {"A": eps[sl].contiguous()}
+            loss += float(tr.train_step({"A": {k: v[sl].contiguous() for k, v in batch.items()}})["loss"])
+        torch.cuda.synchronize()
+        assert all(v is not None for v in tr._native_cache.values()), "the native step must have run"
+        return loss, sums["core"], sums["A"]
+
+    l1, gc1, gm1 = run(1)
+    l4, gc4, gm4 = run(4)
+    # (the loss scale sqrt(ds_size / batch) differs between the two batchings: loss(512) = loss(4 x 128) / 2, gradients likewise)
+    assert abs(l1 - l4 / 2.0) <= 1e-4 * abs(l1)
+    check_rel("B=512 step vs 4 x 128: core arena", gc1, gc4 / 2.0, 1e-3)
+    check_rel("B=512 step vs 4 x 128: mouse arena", gm1, gm4 / 2.0, 1e-3)
+    assert bool(torch.isfinite(gc1).all()) and bool(torch.isfinite(gm1).all())

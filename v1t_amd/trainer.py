@@ -274,6 +274,8 @@ class _NativeStep:
             u.src = P(t_["src"])
             for k in range(4):
                 u.gp[k], u.dgp[k] = P(t_["gp"][k]), P(t_["dgp"][k])
+            # (d sigma / d mu are OVERWRITTEN by the sample-position backward, every other gradient is accumulated: one unit per mouse and step,
+            # and the optimizer zeroes the arena behind it - tests that sum several calls take the gradients per call)
             u.mu, u.dmu, u.sigma, u.dsigma = P(t_["mu"]), P(t_["dmu"]), t_["sigma"], t_["dsigma"]
             u.feat, u.dfeat, u.bias, u.dbias = t_["feat"], t_["dfeat"], P(t_["bias"]), P(t_["dbias"])
             u.eps, u.grid, u.dgrid = t_["eps"].data_ptr(), t_["grid"].data_ptr(), t_["dgrid"].data_ptr()
