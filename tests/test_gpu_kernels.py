@@ -135,7 +135,10 @@ def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
                 check_rel(f"test_attention_forward_backward:" + str(nm), e[:, i].cpu(), d[:, i].cpu(), 1e-2)
 
 
-@pytest.mark.parametrize("B,C,H,W,N", [(3, 155, 29, 57, 1000), (2, 64, 29, 57, 257), (1, 40, 15, 29, 3), (2, 155, 5, 7, 900)])
+@pytest.mark.parametrize("B,C,H,W,N", [(3, 155, 29, 57, 1000), (2, 64, 29, 57, 257), (1, 40, 15, 29, 3), (2, 155, 5, 7, 900),
+                                       # edge shapes (round 4): one cell / one neuron / one channel, channel counts around the 64-lane passes, 33 images, a map of
+                                       # exactly 4096 cells (the sorted backward's LDS histogram) and one beyond it (atomic form)
+                                       (1, 1, 1, 1, 1), (33, 63, 2, 3, 7), (2, 65, 3, 2, 130), (1, 160, 64, 64, 300), (2, 129, 65, 64, 50), (17, 256, 4, 4, 64)])
 def test_readout(ctx, B, C, H, W, N):
     from oracle import v1t_oracle as O
 
