@@ -362,6 +362,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
     const uint32_t dbase = a.adrop.key + ((uint32_t)(b * a.H + h) * T2 + ((uint32_t)q >> 1)) * ADROP_K1 + (uint32_t)(2 * h2) * ADROP_K2;
     const uint32_t sh_even = 16 * (q & 1), sh_odd = sh_even + 8;
+    const uint32_t thr8v = a.adrop.thresh8;
+    (void)sh_odd; (void)thr8v;
 
     const int koff = (lane & 31) * G::RSTR + 8 * h2;
     const int voff = tr_lane_off(lane, G::TSTR);
@@ -440,13 +442,28 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
         KP_STAMP(3);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            bool keep[4] = {true, true, true, true};
-            if constexpr (DROP) drop4(dbase + (uint32_t)(16 * kt + 4 * g) * ADROP_K2, ADROP_K2, sh_even, sh_odd, a.adrop.thresh8, keep);
+            uint32_t wq[2] = {0u, 0u};
+            // dropout decisions by a byte compare (v_cmp_ge_u32_sdwa + select: 2 instructions per element, a shift per word) instead of bit-field
+            // extract + compare + select; the same decisions bit for bit (round 4: forward 979 -> 962-967 us, profiles/r04_attn_experiments.txt #6)
+            if constexpr (DROP) {  // the two words of this group, shifted so that this query's decisions are bytes 0 (even key) and 1 (odd key)
+                const uint32_t x0 = dbase + (uint32_t)(16 * kt + 4 * g) * ADROP_K2;
+                wq[0] = mix1(x0) >> sh_even;
+                wq[1] = mix1(x0 + ADROP_K2) >> sh_even;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float p = fast_exp2(fmaf(s[4 * g + j], c, negm));
                 lsum += p;
-                s[4 * g + j] = keep[j] ? p : 0.f;
+                if constexpr (DROP) {
+                    float pd;
+                    if ((j & 1) == 0)
+                        asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(wq[j >> 1]), "v"(thr8v), "v"(p) : "vcc");
+                    else
+                        asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(wq[j >> 1]), "v"(thr8v), "v"(p) : "vcc");
+                    s[4 * g + j] = pd;
+                } else {
+                    s[4 * g + j] = p;
+                }
             }
         }
         const bf16x8 p0 = acc_to_b_pk(s, 0), p1 = acc_to_b_pk(s, 1);
@@ -1467,11 +1484,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
     const uint32_t dbase = a.adrop.key + ((uint32_t)bh * T2 + (uint32_t)(2 * h2)) * ADROP_K1 + ((uint32_t)key >> 1) * ADROP_K2;
     const uint32_t dshift = 8 * (key & 1);
-    const uint32_t dthr = a.adrop.thresh8 * 0x00010001u;
-    auto keep_word = [&](int blk, int wi) {  // wi = 2 g + u
-        const uint32_t w = mix1(dbase + (uint32_t)(16 * blk + 4 * (wi >> 1) + (wi & 1)) * ADROP_K1) >> dshift;
-        return ((w & 0x00FF00FFu) | 0x01000100u) - dthr;
-    };
+    // the raw word shifted so that this key's two decisions are bytes 0 (even row) and 2 (odd row); the compare reads the byte itself
+    // (v_cmp_ge_u32_sdwa): compare + select per element. (Rounds 2-3: a 9-bit SWAR preparation per word - and / or / sub - then a 1-bit v_bfe_i32
+    // and a v_and per element; same decisions bit for bit, 24 vector instructions fewer per 32 x 32 block: backward pair 2519 / 2530 -> 2480 / 2484 us,
+    // profiles/r04_attn_experiments.txt #6.)
+    const uint32_t dthr8 = a.adrop.thresh8;
+    auto keep_word = [&](int blk, int wi) { return mix1(dbase + (uint32_t)(16 * blk + 4 * (wi >> 1) + (wi & 1)) * ADROP_K1) >> dshift; };
 
     if (wave < 4) {
         // ------------------------------------------------------------------ producer
@@ -1586,10 +1604,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
                             // consumers are the critical path of a step (ablation: their 8 hash words cost the kernel 7 %) while
                             // the producers wait ~600 cycles at every barrier
                             if ((j & 1) == 0) kw[wi >> 2][wi & 3] = keep_word(i, wi);
-                            uint32_t km;  // asm: hipcc otherwise rewrites the 1-bit sign extension + and into and + compare + select
-                            if ((j & 1) == 0) asm("v_bfe_i32 %0, %1, 8, 1" : "=v"(km) : "v"(kw[wi >> 2][wi & 3]));
-                            else asm("v_bfe_i32 %0, %1, 24, 1" : "=v"(km) : "v"(kw[wi >> 2][wi & 3]));
-                            const float pd = __uint_as_float(__float_as_uint(p) & km);
+                            float pd;
+                            if ((j & 1) == 0)
+                                asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(kw[wi >> 2][wi & 3]), "v"(dthr8), "v"(p) : "vcc");
+                            else
+                                asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(kw[wi >> 2][wi & 3]), "v"(dthr8), "v"(p) : "vcc");
                             dp[r] = fmaf(pd, dp[r], p * nd[r]);
                             s[r] = pd;
                         } else {
