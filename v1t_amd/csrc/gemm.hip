@@ -5,6 +5,7 @@
 // by 16 B (80-B stride -> the 16 rows a ds_read_b128 lane group touches land on 16 distinct
 // 16-B slots), double-buffered LDS, next tile's global loads issued before the MFMAs and written
 // to the other buffer after them (one barrier per K-tile).
+#include <type_traits>
 #include <cstdlib>
 
 #include "gemm.h"
@@ -1055,39 +1056,46 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(GemmNTArgs g, LnBwdA
     const size_t row0 = (size_t)b * l.T;
     const int nk = g.K / BK;
 
-    u32x4 ra[A_ITERS], rb[B_ITERS];
-    auto gload = [&](int kt) {
+    // two K tiles of operand loads in flight (register sets 0 / 1, tile kt in set kt & 1), one tile in LDS ahead of the MFMAs: a workgroup's K loop is a
+    // chain of HBM round trips (64 B of each of its 128 rows per tile), and a launch with fewer workgroups than the chip holds has nothing else to cover them
+    u32x4 ra[2][A_ITERS], rb[2][B_ITERS];
+    auto gload = [&](auto set, int kt) {
+        constexpr int S = decltype(set)::value;
         const int k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
             const int c = tid + NT * i, row = c / KC, kc = c % KC;
-            ra[i] = *(const u32x4*)(g.A + (row0 + min(t0 + row, l.T - 1)) * g.lda + k0 + 8 * kc);  // rows past the image: clamped, masked below
+            ra[S][i] = *(const u32x4*)(g.A + (row0 + min(t0 + row, l.T - 1)) * g.lda + k0 + 8 * kc);  // rows past the image: clamped, masked below
         }
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
-            const int c = tid + NT * i, row = c / KC, kc = c % KC;
-            if (c < B_CHUNKS) rb[i] = *(const u32x4*)(g.B + (size_t)row * g.ldb + k0 + 8 * kc);
+        for (int i = 0; i < B_ITERS; ++i) {  // no branch around a load: the compiler's vmcnt counts stay exact (lanes past the tile repeat its last chunk)
+            const int c = min(tid + NT * i, B_CHUNKS - 1), row = c / KC, kc = c % KC;
+            rb[S][i] = *(const u32x4*)(g.B + (size_t)row * g.ldb + k0 + 8 * kc);
         }
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](auto set, int buf) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
             const int c = tid + NT * i, row = c / KC, kc = c % KC;
-            *(u32x4*)(&sA[buf][row * LS + 8 * kc]) = ra[i];
+            *(u32x4*)(&sA[buf][row * LS + 8 * kc]) = ra[S][i];
         }
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
             const int c = tid + NT * i, row = c / KC, kc = c % KC;
-            if (c < B_CHUNKS) *(u32x4*)(&sB[buf][row * LS + 8 * kc]) = rb[i];
+            if (c < B_CHUNKS) *(u32x4*)(&sB[buf][row * LS + 8 * kc]) = rb[S][i];
         }
     };
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
     f32x16 acc[NBLK];
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    gload(0);
-    swrite(0);
+    gload(set0{}, 0);
+    gload(set1{}, min(1, nk - 1));
+    swrite(set0{}, 0);
     __syncthreads();
     const int frag_off = (lane & 31) * LS + 8 * (lane >> 5);
     auto ktile = [&](int buf) {
@@ -1101,14 +1109,26 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(GemmNTArgs g, LnBwdA
             }
         }
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        const int buf = kt & 1;
-        gload(kt + 1);
-        ktile(buf);
-        swrite(buf ^ 1);
+    // tile kt sits in LDS buffer kt & 1, tile kt + 1 is in flight into set (kt + 1) & 1; past the last tile the loads repeat it (no branch in the loop)
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+        gload(set0{}, kt + 2);
+        ktile(0);
+        swrite(set1{}, 1);
+        __syncthreads();
+        gload(set1{}, min(kt + 3, nk - 1));
+        ktile(1);
+        swrite(set0{}, 0);
         __syncthreads();
     }
-    ktile((nk - 1) & 1);
+    if (kt + 1 < nk) {  // an even count: tiles nk - 2 (buffer 0) and nk - 1 (set 1)
+        ktile(0);
+        swrite(set1{}, 1);
+        __syncthreads();
+        ktile(1);
+    } else {
+        ktile(0);
+    }
     __syncthreads();  // every wave is done with the operand tiles: the bf16 staging below reuses them
 
     // ---- LayerNorm backward on the accumulators: column = 32 nb + (lane & 31), row = 32 wave + acc_row(r, lane)
