@@ -19,7 +19,7 @@ dropout ON (p=0.0229 / 0.2544, counter-based masks), readout position sampling O
 N > 1: per-mouse data parallelism (config C3): mice are sharded over ranks, the shared core's gradient arena is
 all-reduced (SUM) over RCCL in per-block buckets behind the backward; total work per step is fixed (112 images)
 => "scaling": "strong". Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel timed
-live with hipEvents on its stream; HBM traffic from the tracked PMC summary profiles/r04_pmc_attention.json, which must
+live with hipEvents on its stream; HBM traffic from the tracked PMC summary profiles/r05_pmc_attention.json, which must
 describe the launch shape of this run) and, at N = 1, `cpu_baseline` (the CPU oracle timed on the host).
 """
 from __future__ import annotations
@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_attention.json")  # collected by tools/pmc_bench.sh on the GPU box (separate --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_attention.json")  # collected by tools/pmc_bench.sh on the GPU box (separate --pmc passes)
 
 
 def algorithmic_flops(args, n_neurons: int) -> dict:
@@ -270,7 +270,14 @@ def count_gpus_without_hip() -> int:
         seen = True
         if int(props.get("simd_count", "0")) > 0:
             n += 1
-    return n if seen else -1
+    if not seen:
+        return -1
+    # a restricted visible set (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES): the runtime will offer at most that many
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def spawn_ranks(a) -> int:
@@ -279,7 +286,9 @@ def spawn_ranks(a) -> int:
     output to stderr. The parent never initialises the GPU (it counts devices in sysfs; unknown -> the children validate) and never re-executes
     itself: the ranks are fresh children. The children are POLLED: the first non-zero exit terminates the rest (a crashed rank would otherwise
     leave its siblings in the rendezvous or in a collective until the library's timeout) and becomes the exit code; 2 when the node has fewer
-    than N GPUs (never a silent single-GPU line)."""
+    than N GPUs (never a silent single-GPU line). A rank that HANGS is caught twice: every rank runs its own watchdog (`Watchdog`: no progress
+    mark for V1T_BENCH_DEADLINE_S seconds -> the rank exits 124, which ends the launch here or under torchrun), and the launcher itself
+    terminates all ranks and returns 124 when the whole launch exceeds V1T_BENCH_LAUNCH_DEADLINE_S (default 900 s)."""
     import socket
     import subprocess
 
@@ -301,7 +310,18 @@ def spawn_ranks(a) -> int:
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=None if r == 0 else sys.stderr, stderr=sys.stderr))
     code, live = 0, list(procs)
+    t_end = time.time() + float(os.environ.get("V1T_BENCH_LAUNCH_DEADLINE_S", "900"))
     while live:
+        if time.time() > t_end:
+            print(f"bench.py: launch deadline passed with {len(live)} rank(s) still running: terminating them", file=sys.stderr, flush=True)
+            for q_ in live:  # (exact children of this launcher, by handle)
+                q_.terminate()
+            for q_ in live:
+                try:
+                    q_.wait(timeout=10)
+                except Exception:  # noqa: BLE001
+                    q_.kill()
+            return code or 124
         for p_ in list(live):
             rc = p_.poll()
             if rc is None:
@@ -315,6 +335,94 @@ def spawn_ranks(a) -> int:
     return code
 
 
+class Watchdog:
+    """Per-rank progress deadline. The 8-GPU run of this bench happens once, on hardware nobody can rehearse on: a rank
+    that stops making progress - a collective that never completes, a rendezvous that never forms - must END the run instead of sitting in
+    the library's timeout. `mark(phase)` records progress; a daemon thread exits the process with code 124 when no mark arrived for
+    V1T_BENCH_DEADLINE_S seconds (default 240: above the first RCCL initialisation of 8 ranks, far below the driver's budget). Under
+    torchrun or bench.py's own launcher a rank exiting non-zero terminates its siblings. `on_expire` (rank 0) gets a chance to print the
+    failure line first."""
+
+    def __init__(self, rank: int, on_expire=None):
+        import threading
+
+        self.rank, self.deadline = rank, float(os.environ.get("V1T_BENCH_DEADLINE_S", "240"))
+        self.phase, self.t, self.on_expire, self._stop = "start", time.monotonic(), on_expire, False
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+
+    def mark(self, phase: str) -> None:
+        self.phase, self.t = phase, time.monotonic()
+
+    def watch_sigterm(self) -> None:
+        """Rank 0 only, from the main thread: when the launcher (torchrun or bench.py's own) terminates this rank because ANOTHER rank failed,
+        the failure line is still printed. The C-level signal handler writes the signal number to a wake-up socket the moment SIGTERM
+        arrives - also while the main thread sits inside a collective or a synchronize - and a daemon thread reads it."""
+        import signal
+        import socket
+        import threading
+
+        r, w = socket.socketpair()
+        w.setblocking(False)
+        signal.set_wakeup_fd(w.fileno(), warn_on_full_buffer=False)
+        signal.signal(signal.SIGTERM, lambda *_: None)
+        self._socks = (r, w)
+
+        def run():
+            while True:
+                b = r.recv(1)
+                if b and b[0] == signal.SIGTERM:
+                    try:
+                        if self.on_expire is not None:
+                            self.on_expire(f"terminated by the launcher in phase '{self.phase}' (another rank failed or a deadline passed)")
+                    finally:
+                        os._exit(143)
+
+        threading.Thread(target=run, daemon=True).start()
+
+    def stop(self) -> None:
+        self._stop = True
+
+    def _run(self) -> None:
+        while not self._stop:
+            time.sleep(0.5)
+            if time.monotonic() - self.t > self.deadline and not self._stop:
+                msg = f"no progress for {self.deadline:.0f} s in phase '{self.phase}'"
+                print(f"[bench] rank {self.rank}: {msg}: exiting 124", file=sys.stderr, flush=True)
+                try:
+                    if self.on_expire is not None:
+                        self.on_expire(msg)
+                finally:
+                    os._exit(124)
+
+
+def sources_hash() -> str:
+    """sha256 over the attention kernel sources (csrc/attention.hip + attention.h + common.h): stored in the PMC summary by tools/pmc_bench.sh
+    and compared here, so that a kernel change that forgot to re-collect the counters shows as `traffic_stale` in the line."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("attention.hip", "attention.h", "common.h"):
+        with open(os.path.join(ROOT, "v1t_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_stale() -> bool:
+    """True when the tracked PMC summary was measured on other attention sources than the ones the LOADED library was built from
+    (v1t_amd/build.py records them next to the .so; without that record: the sources in the tree)."""
+    try:
+        from v1t_amd import lib as L
+
+        built = None
+        info = L.LIB_PATH + ".buildinfo.json"
+        if os.path.exists(info):
+            built = json.load(open(info)).get("attention_sources_sha16")
+        return json.load(open(PMC_FILE)).get("sources_sha16") != (built or sources_hash())
+    except Exception:  # noqa: BLE001
+        return True
+
+
 def dry_run(a) -> int:
     """Rendezvous check on the CPU (tests/test_bench_launch.py): gloo group over the launcher's environment, one all-reduce."""
     import torch.distributed as dist
@@ -322,15 +430,24 @@ def dry_run(a) -> int:
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if os.environ.get("V1T_BENCH_FAIL_RANK") == str(rank):  # test hook (tests/test_bench_launch.py): this rank dies before the rendezvous
         return 3
+    wd = Watchdog(rank)
+    if os.environ.get("V1T_BENCH_HANG_RANK") == str(rank):  # test hook: this rank stops making progress before the rendezvous
+        wd.mark("hung on purpose (V1T_BENCH_HANG_RANK)")
+        time.sleep(3600)
+    wd.mark("rendezvous")
     if world != a.gpus:
         print(f"--gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
     seen = torch.ones(1)
     if world > 1:
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import datetime
+
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(os.environ.get("V1T_DIST_TIMEOUT_S", "120"))))
+        wd.mark("all-reduce")
         dist.all_reduce(seen, op=dist.ReduceOp.SUM)
         dist.barrier()
         dist.destroy_process_group()
+    wd.stop()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_in_group": int(seen.item())}), flush=True)
     return 0
@@ -343,6 +460,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--neurons", type=int, default=None)
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c4", "c5"])
+    ap.add_argument("--path", default="native", choices=["native", "module", "module-fused"],
+                    help="native: the fused trainer (Trainer.train_step -> _NativeStep; the default and the headline). module: the reference's own loop "
+                         "restated over the registry modules - per mouse Model.forward, criterion, (micro/batch) * model.regularizer, .backward(), then "
+                         "torch.optim.AdamW.step() over model.get_parameters() (reference train.py:42-116, 216-223): what `train.py --core vit "
+                         "--readout gaussian2d` runs after install_into_reference(). module-fused: the same loop with the opt-in v1t_amd.FusedAdamW optimizer")
     ap.add_argument("--rollout", default="row", choices=["row", "full"], help="c5: row-vector chain (default) or the reference's full (T x T) matrix chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="roofline.traffic = null instead of reading the tracked PMC summary (used while collecting it)")
@@ -360,10 +482,40 @@ def main():
     if a.dry_run:
         raise SystemExit(dry_run(a))
 
+    state = {"line": None}  # what rank 0 knows of the line so far: printed with the failure if the run cannot finish
+
+    def fail_line(msg: str) -> None:
+        if int(os.environ.get("RANK", "0")) == 0:
+            base = state["line"] or {"metric": "training images/sec at batch 16x7 mice (V1T core vit + gaussian2d readout)", "unit": "images/s", "n_gpus": a.gpus,
+                                     "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "config": {}}
+            base = dict(base, value=None, ms_per_step=None, failed=msg)
+            base["config"] = dict(base.get("config", {}), exchange=f"failed: {msg}")
+            print(json.dumps(base), flush=True)
+
+    wd = Watchdog(int(os.environ.get("RANK", "0")), on_expire=fail_line)
+    wd.mark("process group initialisation")
+    if int(os.environ.get("RANK", "0")) == 0 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        wd.watch_sigterm()
+    try:
+        run_training(a, wd, state)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001  (an RCCL / HIP error on any rank: the line still prints, with the failure, and rc != 0)
+        import traceback
+
+        traceback.print_exc()
+        fail_line(f"{type(e).__name__}: {e}")
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)  # not sys.exit: a process group whose collective failed can hang in its destructor
+    wd.stop()
+
+
+def run_training(a, wd, state):
     import torch.distributed as dist
     import v1t_amd
     from v1t_amd import lib as L
-    from v1t_amd.dist import MouseSharding, init_from_env
+    from v1t_amd.dist import MouseSharding, describe_rank, init_from_env
     from v1t_amd.synthetic import MOUSE_IDS, default_args, make_batch, make_ds, sensorium_config
     from v1t_amd.trainer import Trainer
 
@@ -418,13 +570,22 @@ def main():
     torch.manual_seed(args.seed)  # identical initial core on every rank
     model = v1t_amd.Model(args, ds).to(dev)
     torch.manual_seed(args.seed + 7919 * (rank + 1))  # after the (identical) initialisation: per-rank draws of eps / DropPath
+    wd.mark("mouse sharding / group creation")
     sharding = MouseSharding(args.mouse_ids, rank=rank, world=world, batch_size=args.batch_size)
+    if world > 1:  # before the first collective: who runs what, where (a hung rank is identifiable from the log)
+        print(f"[bench] {describe_rank(sharding, dev)} (pid {os.getpid()}, {torch.cuda.get_device_name(dev)})", file=sys.stderr, flush=True)
     trainer = Trainer(args, model, ds, sharding=sharding)
+    if a.path != "native" and world > 1:
+        raise SystemExit("--path module is the reference's single-device loop (train.py:42-116); the data-parallel step is --path native")
     batches = {m: make_batch(args, m, neurons[m], args.batch_size, dev, seed=i) for i, m in enumerate(args.mouse_ids) if m in sharding.local_mice()}
 
     lib = L.load()
     ranks_seen, backend = 1, "none"
+    state["line"] = {"metric": metric, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "strong",
+                     "vs_baseline": None, "dtype": "bf16+fp16", "data": "synthetic",
+                     "config": {"workload": workload, "global_batch": sharding.images_per_step(), "parallelism": f"mouse-dp{world}"}}
     if world > 1:
+        wd.mark("first collective (all-reduce of ones)")
         cnt = torch.ones(1, device=dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)  # how many ranks the collective library really joined (goes into the JSON line)
         ranks_seen, backend = int(cnt.item()), str(dist.get_backend())
@@ -434,6 +595,7 @@ def main():
         core.prepare()
         core._arena.attach_grads()
         n = core._arena.param_floats
+        wd.mark("exchange self-check")
         probe = torch.arange(n, device=dev, dtype=torch.float32).remainder_(97.0).mul_(rank + 1.0)
         ref = probe.clone()
         dist.all_reduce(ref, op=dist.ReduceOp.SUM)
@@ -454,19 +616,62 @@ def main():
                     print("[bench] overlapped exchange failed its self-check: using the blocking all-reduce", file=sys.stderr, flush=True)
                 trainer.overlap = False
         core._arena.grad.zero_()
+    step_path = {"v": None}
+    if a.path == "native":
+        def one_step():
+            o = trainer.train_step(batches)
+            step_path["v"] = trainer.last_step_path
+            return o["loss"]
+    else:
+        # The reference's loop restated (train.py:42-116): per mouse Model.forward -> criterion -> (micro / batch) * model.regularizer ->
+        # backward (gradients accumulate over the mice), then optimizer.step() + zero_grad(). micro-batch = batch (on 288 GB the
+        # reference's compute_micro_batch_size reaches the batch size, utils/utils.py:431-464). The optimizer is torch.optim.AdamW over
+        # model.get_parameters(core_lr) exactly as train.py:216-223 builds it ("module"), or the opt-in fused optimizer with the same
+        # interface over the flat arenas ("module-fused", v1t_amd.FusedAdamW.for_model).
+        from v1t_amd.losses import PoissonLoss
+
+        criterion = PoissonLoss(args, ds)
+        core_lr = args.lr if getattr(args, "core_lr", None) is None else args.core_lr
+        if a.path == "module":
+            optimizer = torch.optim.AdamW(params=model.get_parameters(core_lr=core_lr), lr=args.lr, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_eps, weight_decay=0)
+        else:
+            optimizer = v1t_amd.FusedAdamW.for_model(model, lr=args.lr, core_lr=core_lr, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_eps)
+        model.train(True)
+        optimizer.zero_grad()
+        step_path["v"] = "per-mouse"
+
+        def one_step():
+            total = None
+            for m in args.mouse_ids:
+                b = batches[m]
+                bs = b["image"].size(0)
+                y_pred, _, _ = model(inputs=b["image"], mouse_id=m, behaviors=b["behavior"], pupil_centers=b["pupil_center"])
+                loss = criterion(y_true=b["response"], y_pred=y_pred, mouse_id=m, batch_size=bs)
+                reg = (b["response"].size(0) / bs) * model.regularizer(m)
+                tl = loss + reg
+                tl.backward()
+                total = loss.detach() if total is None else total + loss.detach()
+            optimizer.step()
+            optimizer.zero_grad()
+            return total
+
+    wd.mark("warm-up steps")
     for _ in range(a.warmup):
-        trainer.train_step(batches)
+        one_step()
+        wd.mark("warm-up steps")
     torch.cuda.synchronize()
-    n_local_launches = 16 * a.steps * len(sharding.local_units()) * args.num_blocks  # up to 15 windows + margin
+    units_per_step = len(sharding.local_units())
+    n_local_launches = 16 * a.steps * max(units_per_step, 1) * args.num_blocks  # up to 15 windows + margin (per-mouse launches on the module path)
     L.check(lib.v1t_profile_enable(a.profile_class, n_local_launches + 8))
     def window():
         """EXACTLY a.steps steps between barrier + synchronize on both sides; the maximum over ranks."""
+        wd.mark("timed window")
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            o = trainer.train_step(batches)
+            o = one_step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -490,7 +695,8 @@ def main():
     launches, total_ms = C.c_int(), C.c_double()
     L.check(lib.v1t_profile_read(C.byref(launches), C.byref(total_ms)))
     L.check(lib.v1t_profile_enable(-1, 0))
-    loss = float(out["loss"])
+    loss = float(out)
+    wd.mark("measured-peak probe / report")
     # un-timed, BEHIND the timed windows (75 ms of back-to-back MFMAs in front of them would hand the first window a pre-heated chip):
     # the chip is as warm as the step left it, so the clock the probe reports is the loaded one
     peak_m = measured_peak(lib, L) if rank == 0 else None
@@ -506,6 +712,8 @@ def main():
         units = sharding.local_units()
         per_rank = sum(args.batch_size if sl is None else (sl.stop - sl.start) for _, sl in units)
         imgs_launch = min(per_rank, trainer.core_group * args.batch_size) if (trainer.batch_core and len(units) > 1) else args.batch_size
+        if step_path["v"] == "per-mouse":
+            imgs_launch = args.batch_size  # one core pass per mouse-batch
         per_launch = mult * fl["attn_fwd_per_image_block"] * imgs_launch
         DPad = (args.emb_dim + 31) // 32 * 32
         traffic = pmc_traffic(key, imgs_launch, args.num_heads, fl["T"], DPad) if (key and DPad >= 128 and not a.no_pmc) else None
@@ -526,12 +734,19 @@ def main():
             "dtype": "bf16+fp16",
             "data": "synthetic",
             "config": {"workload": workload, "global_batch": sharding.images_per_step(), "parallelism": f"mouse-dp{world}", "ranks_in_group": ranks_seen, "backend": backend,
-                       "exchange": ("bucketed async all-reduce behind per-block events" if trainer.overlap else "blocking all-reduce") if world > 1 else "none"},
+                       "exchange": ("bucketed async all-reduce behind per-block events" if trainer.overlap else "blocking all-reduce") if world > 1 else "none",
+                       # which step ran: "native" = the fused trainer's fixed C-ABI sequence over all local mice; "batched-autograd" = all local mice
+                       # through the shared core in one pass under torch autograd; "per-mouse" = the reference's loop over mice (train.py:97-111)
+                       "step_path": step_path["v"], "path": a.path,
+                       "optimizer": {"native": "v1t_amd.FusedAdamW (L1 folded in)", "module": "torch.optim.AdamW (train.py:216-223)", "module-fused": "v1t_amd.FusedAdamW.for_model (opt-in)"}[a.path]},
             "loss": loss,
             "model_tflops_per_s": round(fl["train_per_image"] * images / dt / 1e12, 2),
             "model_frac_of_bf16_peak": round(fl["train_per_image"] * images / dt / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             "roofline": {"kernel": label, "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": None if traffic is None else "measured offline: " + os.path.relpath(PMC_FILE, ROOT),
+                         # the counters were collected on the kernel sources whose hash the summary carries; True = the library loaded now was built
+                         # from other attention sources (re-run tools/pmc_bench.sh)
+                         "traffic_stale": None if traffic is None else pmc_stale(),
                          "launches": launches.value, "avg_ms": round(avg_ms, 4), "flops_per_launch": per_launch,
                          "peak_measured": peak_m["tflops"], "frac_of_measured": round(achieved / peak_m["tflops"], 4), "peak_measured_clock_ghz": peak_m["clock_ghz"],
                          "peak_measured_how": f"v1t_mfma_peak_probe: v_mfma_f32_32x32x16_bf16 back to back on all CUs, register operands, random data, "

@@ -245,6 +245,9 @@ int v1t_adamw_step(float* p, float* g, float* m, float* v, long long n, float lr
                    void* stream);
 int v1t_l1_sum(const float* p, long long n, float scale, float* out_accum, void* stream);   /* out += scale*sum|p| */
 int v1t_l1_grad(const float* p, float* g, long long n, float scale, void* stream);          /* g += scale*sign(p) */
+/* the same with the upstream gradient of the regulariser's autograd node (train.py:71: (micro / batch) * model.regularizer) read on the
+ * device: g += scale * gscale[0] * sign(p) - the backward of the L1 term without a host round trip */
+int v1t_l1_grad_dev(const float* p, float* g, long long n, float scale, const float* gscale, void* stream);
 
 /* ------------------------------------------------------------- building blocks (parity tests) */
 /* C[M][N] (bf16 or fp32) = A[M][K] . B[N][K]^T, bf16 inputs, fp32 accumulate */

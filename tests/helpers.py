@@ -70,3 +70,30 @@ def build_native_model(cfg, sd, device, dropout=None):
     r = model.load_state_dict(sd, strict=False)
     assert not r.unexpected_keys and set(r.missing_keys) <= {"image_cropper.grid", "elu1.one"}, r  # every key of the reference-shaped state dict has a home
     return model.to(device), args
+
+
+def replay_dropout_masks(core, cfg, B, seed, dev):
+    """The keep masks the kernels drew for forward seed `seed` (counter-based: `v1t_dropout_mask` evaluates the same hash the
+    forward / backward kernels evaluate), shaped for `oracle.v1t_oracle.total_loss(..., masks=...)`: exact-mask replay of the patch,
+    attention-P, projection, FC1 and FC2 dropouts (reference vit.py:125-128, 144-151, 229-232, 263)."""
+    from v1t_amd import lib as L
+
+    lib = L.load()
+    T, D, H, M = core.num_tokens, cfg.emb_dim, cfg.num_heads, cfg.mlp_dim
+
+    def mask(stream, p, rows, cols, shape, take=None):
+        m = torch.empty(rows * cols, dtype=torch.uint8, device=dev)
+        L.check(lib.v1t_dropout_mask(seed, stream, p, rows, cols, m.data_ptr(), L.stream()))
+        m = m.view(rows, cols)
+        if take is not None:
+            m = m[:, :take]
+        return m.reshape(shape).cpu()
+
+    masks = {"patch": mask(0xFFFF, cfg.p_dropout, B * T, core.padded_dim, (B, T, D), D), "attn_p": float(lib.v1t_attention_dropout_rate(cfg.t_dropout))}
+    assert abs(masks["attn_p"] - cfg.t_dropout) <= 1 / 512
+    for k in range(cfg.num_blocks):
+        masks[f"attn{k}"] = mask(8 * k + 0, cfg.t_dropout, B * H * T, T, (B, H, T, T))
+        masks[f"proj{k}"] = mask(8 * k + 1, cfg.t_dropout, B * T, core.padded_dim, (B, T, D), D)
+        masks[f"fc1{k}"] = mask(8 * k + 2, cfg.t_dropout, B * T, (M + 31) // 32 * 32, (B, T, M), M)
+        masks[f"fc2{k}"] = mask(8 * k + 3, cfg.t_dropout, B * T, core.padded_dim, (B, T, D), D)
+    return masks

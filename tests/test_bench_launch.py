@@ -48,6 +48,31 @@ def test_a_crashed_rank_ends_the_launch():
     assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
 
 
+def test_a_hung_rank_ends_the_launch():
+    # rank 1 stops making progress before the rendezvous (the launcher polled for CRASHED children only). Its own
+    # watchdog (no progress mark for V1T_BENCH_DEADLINE_S) exits 124; the launcher terminates rank 0, which sits in the rendezvous,
+    # and returns 124 - no benchmark line, long before gloo's timeout
+    import time
+
+    t0 = time.time()
+    r = _run("--gpus", "2", "--dry-run", env={"V1T_BENCH_HANG_RANK": "1", "V1T_BENCH_DEADLINE_S": "5", "V1T_DIST_TIMEOUT_S": "100"})
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert time.time() - t0 < 90
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    assert "no progress" in r.stderr and "rank 1" in r.stderr
+
+
+def test_launch_deadline_terminates_all_ranks():
+    # both the per-rank watchdogs out of the picture (long deadline): the launcher's own deadline ends a launch whose ranks all sit still
+    import time
+
+    t0 = time.time()
+    r = _run("--gpus", "2", "--dry-run", env={"V1T_BENCH_HANG_RANK": "1", "V1T_BENCH_DEADLINE_S": "600", "V1T_BENCH_LAUNCH_DEADLINE_S": "8", "V1T_DIST_TIMEOUT_S": "300"})
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert time.time() - t0 < 90
+    assert "launch deadline" in r.stderr
+
+
 import pytest  # noqa: E402
 
 
@@ -62,6 +87,8 @@ def test_bench_line_contract_on_the_gpu():
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
+    assert d["config"]["step_path"] == "native" and d["config"]["path"] == "native"  # which step ran is part of every line
+    assert d["roofline"]["traffic_stale"] in (True, False)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "images/s" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - d["config"]["global_batch"] / d["ms_per_step"] * 1e3) <= 1e-3 * d["value"]

@@ -1,8 +1,8 @@
-# usage (GPU box): bash tools/pmc_bench.sh  -> gpurun_out/${RND:-r03}_pmc_attention.json + .txt: per-launch FETCH_SIZE / WRITE_SIZE (KiB) of the
+# usage (GPU box): bash tools/pmc_bench.sh  -> gpurun_out/${RND:-r05}_pmc_attention.json + .txt: per-launch FETCH_SIZE / WRITE_SIZE (KiB) of the
 # attention kernels inside bench.py (112-image training launches, dropout on) and inside the C5 eval pass (256-image launches),
 # separate --pmc passes as MI355X_MICROARCH.md prescribes; FETCH_SIZE needs x2 on gfx950 (applied by bench.py, not here).
-# Copy the two files to profiles/ (tracked) - bench.py reads profiles/${RND:-r03}_pmc_attention.json at run time.
-export RND=${RND:-r03}
+# Copy the two files to profiles/ (tracked) - bench.py reads profiles/${RND:-r05}_pmc_attention.json at run time.
+export RND=${RND:-r05}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcb_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-pmc > /tmp/pmcb_$C.log 2>&1
@@ -10,7 +10,11 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python3 - <<'PY'
 import csv, glob, json, os, collections
-out = {"shape": {"H": 4, "T": 1654, "DP": 160}, "kernels": {}, "source": "tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB per launch, mean over launches"}
+import hashlib
+_h = hashlib.sha256()
+for _f in ("attention.hip", "attention.h", "common.h"):  # the same hash bench.py computes (sources_hash): a later kernel change shows as traffic_stale
+    _h.update(open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "v1t_amd", "csrc", _f), "rb").read())
+out = {"shape": {"H": 4, "T": 1654, "DP": 160}, "sources_sha16": _h.hexdigest()[:16], "kernels": {}, "source": "tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB per launch, mean over launches"}
 names = {"attn_bwd_dkv2_kernel": "attn_bwd_dkv2", "attn_bwd_dq2_kernel": "attn_bwd_dq2", "attn_fwd_kernel": "attn_fwd", "attn_fwd2_kernel": "attn_fwd", "attn_delta2_kernel": "attn_delta2"}
 lines = []
 for tag, images, suffix in (("pmcb", 112, ""), ("pmce", 256, "_eval")):

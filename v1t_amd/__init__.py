@@ -4,9 +4,10 @@ from .core import Core, ViTCore, get_core, register as register_core  # noqa: F4
 from .cct import CCTCore  # noqa: F401  (importing it fills the "cct" registry entry, as core/__init__.py:1 does in the reference)
 from .readout import Gaussian2DReadout, Readout, Readouts, register as register_readout  # noqa: F401
 from .model import ELU1, CoreShifter, CoreShifters, ImageCropper, Model  # noqa: F401
+from .trainer import FusedAdamW  # noqa: F401  (opt-in optimizer for the reference's own loop: FusedAdamW.for_model)
 
 __all__ = ["Core", "ViTCore", "CCTCore", "get_core", "register_core", "Gaussian2DReadout", "Readout", "Readouts", "register_readout",
-           "ELU1", "CoreShifter", "CoreShifters", "ImageCropper", "Model", "install_into_reference"]
+           "ELU1", "CoreShifter", "CoreShifters", "ImageCropper", "Model", "FusedAdamW", "install_into_reference"]
 
 
 def install_into_reference() -> bool:

@@ -68,6 +68,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
             list(ex.map(run, jobs))
     if jobs or force or _stale(lib_path, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs])
+        # what this library was built from: bench.py compares it with the sources the tracked PMC summary was measured on
+        import hashlib
+        import json
+
+        h = hashlib.sha256()
+        for f in ("attention.hip", "attention.h", "common.h"):
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+        with open(lib_path + ".buildinfo.json", "w") as fh:
+            json.dump({"attention_sources_sha16": h.hexdigest()[:16], "extra_flags": EXTRA}, fh)
     return lib_path
 
 

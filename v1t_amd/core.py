@@ -179,9 +179,10 @@ class _L1Fn(torch.autograd.Function):
     def backward(ctx, g):
         a = ctx.arena
         a.attach_grads()
-        # g is a 0-dim tensor; the usual case is exactly 1 (or B_micro/B_full) — read it on the host only if needed
-        gs = float(g) if g.numel() == 1 else 1.0
-        L.check(L.load().v1t_l1_grad(a.data.data_ptr() + 4 * ctx.start, a.grad.data_ptr() + 4 * ctx.start, ctx.n, ctx.scale * gs, L.stream()), "l1_grad")
+        # g is the 0-dim upstream gradient (1, or B_micro / B_full: train.py:71); the kernel reads it on the device - `float(g)` here was a
+        # host sync in the middle of every micro-batch's backward on the reference's own loop
+        g = g.to(torch.float32).contiguous()
+        L.check(L.load().v1t_l1_grad_dev(a.data.data_ptr() + 4 * ctx.start, a.grad.data_ptr() + 4 * ctx.start, ctx.n, ctx.scale, g.data_ptr(), L.stream()), "l1_grad")
         return None, None, None, None, None
 
 

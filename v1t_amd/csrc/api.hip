@@ -1176,6 +1176,10 @@ int v1t_adamw_step(float* p, float* g, float* m, float* v, long long n, float lr
 }
 int v1t_l1_sum(const float* p, long long n, float scale, float* out, void* stream) { return launch_l1_sum(p, n, scale, out, (hipStream_t)stream); }
 int v1t_l1_grad(const float* p, float* g, long long n, float scale, void* stream) { return launch_l1_grad(p, g, n, scale, (hipStream_t)stream); }
+int v1t_l1_grad_dev(const float* p, float* g, long long n, float scale, const float* gscale, void* stream) {
+    if (!gscale) return V1T_ERR_ARG;
+    return launch_l1_grad_dev(p, g, n, scale, gscale, (hipStream_t)stream);
+}
 
 int v1t_gemm_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C, int ldc, int out_f32, void* stream) {
     GemmNTArgs g{};

@@ -150,6 +150,7 @@ struct AdamArgs {
 int launch_adamw(const AdamArgs& a, hipStream_t s);
 int launch_l1_sum(const float* p, long long n, float scale, float* out_accum, hipStream_t s);
 int launch_l1_grad(const float* p, float* g, long long n, float scale, hipStream_t s);
+int launch_l1_grad_dev(const float* p, float* g, long long n, float scale, const float* gscale, hipStream_t s);
 
 struct LossArgs {
     const float* u;      // [B][N] readout pre-activation

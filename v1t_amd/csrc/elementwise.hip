@@ -794,6 +794,15 @@ __global__ void l1_grad_kernel(const float* __restrict__ p, float* g, long long 
     }
 }
 
+// the same with the upstream gradient read on the device (an autograd node's grad_output: no host round trip in the backward)
+__global__ void l1_grad_dev_kernel(const float* __restrict__ p, float* g, long long n, float scale, const float* __restrict__ gscale) {
+    const float sc = scale * gscale[0];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = p[i];
+        g[i] += sc * ((x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f));
+    }
+}
+
 // ELU1 (models/utils.py:109-118) + Poisson loss (losses.py:153-166) forward and dLoss/du.
 DEVFN void elu1_poisson_body(const LossArgs& a, int bx, int nbx, float (&sred)[4]) {
     const float eps = 1.1920928955078125e-07f;
@@ -1075,6 +1084,11 @@ int launch_l1_sum(const float* p, long long n, float scale, float* out, hipStrea
 int launch_l1_grad(const float* p, float* g, long long n, float scale, hipStream_t s) {
     if (n <= 0) return V1T_OK;
     hipLaunchKernelGGL(l1_grad_kernel, dim3(nblocks(n, 4096)), dim3(256), 0, s, p, g, n, scale);
+    return ok();
+}
+int launch_l1_grad_dev(const float* p, float* g, long long n, float scale, const float* gscale, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(l1_grad_dev_kernel, dim3(nblocks(n, 4096)), dim3(256), 0, s, p, g, n, scale, gscale);
     return ok();
 }
 int launch_adamw_multi(const AdamArgs* a, int n, hipStream_t s) {

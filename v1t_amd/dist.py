@@ -192,8 +192,21 @@ class MouseSharding:
                 a.step = int(st.item())
 
 
-def init_from_env(backend: t.Optional[str] = None) -> t.Tuple[int, int, int]:
-    """(rank, local_rank, world) from torchrun's environment; initialises the process group when world > 1."""
+def describe_rank(sharding: "MouseSharding", device: t.Any) -> str:
+    """`rank r / world -> device -> mice / slices`: one line a rank logs to stderr BEFORE its first collective, so that a hung or
+    mis-placed rank of a run nobody can rehearse (VERDICT r04 #6) is identifiable from the log alone."""
+    units = ", ".join(m if sl is None else f"{m}[{sl.start}:{sl.stop}]" for m, sl in sharding.local_units())
+    shared = ", ".join(f"{m}<->{sharding.owners[m]}" for m in sharding.shared_mice())
+    return f"rank {sharding.rank}/{sharding.world} -> {device} -> {units or 'no units'}" + (f"; shared mice {shared}" if shared else "")
+
+
+def init_from_env(backend: t.Optional[str] = None, timeout_s: t.Optional[float] = None) -> t.Tuple[int, int, int]:
+    """(rank, local_rank, world) from torchrun's environment; initialises the process group when world > 1.
+
+    `timeout_s` (default: V1T_DIST_TIMEOUT_S or 120 s) bounds the rendezvous and every collective: the library default (10 min for
+    RCCL, 30 min for gloo) would let one hung rank burn a whole benchmark budget before anything fails."""
+    import datetime
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -204,5 +217,7 @@ def init_from_env(backend: t.Optional[str] = None) -> t.Tuple[int, int, int]:
             backend = os.environ.get("V1T_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("V1T_DIST_TIMEOUT_S", "120"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     return rank, local, world

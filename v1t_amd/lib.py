@@ -108,6 +108,7 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
     "v1t_l1_sum": (c_int, [c_void_p, c_ll, c_float, c_void_p, c_void_p]),
     "v1t_l1_grad": (c_int, [c_void_p, c_void_p, c_ll, c_float, c_void_p]),
+    "v1t_l1_grad_dev": (c_int, [c_void_p, c_void_p, c_ll, c_float, c_void_p, c_void_p]),
     "v1t_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "v1t_gemm_tn": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "v1t_gemm_tn_slab_bytes": (c_ll, [c_int, c_int, c_int, c_int]),

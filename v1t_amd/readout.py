@@ -303,6 +303,8 @@ class Gaussian2DReadout(Readout):
         L.require_cuda(inputs, "Gaussian2DReadout.forward")
         B, c, h, w = inputs.shape
         n = self.num_neurons
+        if torch.is_grad_enabled():
+            self._visited = True  # FusedAdamW.step (opt-in optimizer of the reference's own loop) steps the mice seen since its last step
         grid = self._grid(B, sample, eps, shifts)
         tokens = getattr(inputs, "_v1t_tokens", None)
         if tokens is not None and tokens.shape[0] == B:
