@@ -15,7 +15,9 @@
  * v1t_vit_backward(_events) additionally owns one internal stream per plan (created by its first small launch, destroyed with the plan) on which
  * the weight-gradient GEMMs of launches below 65 536 rows run, joined to `stream` by events before the call returns its last launch.
  * Return value 0 = ok, negative = error code below (the Python shim raises RuntimeError, which the reference's OOM probe utils/utils.py:460
- * relies on). Thread-safe for distinct handles / distinct streams.
+ * relies on). Thread-safe for distinct handles; calls on ONE handle must be serialised by the caller (the plan owns the second stream and
+ * the events of its backward, created on first use on the device that is current then: two backward calls on the same plan from two threads
+ * or two streams would race on them).
  */
 #ifndef V1T_AMD_H
 #define V1T_AMD_H
@@ -288,6 +290,11 @@ int v1t_attention_backward_ws(const void* qkv, const void* o, const void* dO, co
 int v1t_rollout_headmax(const void* qkv, const float* lse2, int B, int H, int T, int DP,
                         const float* scale, int scale_per_head, int mask_diag, float* A, int TP,
                         float* rowsum, void* stream);
+/* The same for the first q_rows query rows only (whole 128-row workgroups: rows beyond the last one of them are not written): the row
+ * chain starts from v = e_0, so its first step (the LAST block, attention_rollout.py:113-118) reads row 0 of that block's matrix alone. */
+int v1t_rollout_headmax_rows(const void* qkv, const float* lse2, int B, int H, int T, int DP,
+                             const float* scale, int scale_per_head, int mask_diag, float* A, int TP,
+                             float* rowsum, int q_rows, void* stream);
 /* Per-head softmax probabilities of one block, P (B, H, T, TP) fp32 (pad columns zero): what the reference's Recorder hooks
  * capture from every block's `attend` module (attention_rollout.py:31-36, stacked to (B, L, H, T, T) at :76), recomputed from
  * the saved qkv and log2-sum-exp like v1t_rollout_headmax. 43.8 MB per image and block at the default size: for a bounded

@@ -59,7 +59,8 @@ def test_a_hung_rank_ends_the_launch():
     assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
     assert time.time() - t0 < 90
     assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
-    assert "no progress" in r.stderr and "rank 1" in r.stderr
+    # (whichever watchdog fires first ends the launch: the hung rank's, or rank 0's, which waits for it in the rendezvous)
+    assert "no progress" in r.stderr and ("rank 1" in r.stderr or "rank 0" in r.stderr)
 
 
 def test_launch_deadline_terminates_all_ranks():

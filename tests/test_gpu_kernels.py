@@ -115,9 +115,9 @@ def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
     gq, d = gq.view(B * T, 3, H * DP), dqkv.float().view(B * T, 3, H * DP)
     for i, nm in enumerate("qkv"):
         if float(gq[:, i].abs().max()) > 0:
-            check_rel(f"test_attention_forward_backward:" + str(nm), d[:, i].cpu(), gq[:, i].cpu(), 2e-2)  # bf16 P / dS / outputs
+            check_rel(f"test_attention_forward_backward:" + str(nm), d[:, i].cpu(), gq[:, i].cpu(), 1.2e-2)  # bf16 P / dS / outputs (worst measured 7.8e-3, GPUTEST r05)
     if lsa and T > 1:  # the scale is a learnable parameter only with LSA (vit.py:235-239)
-        check_rel("test_attention_forward_backward:6", dscale.cpu(), gs.cpu(), 2e-2)
+        check_rel("test_attention_forward_backward:6", dscale.cpu(), gs.cpu(), 1.2e-2)
     if not lsa:
         # materialised-dS' path (producer / consumer dK/dV kernel writes dS', dQ = dS' . K as a GEMM): same bf16 products as
         # the recompute path, summed in another order
@@ -131,7 +131,7 @@ def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
         e = d2.float().view(B * T, 3, H * DP)
         for i, nm in enumerate("qkv"):
             if float(gq[:, i].abs().max()) > 0:
-                check_rel(f"test_attention_forward_backward:" + str(nm), e[:, i].cpu(), gq[:, i].cpu(), 2e-2)
+                check_rel(f"test_attention_forward_backward:" + str(nm), e[:, i].cpu(), gq[:, i].cpu(), 1.2e-2)
                 check_rel(f"test_attention_forward_backward:" + str(nm), e[:, i].cpu(), d[:, i].cpu(), 1e-2)
 
 
@@ -637,8 +637,8 @@ def test_attention_random_shapes(ctx):
                 if float(r.abs().max()) == 0.0:
                     continue
                 e = rel_to_max(dd[j].cpu(), r.cpu())
-                worst = max(worst, e / 2e-2)
-                assert e < 2e-2, f"{tag}: {nm} d{c} {e:.3e}"
+                worst = max(worst, e / 1.2e-2)
+                assert e < 1.2e-2, f"{tag}: {nm} d{c} {e:.3e}"
     from tests.helpers import record_margin
 
     record_margin("test_attention_random_shapes: worst error / bound over 34 shapes", worst, 1.0)

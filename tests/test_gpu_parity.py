@@ -12,7 +12,7 @@ import torch
 
 from oracle import v1t_oracle as O
 from oracle import weights as W
-from tests.helpers import assert_close, build_native_model, check_rel, record_margin, rel_to_max, sample
+from tests.helpers import assert_close, build_native_model, check_rel, check_rel_bulk, record_margin, rel_to_max, sample
 
 pytestmark = pytest.mark.gpu
 Y_RTOL, Y_ATOL = 1e-3, 1e-6
@@ -603,7 +603,7 @@ def test_core_batched_over_mice_equals_per_mouse(dev, variant):
         # next GEMM's operand, ONE element of dy rounds the other way in some runs and not in others: 1.8e-5 of the tensor's max usually, 3.2e-4
         # when it happens (round 4: variant 5 failed 2 of 12 identical runs at a bound of 1e-4, with the weight-gradient stream on or off). The
         # bound is therefore a few bf16 ulps of one element, not the fp32 noise floor.
-        check_rel(f"test_core_batched_over_mice_equals_per_mouse:" + str(k), got[k], ref[k], 1e-3)
+        check_rel_bulk(f"test_core_batched_over_mice_equals_per_mouse:" + str(k), got[k], ref[k], 1e-4, 1e-3)  # bulk 1e-4, a handful of elements up to 1e-3
     model.core.behavior_mode = 4
     with pytest.raises(NotImplementedError):
         model.core.forward_many([b["image"] for _, b in pairs], [m for m, _ in pairs], [b["behavior"] for _, b in pairs], [b["pupil_center"] for _, b in pairs])
@@ -647,7 +647,7 @@ def test_native_step_equals_autograd_step(dev, variant):
     assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref)
     assert set(ref) == set(got) == {"core", "A", "B", "C"}
     for k in ref:
-        check_rel(f"test_native_step_equals_autograd_step:" + str(k), got[k], ref[k], 1e-3)  # float atomics in both paths: last bits, or one bf16 rounding flip (see test_core_batched_over_mice_equals_per_mouse)
+        check_rel_bulk(f"test_native_step_equals_autograd_step:" + str(k), got[k], ref[k], 1e-4, 1e-3)  # float atomics in both paths: last bits, or one bf16 rounding flip (see test_core_batched_over_mice_equals_per_mouse)
 
 
 def test_native_step_losses_do_not_alias_and_fallback_warns(dev):

@@ -186,6 +186,83 @@ class _L1Fn(torch.autograd.Function):
         return None, None, None, None, None
 
 
+def cached_scalar(buf: torch.Tensor) -> float:
+    """float(buf) for a 0-dim device buffer (the modules' `reg_scale`), read from the device ONCE per value: `float(tensor)` is a host
+    sync, and one in `regularizer()` stalls the reference's loop behind every mouse's forward (round 5: the per-mouse path then enqueued
+    its loss / regulariser kernels into an empty queue, 1.3 ms of exposed launch latency per mouse). Keyed on the buffer's storage and
+    version counter, so `load_state_dict`, `.to()` or an in-place change re-reads it."""
+    key = (buf.data_ptr(), buf._version, buf.device)
+    c = buf.__dict__.get("_v1t_scalar")
+    if c is None or c[0] != key:
+        c = (key, float(buf))
+        buf.__dict__["_v1t_scalar"] = c
+    return c[1]
+
+
+def _runs(tensors: t.Sequence[torch.Tensor]) -> t.List[t.Tuple[int, int, t.List[int]]]:
+    """(first data_ptr, floats, indices) of maximal runs of fp32 tensors that sit back to back in memory (the flat arenas)."""
+    order = sorted(range(len(tensors)), key=lambda i: tensors[i].data_ptr())
+    runs: t.List[t.Tuple[int, int, t.List[int]]] = []
+    for i in order:
+        x = tensors[i]
+        if runs and runs[-1][0] + 4 * runs[-1][1] == x.data_ptr():
+            runs[-1] = (runs[-1][0], runs[-1][1] + x.numel(), runs[-1][2] + [i])
+        else:
+            runs.append((x.data_ptr(), x.numel(), [i]))
+    return runs
+
+
+class _L1ParamsFn(torch.autograd.Function):
+    """scale * sum_p sum|p| over a list of dense fp32 GPU parameters (core_shifter.py:36-37, image_cropper.py:38-39): one `v1t_l1_sum`
+    launch per run of parameters that are contiguous in memory (one, when they live in a mouse arena) instead of abs / sum / add per
+    parameter; the backward adds scale * g * sign(p) straight into the attached gradient views (`v1t_l1_grad_dev`, g read on the device)
+    or returns the gradients where a parameter has no such view."""
+
+    @staticmethod
+    def forward(ctx, scale: float, *params):
+        out = torch.zeros((), dtype=torch.float32, device=params[0].device)
+        runs = _runs(params)
+        lib = L.load()
+        for ptr, n, _ in runs:
+            L.check(lib.v1t_l1_sum(ptr, n, scale, out.data_ptr(), L.stream()), "l1_sum")
+        ctx.params, ctx.scale, ctx.runs = params, scale, runs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        params, lib = ctx.params, L.load()
+        g = g.to(torch.float32).contiguous()
+        grads: t.List[t.Optional[torch.Tensor]] = [None] * len(params)
+        for ptr, n, idx in ctx.runs:
+            sinks = [L.grad_sink(params[i]) for i in idx]
+            if all(r is None for _, r in sinks) and [x[0] for x in _runs([s_ for s_, _ in sinks])] == [sinks[0][0].data_ptr()]:
+                L.check(lib.v1t_l1_grad_dev(ptr, sinks[0][0].data_ptr(), n, ctx.scale, g.data_ptr(), L.stream()), "l1_grad")  # the whole run in one launch
+                continue
+            for i, (sink, ret) in zip(idx, sinks):
+                L.check(lib.v1t_l1_grad_dev(params[i].data_ptr(), sink.data_ptr(), params[i].numel(), ctx.scale, g.data_ptr(), L.stream()), "l1_grad")
+                grads[i] = ret
+        return (None, *grads)
+
+
+def l1_of_parameters(module: nn.Module, reg_scale: torch.Tensor):
+    """`reg_scale * sum(p.abs().sum() for p in module.parameters())` (the reference's shifter regularisers). GPU: fused (above), and
+    exactly 0.0 without a launch when the scale is zero (the reference's default `shifter_reg_scale` / `cropper_reg_scale`: the term
+    and its gradient are 0 * ...)."""
+    ps = [p for p in module.parameters()]
+    if not ps or not ps[0].is_cuda or any(p.dtype != torch.float32 or not p.is_contiguous() for p in ps):
+        total = 0
+        for p in ps:
+            total = total + p.abs().sum()
+        return reg_scale * total
+    scale = cached_scalar(reg_scale)
+    if scale == 0.0:
+        return 0.0
+    if not any(p.requires_grad for p in ps) or not torch.is_grad_enabled():
+        with torch.no_grad():
+            return _L1ParamsFn.apply(scale, *ps)
+    return _L1ParamsFn.apply(scale, *ps)
+
+
 def _seq(*mods: nn.Module) -> nn.Sequential:
     return nn.Sequential(*mods)
 
@@ -419,7 +496,7 @@ class ViTCore(Core):
         """L1 over ALL core parameters (vit.py:419-421), computed by a HIP reduction over the arena."""
         self.prepare()
         a = self._arena
-        return _L1Fn.apply(a, 0, a.param_floats, float(self.reg_scale), self._anchor)
+        return _L1Fn.apply(a, 0, a.param_floats, cached_scalar(self.reg_scale), self._anchor)
 
     def forward_tokens(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor,
                        keep_workspace: bool = False) -> torch.Tensor:

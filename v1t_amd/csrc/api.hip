@@ -169,7 +169,7 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
 // so it is the default. V1T_ATTN_BWD_DS=0 (dev) selects the fused recompute kernel, which LSA (mask_diag) always uses.
 static const int g_attn_ds = (std::getenv("V1T_ATTN_BWD_DS") && !atoi(std::getenv("V1T_ATTN_BWD_DS"))) ? 0 : 1;
 struct ScratchLayout {
-    long long G, dy, dhpre, dz, dO, delta, dqkv, dbeta, slab, pu, pgd, pdu, ds, total;
+    long long G, dy, dy2, dhpre, dz, dO, delta, dqkv, dbeta, slab, pu, pgd, pdu, ds, total;
 };
 // contraction rows per workgroup of the weight-gradient GEMMs: aim at >= ~512 workgroups
 int tn_mchunk(long long R, int tiles) {
@@ -206,6 +206,13 @@ static bool x16_gelu_out(const v1t_vit* h, long long R) {
     return !g_keep_bf16 && g_fwd_f16 && !(g_nosplit & 8) && gemm_tn_takes_f16_x(h->DP, h->MP, tn_plan(h, R).mc_fc2);
 }
 
+// Weight-gradient GEMMs beside the dX GEMMs on a second stream (backward, below): for launches under 65 536 rows, or as V1T_DW_SIDE=0 / 1
+// forces (dev). One place decides for the scratch layout (four slab regions instead of one) and for the backward.
+static bool dw_side_for(long long R) {
+    static const int dw_force = std::getenv("V1T_DW_SIDE") ? atoi(std::getenv("V1T_DW_SIDE")) : -1;
+    return dw_force >= 0 ? dw_force > 0 : R < 65536;
+}
+
 ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     ScratchLayout s;
     const long long R = (long long)B * h->T;
@@ -217,13 +224,15 @@ ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     };
     s.G = take(R * h->DP * 4);
     s.dy = take(R * h->DP * 2);
+    s.dy2 = take(R * h->DP * 2);  // the two residual branches' output gradients alternate between dy and dy2 (backward, below)
     s.dhpre = take(R * h->MP * 2);
     s.dz = take(R * h->DP * 4);
     s.dO = take(R * h->HDP * 2);
     s.delta = take((long long)B * h->H * h->T * 4);
     s.dqkv = take(R * 3 * h->HDP * 2);
     s.dbeta = take((long long)h->NB * B * h->DP * 4);
-    s.slab = take(4 * (((long long)tn_plan(h, R).slab + 255) / 256 * 256));  // one region per weight-gradient GEMM of a block (they may run beside the dX GEMMs)
+    // one region per weight-gradient GEMM of a block where they run beside the dX GEMMs (second stream), else one region they share in turn
+    s.slab = take((dw_side_for(R) ? 4 : 1) * (((long long)tn_plan(h, R).slab + 255) / 256 * 256));
     const long long RU = (long long)B * h->RCI;
     s.pu = take(h->s_pw >= 0 ? RU * h->PDX * 2 : 0);
     s.pgd = take(h->s_pw >= 0 ? RU * h->DP * 2 : 0);
@@ -685,15 +694,20 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
     }
 
     if (h->inject)
-        for (int k = 0; k < h->NB; ++k) {
-            const BmlpOff& bo = h->blk[k].bmlp[bm];
-            BmlpArgs ba{};
-            ba.v = behaviors; ba.B = B; ba.IN = h->IN; ba.J = h->J; ba.D = D; ba.DP = DP;
-            ba.W1 = arena + bo.w1; ba.b1 = bo.b1 >= 0 ? arena + bo.b1 : nullptr;
-            ba.W3 = arena + bo.w3; ba.b3 = bo.b3 >= 0 ? arena + bo.b3 : nullptr;
-            ba.hid = (float*)(ws + w.hid) + (size_t)k * B * h->J;
-            ba.out = (float*)(ws + w.beta) + (size_t)k * B * DP;
-            CHECK(launch_bmlp_fwd(ba, s));
+        for (int k0 = 0; k0 < h->NB; k0 += BMLP_MAX_BLOCKS) {  // every block's BehaviorMLP in one launch
+            BmlpBatch bb{};
+            bb.n = std::min(BMLP_MAX_BLOCKS, h->NB - k0);
+            for (int i = 0; i < bb.n; ++i) {
+                const int k = k0 + i;
+                const BmlpOff& bo = h->blk[k].bmlp[bm];
+                BmlpArgs& ba = bb.blk[i];
+                ba.v = behaviors; ba.B = B; ba.IN = h->IN; ba.J = h->J; ba.D = D; ba.DP = DP;
+                ba.W1 = arena + bo.w1; ba.b1 = bo.b1 >= 0 ? arena + bo.b1 : nullptr;
+                ba.W3 = arena + bo.w3; ba.b3 = bo.b3 >= 0 ? arena + bo.b3 : nullptr;
+                ba.hid = (float*)(ws + w.hid) + (size_t)k * B * h->J;
+                ba.out = (float*)(ws + w.beta) + (size_t)k * B * DP;
+            }
+            CHECK(launch_bmlp_fwd_multi(bb, s));
         }
 
     const bool x16o = x16_attn_out(h, R), x16a = x16_gelu_out(h, R);  // only the fp16 planes of o / gelu(h) are written
@@ -803,7 +817,12 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
     if (bm < 0 || bm >= h->nbmlp) return V1T_ERR_ARG;
 
     float* G = (float*)(sc + sl.G);
+    // dy: gradient of a block's FC2 output (the MLP branch), dyp: gradient of its projection output (the attention branch). Two buffers, so
+    // that the kernel that writes the one (LN2 backward -> dyp, LN1 backward -> dy of the block before) never has to wait for the weight-
+    // gradient GEMM that still reads the other on the second stream: with ONE buffer the main stream idled 25-36 us per block in front of
+    // the LN2 backward at a rank's share of an 8-GPU step (join of dW2, launched three short kernels earlier)
     bf16_t* dy = (bf16_t*)(sc + sl.dy);
+    bf16_t* dyp = (bf16_t*)(sc + sl.dy2);
     bf16_t* dhpre = (bf16_t*)(sc + sl.dhpre);
     float* dz = (float*)(sc + sl.dz);
     bf16_t* dO = (bf16_t*)(sc + sl.dO);
@@ -818,16 +837,21 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
     // two would fight for HBM (a side-stream experiment with the slab reductions alone lost 0.4 %, profiles/r04_gemm_experiments.txt); at a
     // rank's share of a multi-GPU step (23 k rows: ~182 workgroups per launch on 256 CUs, latency-bound) the second stream fills idle CUs.
     // V1T_DW_SIDE=0 / 1 forces it off / on (dev).
-    static const int dw_force = std::getenv("V1T_DW_SIDE") ? atoi(std::getenv("V1T_DW_SIDE")) : -1;
-    const bool dw_side = slab && (dw_force >= 0 ? dw_force > 0 : R < 65536);
+    const bool dw_side = slab && dw_side_for(R);
     if (dw_side && !h->dw_stream) {
-        if (hipStreamCreateWithFlags(&h->dw_stream, hipStreamNonBlocking) != hipSuccess) return V1T_ERR_LAUNCH;
+        // V1T_DW_PRIO=low (dev, A/B): the second stream at the lowest queue priority, so that its workgroups only take CUs the main stream's
+        // kernels leave idle
+        static const bool dw_low = std::getenv("V1T_DW_PRIO") && std::string(std::getenv("V1T_DW_PRIO")) == "low";
+        int lo = 0, hi = 0;
+        if (dw_low && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) {
+            if (hipStreamCreateWithPriority(&h->dw_stream, hipStreamNonBlocking, lo) != hipSuccess) return V1T_ERR_LAUNCH;
+        } else if (hipStreamCreateWithFlags(&h->dw_stream, hipStreamNonBlocking) != hipSuccess) return V1T_ERR_LAUNCH;
         for (int i = 0; i < 4; ++i)
             if (hipEventCreateWithFlags(&h->dw_ready[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->dw_done[i], hipEventDisableTiming) != hipSuccess) return V1T_ERR_LAUNCH;
     }
     // GEMM j of a block (0 dW2, 1 dW1, 2 dWo, 3 dWqkv): on the second stream behind everything enqueued on `s` so far; join_dw(j) makes `s` wait for it
     auto launch_dw = [&](GemmTNArgs& t, int j) -> int {
-        t.slab = slab ? slab + (size_t)j * slab_stride : nullptr;
+        t.slab = slab ? slab + (dw_side ? (size_t)j * slab_stride : 0) : nullptr;
         if (!dw_side) return launch_gemm_tn(t, s);
         if (hipEventRecord(h->dw_ready[j], s) != hipSuccess || hipStreamWaitEvent(h->dw_stream, h->dw_ready[j], 0) != hipSuccess) return V1T_ERR_LAUNCH;
         const int rc = launch_gemm_tn(t, h->dw_stream);
@@ -835,9 +859,18 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         return hipEventRecord(h->dw_done[j], h->dw_stream) == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
     };
     bool dw_pending[4] = {false, false, false, false};
+    int join_err = V1T_OK;
     auto join_dw = [&](int j) {
-        if (dw_side && dw_pending[j]) { (void)hipStreamWaitEvent(s, h->dw_done[j], 0); dw_pending[j] = false; }
+        if (dw_side && dw_pending[j]) {
+            if (hipStreamWaitEvent(s, h->dw_done[j], 0) != hipSuccess) join_err = V1T_ERR_LAUNCH;
+            dw_pending[j] = false;
+        }
     };
+    // a failed launch in mid-block must not leave second-stream work un-joined behind `s` (the caller may free or reuse the scratch)
+    struct DwGuard {
+        decltype(join_dw)& join;
+        ~DwGuard() { for (int j = 0; j < 4; ++j) join(j); }
+    } dw_guard{join_dw};
     const bool x16o = x16_attn_out(h, R), x16a = x16_gelu_out(h, R);  // the forward left only the fp16 planes of o / gelu(h)
 
     const float* gin = gout;
@@ -886,7 +919,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         t.m_chunk = tp.mc_fc1;
         CHECK(launch_dw(t, 1));  // reads dhpre, z2
         dw_pending[1] = true;
-        join_dw(0);              // dW2 reads dy, which the LayerNorm backward below overwrites (dy_next)
+        join_dw(2);              // the previous block's dWo read dyp, which the LayerNorm backward below overwrites (dy_next)
         // dz2 = d_hpre . W1
         g = GemmNTArgs{};
         g.A = dhpre; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc1_t); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = dz; g.ldc = DP;
@@ -894,7 +927,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         LnBwdArgs lb{};
         lb.dz = dz; lb.x = xm; lb.mean = (const float*)(wb + w.mean2); lb.rstd = (const float*)(wb + w.rstd2); lb.gamma = arena + b.ln2w;
         lb.gin = gin; lb.gout = G; lb.dgamma = grads + b.ln2w; lb.dbeta = grads + b.ln2b; lb.dinject = nullptr;
-        lb.dy_next = dy; lb.dbias_next = b.projb >= 0 ? grads + b.projb : nullptr;
+        lb.dy_next = dyp; lb.dbias_next = b.projb >= 0 ? grads + b.projb : nullptr;
         lb.drop_next = make_drop(train, h->c.t_dropout, seed, 8 * k + 1);
         lb.scale_next = path_scale ? path_scale + (size_t)(2 * k + 0) * B : nullptr;
         lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
@@ -903,15 +936,15 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
 
         // ---- attention branch: dWo += dy^T o
         t = GemmTNArgs{};
-        t.Y = dy; t.ldy = DP; t.X = x16o ? (const bf16_t*)(wb + w.o_lo) : o; t.x_f16 = x16o; t.ldx = HDP; t.M = R; t.NY = DP; t.NX = HDP; t.dW = grads + b.proj; t.ldw = h->HD;
+        t.Y = dyp; t.ldy = DP; t.X = x16o ? (const bf16_t*)(wb + w.o_lo) : o; t.x_f16 = x16o; t.ldx = HDP; t.M = R; t.NY = DP; t.NX = HDP; t.dW = grads + b.proj; t.ldw = h->HD;
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->HEP; t.xseg_valid = h->HE; t.alpha = 1.f;
         t.m_chunk = tp.mc_proj;
-        CHECK(launch_dw(t, 2));  // reads dy, o
+        CHECK(launch_dw(t, 2));  // reads dyp, o
         dw_pending[2] = true;
         join_dw(3);              // the previous block's dWqkv read dqkv, which this block's attention backward overwrites
         // dO = dy . Wo
         g = GemmNTArgs{};
-        g.A = dy; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_proj_t); g.ldb = DP; g.M = R; g.N = HDP; g.K = DP; g.C = dO; g.ldc = HDP;
+        g.A = dyp; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_proj_t); g.ldb = DP; g.M = R; g.N = HDP; g.K = DP; g.C = dO; g.ldc = HDP;
         AttnArgs at{};
         at.qkv = qkv; at.ldqkv = 3 * HDP; at.o = x16o ? (bf16_t*)(wb + w.o_lo) : (bf16_t*)o; at.o_f16 = x16o; at.ldo = HDP; at.lse2 = (float*)(wb + w.lse2);
         at.B = B; at.H = h->H; at.T = h->T; at.scale = arena + b.scale; at.scale_per_head = h->c.use_lsa ? 1 : 0; at.mask_diag = h->c.use_lsa ? 1 : 0;
@@ -940,7 +973,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         t.m_chunk = tp.mc_qkv;
         CHECK(launch_dw(t, 3));  // reads dqkv, z1
         dw_pending[3] = true;
-        join_dw(2);              // dWo reads dy, which the LayerNorm backward below overwrites (dy_next of the block before)
+        join_dw(0);              // dW2 read dy, which the LayerNorm backward below overwrites (dy_next of the block before)
         // dz1 = dqkv . Wqkv
         g = GemmNTArgs{};
         g.A = dqkv; g.lda = 3 * HDP; g.B = (const bf16_t*)(sh + b.s_qkv_t); g.ldb = 3 * HDP; g.M = R; g.N = DP; g.K = 3 * HDP; g.C = dz; g.ldc = DP;
@@ -964,6 +997,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         }
     }
     for (int j = 0; j < 4; ++j) join_dw(j);  // everything of the second stream is behind `s` from here on (slab region 0 is reused below)
+    if (join_err) return join_err;
     // ---- patch embedding backward (gin = grad wrt x0)
     PatchArgs pa{};
     pa.img = images; pa.B = B; pa.C = h->C; pa.IH = h->IH; pa.IW = h->IW; pa.P = h->P; pa.stride = h->S; pa.NH = h->NH; pa.NW = h->NW;
@@ -1239,7 +1273,15 @@ int v1t_rollout_headmax(const void* qkv, const float* lse2, int B, int H, int T,
     AttnArgs a{};
     a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.lse2 = (float*)lse2; a.B = B; a.H = H; a.T = T;
     a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
-    return launch_rollout_headmax(a, DP, A, TP, rowsum, (hipStream_t)stream);
+    return launch_rollout_headmax(a, DP, A, TP, rowsum, 0, (hipStream_t)stream);
+}
+int v1t_rollout_headmax_rows(const void* qkv, const float* lse2, int B, int H, int T, int DP, const float* scale, int scale_per_head,
+                             int mask_diag, float* A, int TP, float* rowsum, int q_rows, void* stream) {
+    if (!qkv || !lse2 || !scale || !A || !rowsum || TP < T || TP % 4 || q_rows <= 0) return V1T_ERR_ARG;
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.lse2 = (float*)lse2; a.B = B; a.H = H; a.T = T;
+    a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
+    return launch_rollout_headmax(a, DP, A, TP, rowsum, q_rows, (hipStream_t)stream);
 }
 int v1t_attention_probs(const void* qkv, const float* lse2, int B, int H, int T, int DP, const float* scale, int scale_per_head,
                         int mask_diag, float* P, int TP, void* stream) {
@@ -1247,7 +1289,7 @@ int v1t_attention_probs(const void* qkv, const float* lse2, int B, int H, int T,
     AttnArgs a{};
     a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.lse2 = (float*)lse2; a.B = B; a.H = H; a.T = T;
     a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
-    return launch_rollout_headmax(a, DP, P, TP, nullptr, (hipStream_t)stream);
+    return launch_rollout_headmax(a, DP, P, TP, nullptr, 0, (hipStream_t)stream);
 }
 int v1t_rollout_matmul(const float* A, const float* rowsum, const float* Xin, float* Xout, int B, int T, int TP, void* stream) {
     if (!A || !rowsum || !Xout || Xout == Xin || B <= 0 || T <= 0) return V1T_ERR_ARG;

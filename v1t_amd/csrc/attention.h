@@ -46,6 +46,6 @@ int launch_attn_rc_pad(const AttnArgs& a, hipStream_t s);
 int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s);  // dq + dkv kernels
 
 // attention rollout building blocks (reference utils/attention_rollout.py:92-122)
-int launch_rollout_headmax(const AttnArgs& a, int DP, float* A, int TP, float* rowsum, hipStream_t s);
+int launch_rollout_headmax(const AttnArgs& a, int DP, float* A, int TP, float* rowsum, int q_rows, hipStream_t s);  // q_rows > 0: the first q_rows query rows only
 int launch_rollout_vecmat(const float* A, const float* rowsum, const float* v, float* u, int B, int T, int TP, hipStream_t s);
 int launch_rollout_matmul(const float* A, const float* rowsum, const float* Xin, float* Xout, int B, int T, int TP, hipStream_t s);

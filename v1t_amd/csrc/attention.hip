@@ -2026,6 +2026,12 @@ template <int DP, int HH, bool PH = false>
 __global__ __launch_bounds__(256, 1) void rollout_headmax_kernel(AttnArgs a, float* A, int TP, float* rowsum) {
     using G = Geo<DP>;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][HH][TileDma<DP, G::RSTR>::LDS_ELEMS];
+    // head-max tile of a wave (32 queries x 32 keys fp32) on its way out: a lane holds 16 keys of ONE query (4 x 16 B at a row stride of TP
+    // floats), so stored from the registers an instruction scatters 64 16-B pieces over 32 rows - partial lines for the 2.8 GB this kernel
+    // writes per 256-image launch. Staged through a wave-private block instead (row stride 36 floats: conflict-free 16-B writes and reads)
+    // and written as 8 lanes x 16 B = one 128-B row segment per query row (round 5)
+    constexpr int HS = 36;
+    __shared__ __attribute__((aligned(16))) float sOut[PH ? 1 : 4][PH ? 4 : 32 * HS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
     const int q = blockIdx.x * 128 + 32 * wave + (lane & 31);
@@ -2096,18 +2102,29 @@ __global__ __launch_bounds__(256, 1) void rollout_headmax_kernel(AttnArgs a, flo
             dma_wait_and_barrier();
             continue;
         }
+        if constexpr (!PH) {
+            float* so = sOut[wave];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int key0 = 32 * kt + 8 * g + 4 * h2;
-            f32x4 o;
+            for (int g = 0; g < 4; ++g) {
+                const int key0 = 32 * kt + 8 * g + 4 * h2;
+                f32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int key = key0 + j;
-                const bool dead = key >= a.T || (a.mask_diag && key == q);
-                o[j] = dead ? 0.f : amax[4 * g + j];
-                rs += o[j];
+                for (int j = 0; j < 4; ++j) {
+                    const int key = key0 + j;
+                    const bool dead = key >= a.T || (a.mask_diag && key == q);
+                    o[j] = dead ? 0.f : amax[4 * g + j];
+                    rs += o[j];
+                }
+                *(f32x4*)(so + (lane & 31) * HS + 8 * g + 4 * h2) = o;
             }
-            if (qok && key0 < TP) *(f32x4*)(A + ((size_t)b * a.T + q) * TP + key0) = o;
+            // (LDS operations of one wave execute in order: no barrier between the wave's own writes and reads)
+            const int qw0 = blockIdx.x * 128 + 32 * wave;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + (lane >> 3), kc = 32 * kt + 4 * (lane & 7);
+                const f32x4 o = *(const f32x4*)(so + row * HS + 4 * (lane & 7));
+                if (qw0 + row < a.T && kc < TP) *(f32x4*)(A + ((size_t)b * a.T + qw0 + row) * TP + kc) = o;
+            }
         }
         dma_wait_and_barrier();
     }
@@ -2120,8 +2137,8 @@ __global__ __launch_bounds__(256) void rollout_vecmat_kernel(const float* A, con
     extern __shared__ __attribute__((aligned(16))) float sw[];
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < T; i += 256) {
-        const float vi = v ? v[(size_t)b * T + i] : (i == 0 ? 1.f : 0.f);
-        sw[i] = vi / rowsum[(size_t)b * T + i];
+        // v == nullptr (e_0): only row 0 and its row sum are read - the head-max kernel may have been run for the first rows alone
+        sw[i] = v ? v[(size_t)b * T + i] / rowsum[(size_t)b * T + i] : (i == 0 ? 1.f / rowsum[(size_t)b * T] : 0.f);
     }
     __syncthreads();
     const int j0 = 4 * (blockIdx.x * 256 + threadIdx.x);
@@ -2271,8 +2288,9 @@ __global__ __launch_bounds__(512, 2) void rollout_matmul_kernel(const float* A, 
 }
 
 template <int DP>
-int launch_headmax_t(const AttnArgs& a, float* A, int TP, float* rowsum, hipStream_t s) {
-    dim3 grid((a.T + 127) / 128, a.B);
+int launch_headmax_t(const AttnArgs& a, float* A, int TP, float* rowsum, int q_rows, hipStream_t s) {
+    // q_rows > 0: only the first q_rows query rows (rounded up to whole 128-query workgroups) - the row chain's first step reads row 0 alone
+    dim3 grid(((q_rows > 0 ? std::min(q_rows, a.T) : a.T) + 127) / 128, a.B);
     if (!rowsum) {  // per-head probabilities
         switch (a.H) {
             case 1: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 1, true>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;
@@ -2317,9 +2335,9 @@ int launch_attn_rc_pad(const AttnArgs& a, hipStream_t s) {
 }
 int launch_attn_bwd(const AttnArgs& a, int DP, hipStream_t s) { DP_DISPATCH(bwd_flags, a, s) }
 
-int launch_rollout_headmax(const AttnArgs& a, int DP, float* A, int TP, float* rowsum, hipStream_t s) {
+int launch_rollout_headmax(const AttnArgs& a, int DP, float* A, int TP, float* rowsum, int q_rows, hipStream_t s) {
     if (a.H * (DP > 96 ? 4 : 2) > 16) return V1T_ERR_UNSUPPORTED;  // Q fragments of all heads must fit the register file
-    DP_DISPATCH(launch_headmax_t, a, A, TP, rowsum, s)
+    DP_DISPATCH(launch_headmax_t, a, A, TP, rowsum, q_rows, s)
 }
 int launch_rollout_matmul(const float* A, const float* rowsum, const float* Xin, float* Xout, int B, int T, int TP, hipStream_t s) {
     if (TP % 4 != 0 || TP < T || B > 65535) return V1T_ERR_ARG;

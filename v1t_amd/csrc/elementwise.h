@@ -137,6 +137,7 @@ struct BmlpBatch {
     int n;
 };
 int launch_bmlp_fwd(const BmlpArgs& a, hipStream_t s);
+int launch_bmlp_fwd_multi(const BmlpBatch& bb, hipStream_t s);  // all blocks' B-MLPs in one launch
 int launch_bmlp_bwd(const BmlpBatch& bb, hipStream_t s);  // all blocks' B-MLPs in one launch
 
 struct AdamArgs {

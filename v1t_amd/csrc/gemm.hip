@@ -114,11 +114,85 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
 }
 
 
+// ---- LDS-DMA ring K loop (round 5): launches with at most ONE workgroup per CU ---------------------------------------------------------
+// A launch of <= 256 workgroups (a rank's share of a multi-GPU step, a 16-image launch of the per-mouse loop) runs one 4-wave workgroup per
+// CU, i.e. one wave per SIMD: nothing overlaps a workgroup's K loop, and with the register-staged double buffer a CU has ONE K tile of
+// operand loads (36 KB) in flight - it then fetches at ~12 B per clock (outstanding bytes / memory latency: DESIGN.md "what bounds"), while
+// the same kernel is bandwidth-bound at full-size launches where 2-3 workgroups per CU interleave. Registers cannot hold more tiles (three
+// register sets pushed gemm_nt to one wave per SIMD in AGPR form: profiles/r04_gemm_experiments.txt). LDS can: with one workgroup per CU
+// the whole 160 KB are this workgroup's, so the operand tiles go global -> LDS by LDS-DMA (no registers at all) into a ring of NS stages of
+// [128 + 32 NBLK rows][64 k] bf16 (36 KB at NBLK = 5), NS - 1 stages (108 KB) in flight behind a counted vmcnt, one barrier per 64-wide K
+// tile. Layout: rows unpadded (a DMA instruction writes 1 KB = 8 rows linearly); the 16-B chunk c of row r sits at chunk position
+// c ^ ((r >> 1) & 7), applied on the GLOBAL side (each lane fetches the chunk its LDS slot holds), so that the MFMA fragment reads
+// (16 consecutive rows x 16 B per quarter-wave) touch every bank once. Instruction j = wave + 4 i of a stage covers rows 8 j .. 8 j + 7:
+// i < 4 the A rows, i >= 4 the B rows; j & 1 = wave & 1, so a lane fetches the SAME chunk index in every instruction it issues.
+constexpr int RING_BK = 64, RING_BM = 128;
+template <int NBLK> constexpr int ring_stage_elems() { return (RING_BM + 32 * NBLK) * RING_BK; }
+template <int N> DEVFN void wait_vmcnt_imm() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// arow(i) = GLOBAL row of A (already clamped into the valid range) that tile row 8 wave + 32 i + (lane >> 3) reads, i = 0..3
+template <int NBLK, int NS, bool F16, typename RowFn>
+DEVFN void ring_kloop(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Bm, int ldb, int nk, bf16_t* smem, int wave, int lane,
+                      RowFn arow, f32x16 (&acc)[NBLK]) {
+    constexpr int PW = 4 + NBLK;                    // DMA instructions per wave and stage
+    constexpr int STAGE = ring_stage_elems<NBLK>();  // bf16 elements
+    static_assert(NS >= 3 && (NS - 2) * PW < 64, "ring depth");
+    const int c = (lane & 7) ^ (4 * (wave & 1) + (lane >> 4));  // the chunk this lane fetches (see above)
+    const bf16_t* ap[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ap[i] = A + (size_t)arow(i) * lda + 8 * c;
+    const bf16_t* bp = Bm + (size_t)(8 * wave + (lane >> 3)) * ldb + 8 * c;
+    auto issue = [&](int kt) {
+        bf16_t* st = smem + (kt % NS) * STAGE + wave * 512;  // instruction j at 1 KB * j = 512 elements * (wave + 4 i)
+        const int k0 = kt * RING_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(ap[i] + k0, st + 2048 * i);
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) lds_dma16(bp + (size_t)(32 * i) * ldb + k0, st + 2048 * (4 + i));
+    };
+    // fragment reads: row (lane & 31) of a 32-row block, k chunk 2 ks + (lane >> 5), at chunk position (2 ks + h) ^ ((row >> 1) & 7)
+    int foff[RING_BK / 16];
+    {
+        const int row = lane & 31, h = lane >> 5, sw = (row >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < RING_BK / 16; ++ks) foff[ks] = row * RING_BK + 8 * ((2 * ks + h) ^ sw);
+    }
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) issue(t);
+    for (int t = 0; t < nk; ++t) {
+        const int rem = nk - 1 - t;  // stages behind t that have been issued: min(rem, NS - 2)
+        if (rem >= NS - 2) wait_vmcnt_imm<(NS - 2) * PW>();
+        else if (NS > 3 && rem == 1) wait_vmcnt_imm<PW>();
+        else if (NS > 4 && rem == 2) wait_vmcnt_imm<2 * PW>();
+        else wait_vmcnt_imm<0>();
+        __syncthreads();  // stage t has landed for every wave, and every wave is done with stage t - 1, whose slot the next issue overwrites
+        if (t + NS - 1 < nk) issue(t + NS - 1);
+        const bf16_t* sa = smem + (t % NS) * STAGE + 32 * wave * RING_BK;
+        const bf16_t* sb = smem + (t % NS) * STAGE + RING_BM * RING_BK;
+#pragma unroll
+        for (int ks = 0; ks < RING_BK / 16; ++ks) {
+            const bf16x8 a = *(const bf16x8*)(sa + foff[ks]);
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) {
+                const bf16x8 b = *(const bf16x8*)(sb + 32 * nb * RING_BK + foff[ks]);
+                if constexpr (F16) acc[nb] = mfma32h(a, b, acc[nb]);
+                else acc[nb] = mfma32(a, b, acc[nb]);
+            }
+        }
+    }
+    __syncthreads();  // every wave is done with the operand stages: the epilogues stage their outputs in the same memory
+}
+constexpr int RING_NS = 4;  // 4 x 36 KB at NBLK = 5
+
 // NW waves per workgroup = 32*NW rows (only 4 is launched: 64-row workgroups measured the same time on the
 // single-column-tile GEMMs, which are bound by how they read A, not by workgroups in flight).
-template <int NBLK, int EPI, int NW, int BK, bool F16 = false, bool RD = false>
+template <int NBLK, int EPI, int NW, int BK, bool F16 = false, bool RD = false, int RING = 0>
 __global__ __launch_bounds__(64 * NW, ((EPI == EPI_BIAS_GELU && BK == 32 && NBLK <= 4) || ((EPI == EPI_BIAS_RES || EPI == EPI_DGELU || EPI == EPI_BF16 || EPI == EPI_PATCH) && BK == 32 && NW == 4)) ? 3 : 1) void gemm_nt_kernel(GemmNTArgs g) {
     static_assert(!RD || (EPI == EPI_BF16 && NBLK == 5), "row dot: bf16 output, one 160-column tile per head");
+    static_assert(RING == 0 || (EPI == EPI_BIAS_RES && NW == 4 && BK == RING_BK), "ring K loop: the proj / FC2 form (nothing peeled around the last K tile)");
     constexpr int BM = 32 * NW, NT = 64 * NW;
     constexpr int LS = BK + 8, KC = BK / 8;  // LDS row stride (16-B pad: 80 / 144 B), 16-B chunks per row
     constexpr int A_ITERS = BM * KC / NT;
@@ -128,7 +202,8 @@ __global__ __launch_bounds__(64 * NW, ((EPI == EPI_BIAS_GELU && BK == 32 && NBLK
     static_assert(NW == 4 || (EPI != EPI_BIAS_GELU && EPI != EPI_DGELU), "fragment-order buffers assume 128-row tiles");
     // one allocation: the operand tiles (sA, sB) and, after the K loop, the bf16 output staging of EPI_BF16
     constexpr int CS = BN + 8;  // staging row stride (elements): 16-B aligned rows, odd multiple of 16 B
-    constexpr int SMEM = (2 * BM * LS + 2 * BN * LS) > (BM * CS) ? (2 * BM * LS + 2 * BN * LS) : (BM * CS);
+    constexpr int SMEM_DB = (2 * BM * LS + 2 * BN * LS) > (BM * CS) ? (2 * BM * LS + 2 * BN * LS) : (BM * CS);
+    constexpr int SMEM = RING ? RING * ring_stage_elems<NBLK>() : SMEM_DB;
     __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
     bf16_t (*sA)[BM * LS] = (bf16_t (*)[BM * LS])smem;
     bf16_t (*sB)[BN * LS] = (bf16_t (*)[BN * LS])(smem + 2 * BM * LS);
@@ -180,6 +255,10 @@ __global__ __launch_bounds__(64 * NW, ((EPI == EPI_BIAS_GELU && BK == 32 && NBLK
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
+  if constexpr (RING) {
+    ring_kloop<NBLK, RING, F16>(g.A, g.lda, g.B + (size_t)n0 * g.ldb, g.ldb, nk, smem, wave, lane,
+                                [&](int i) { return min(m0 + 8 * wave + 32 * i + (lane >> 3), g.M - 1); }, acc);
+  } else {
     gload(0);
     swrite(0);
     __syncthreads();
@@ -218,6 +297,7 @@ __global__ __launch_bounds__(64 * NW, ((EPI == EPI_BIAS_GELU && BK == 32 && NBLK
     }
     ktile((nk - 1) & 1);
     __syncthreads();
+  }
 
     // 16-bit outputs go through LDS: a lane holds one column of 16 rows per block, i.e. 2-byte global stores that fill
     // 64 B of two rows per instruction; staged [32 rows][BN] per wave (wave-private, no barrier) and written back as 16-B
@@ -466,6 +546,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_split_kernel(GemmNTArgs g) {
     gemm_epilogue<NBLK, EPI>(g, acc, resv, m0, n0, wave, lane);
 }
 
+// V1T_GEMM_RING=0 (dev, A/B): the register-staged double buffer also for launches of at most one workgroup per CU
+static const bool g_gemm_ring = !(std::getenv("V1T_GEMM_RING") && !atoi(std::getenv("V1T_GEMM_RING")));
 template <int NBLK, int NW, int BK>
 int launch_nt_nw(const GemmNTArgs& a, int epi, hipStream_t s) {
     const int BN = 32 * NBLK, BMW = 32 * NW;
@@ -477,7 +559,16 @@ int launch_nt_nw(const GemmNTArgs& a, int epi, hipStream_t s) {
         switch (epi) {
             case EPI_BF16: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BF16, NW, BK, true>), dim3(grid), blk, 0, s, a); break;
             case EPI_F32: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_F32, NW, BK, true>), dim3(grid), blk, 0, s, a); break;
-            case EPI_BIAS_RES: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_RES, NW, BK, true>), dim3(grid), blk, 0, s, a); break;
+            case EPI_BIAS_RES:
+                if constexpr (NBLK == 5 && NW == 4 && BK == RING_BK) {
+                    // at most one workgroup per CU: the LDS-DMA ring K loop (three 36-KB stages in flight instead of one register-staged tile)
+                    if (g_gemm_ring && grid <= 256 && a.K / BK >= 3) {
+                        hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_RES, NW, BK, true, false, RING_NS>), dim3(grid), blk, 0, s, a);
+                        break;
+                    }
+                }
+                hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_RES, NW, BK, true>), dim3(grid), blk, 0, s, a);
+                break;
             case EPI_PATCH: hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_PATCH, NW, BK, true>), dim3(grid), blk, 0, s, a); break;
             case EPI_BIAS_GELU:
                 if constexpr (NW == 4) { hipLaunchKernelGGL((gemm_nt_kernel<NBLK, EPI_BIAS_GELU, 4, BK, true>), dim3(grid), blk, 0, s, a); break; }
@@ -1034,8 +1125,8 @@ DEVFN float half32_sum(float v) {  // sum over the 32 lanes of a half-wave, retu
     const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // rows 0 <-> 1, 2 <-> 3
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-template <int NBLK, bool NEXT>
-__global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(GemmNTArgs g, LnBwdArgs l) {
+template <int NBLK, bool NEXT, int RING = 0>
+__global__ __launch_bounds__(256, RING ? 1 : 2) void gemm_lnbwd_kernel(GemmNTArgs g, LnBwdArgs l) {
     constexpr int NW = 4, BK = 32, BM = 32 * NW, NT = 64 * NW;
     constexpr int LS = BK + 8, KC = BK / 8;
     constexpr int A_ITERS = BM * KC / NT;
@@ -1043,7 +1134,9 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(GemmNTArgs g, LnBwdA
     constexpr int B_CHUNKS = BN * KC;
     constexpr int B_ITERS = (B_CHUNKS + NT - 1) / NT;
     constexpr int CS = BN + 8;  // staging row stride of the bf16 output (elements)
-    constexpr int SMEM = (2 * BM * LS + 2 * BN * LS) > (BM * CS) ? (2 * BM * LS + 2 * BN * LS) : (BM * CS);
+    constexpr int SMEM_DB = (2 * BM * LS + 2 * BN * LS) > (BM * CS) ? (2 * BM * LS + 2 * BN * LS) : (BM * CS);
+    constexpr int SMEM = RING ? RING * ring_stage_elems<NBLK>() : SMEM_DB;  // RING: the LDS-DMA ring K loop (launches of at most one workgroup per CU)
+    static_assert(!RING || RING * ring_stage_elems<NBLK>() >= BM * CS, "the epilogue's staging fits the ring");
     __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
     static_assert(4 * BN * 4 <= 32 * CS * 2, "column partials fit the wave's staging region");
     bf16_t (*sA)[BM * LS] = (bf16_t (*)[BM * LS])smem;
@@ -1093,6 +1186,11 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(GemmNTArgs g, LnBwdA
     for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+  if constexpr (RING) {
+    // rows past the image: clamped for the fetch, masked below
+    ring_kloop<NBLK, RING, false>(g.A, g.lda, g.B, g.ldb, g.K / RING_BK, smem, wave, lane,
+                                  [&](int i) { return (int)row0 + min(t0 + 8 * wave + 32 * i + (lane >> 3), l.T - 1); }, acc);
+  } else {
     gload(set0{}, 0);
     gload(set1{}, min(1, nk - 1));
     swrite(set0{}, 0);
@@ -1130,6 +1228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(GemmNTArgs g, LnBwdA
         ktile(0);
     }
     __syncthreads();  // every wave is done with the operand tiles: the bf16 staging below reuses them
+  }
 
     // ---- LayerNorm backward on the accumulators: column = 32 nb + (lane & 31), row = 32 wave + acc_row(r, lane)
     const float snext = l.scale_next ? l.scale_next[b] : 1.f;
@@ -1336,6 +1435,12 @@ int launch_gemm_ln_bwd(const GemmNTArgs& g, const LnBwdArgs& l, hipStream_t s) {
         if (l.dy_next) hipLaunchKernelGGL((gemm_lnbwd_kernel<NB, true>), grid, blk, 0, s, g, l);          \
         else hipLaunchKernelGGL((gemm_lnbwd_kernel<NB, false>), grid, blk, 0, s, g, l);                   \
         break;
+    // at most one workgroup per CU (a rank's share of a multi-GPU step, a 16-image launch of the per-mouse loop): the LDS-DMA ring K loop
+    if (g_gemm_ring && l.DP == 160 && grid.x <= 256 && g.K % RING_BK == 0 && g.K / RING_BK >= 3) {
+        if (l.dy_next) hipLaunchKernelGGL((gemm_lnbwd_kernel<5, true, RING_NS>), grid, blk, 0, s, g, l);
+        else hipLaunchKernelGGL((gemm_lnbwd_kernel<5, false, RING_NS>), grid, blk, 0, s, g, l);
+        return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    }
     switch (l.DP / 32) {
         V1T_GLB(1) V1T_GLB(2) V1T_GLB(3) V1T_GLB(4) V1T_GLB(5)
         default: return V1T_ERR_UNSUPPORTED;

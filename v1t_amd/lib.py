@@ -118,6 +118,7 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_attention_backward_ws_bytes": (c_ll, [c_int, c_int, c_int]),
     "v1t_attention_backward_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_u64, c_u32, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     "v1t_rollout_headmax": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "v1t_rollout_headmax_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "v1t_attention_probs": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "v1t_rollout_vecmat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "v1t_rollout_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from . import lib as L
-from .core import get_core
+from .core import get_core, l1_of_parameters
 from .flat import FlatArena
 from .readout import Gaussian2DReadout, Readouts
 
@@ -81,10 +81,7 @@ def _tanh_mlp(widths: t.Sequence[int]) -> nn.Sequential:
 
 
 def _l1(module: nn.Module, scale: torch.Tensor):
-    total = 0
-    for p in module.parameters():
-        total = total + p.abs().sum()
-    return scale * total
+    return l1_of_parameters(module, scale)  # reg_scale * sum_p |p|.sum(), fused on the GPU (core.py)
 
 
 class CoreShifter(nn.Module):
@@ -259,13 +256,20 @@ class Model(nn.Module):
 
     def regularizer(self, mouse_id: str):
         """reference model.py:141-149"""
-        reg = 0
+        terms = []
         if not self.core.frozen:
-            reg = reg + self.core.regularizer()
-        reg = reg + self.readouts.regularizer(mouse_id=mouse_id)
-        reg = reg + self.image_cropper.regularizer(mouse_id=mouse_id)
+            terms.append(self.core.regularizer())
+        terms.append(self.readouts.regularizer(mouse_id=mouse_id))
+        terms.append(self.image_cropper.regularizer(mouse_id=mouse_id))
         if self.core_shifter is not None:
-            reg = reg + self.core_shifter.regularizer(mouse_id=mouse_id)
+            terms.append(self.core_shifter.regularizer(mouse_id=mouse_id))
+        # the reference's `reg = 0; reg += term` chain, without an add kernel for the terms that are exactly the number 0 (no image
+        # shifter; a shifter whose reg_scale is 0)
+        reg = 0
+        for x in terms:
+            if isinstance(x, (int, float)) and x == 0:
+                continue
+            reg = x if (isinstance(reg, (int, float)) and reg == 0) else reg + x
         return reg
 
     def forward(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor, activate: bool = True):

@@ -260,7 +260,14 @@ class Gaussian2DReadout(Readout):
         return l1
 
     def regularizer(self, reduction="sum"):
-        """gaussian2d.py:99-100"""
+        """gaussian2d.py:99-100. GPU, reduction "sum": one `v1t_l1_sum` launch over the neuron-major feature storage (its pad columns are
+        0), and in the backward one `v1t_l1_grad_dev` into the attached gradient storage - instead of abs / sum / mul over the strided
+        (1, C, 1, N) view and their three backward kernels."""
+        f = self.features
+        if reduction == "sum" and f.is_cuda and f.dtype == torch.float32:
+            from .core import cached_scalar
+
+            return _FeatL1Fn.apply(f, self.feature_storage(), cached_scalar(self.reg_scale))
         return self.reg_scale * self.feature_l1(reduction=reduction)
 
     @property
@@ -316,6 +323,33 @@ class Gaussian2DReadout(Readout):
         st = self.feature_storage()
         feat_st = _FeatStorageFn.apply(self.features, st) if self.features.requires_grad else st
         return _Gaussian2dFn.apply(zbuf, grid, feat_st, self.bias, geom, self.features)
+
+
+class _FeatL1Fn(torch.autograd.Function):
+    """scale * sum|features| over the [N][FS] storage (pad columns are exactly 0, so they add nothing and receive sign(0) = 0)."""
+
+    @staticmethod
+    def forward(ctx, feat_param, storage, scale: float):
+        out = torch.zeros((), dtype=torch.float32, device=storage.device)
+        L.check(L.load().v1t_l1_sum(storage.data_ptr(), storage.numel(), scale, out.data_ptr(), L.stream()), "l1_sum")
+        ctx.feat_param, ctx.storage, ctx.scale = feat_param, storage, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fp, st = ctx.feat_param, ctx.storage
+        FS = st.shape[1]
+        g = g.to(torch.float32).contiguous()
+        fg = getattr(fp, "grad", None)
+        ret = None
+        if fg is not None and fg.dtype == torch.float32 and fg.shape == fp.shape and fg.stride(1) == 1 and fg.stride(3) == FS and fg.device == st.device:
+            sink = fg  # (1, C, 1, N) view of an [N][FS] gradient storage (the arena): element (0,0,0,0) is its first float
+        else:
+            sink = torch.zeros_like(st)
+            c = fp.shape[1]
+            ret = sink[:, :c].t()[None, :, None, :]
+        L.check(L.load().v1t_l1_grad_dev(st.data_ptr(), sink.data_ptr(), st.numel(), ctx.scale, g.data_ptr(), L.stream()), "l1_grad")
+        return ret, None, None
 
 
 class _FeatStorageFn(torch.autograd.Function):

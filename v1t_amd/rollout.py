@@ -14,6 +14,7 @@ re-association difference is ~1e-9).
 """
 from __future__ import annotations
 
+import contextlib
 import typing as t
 
 import torch
@@ -88,26 +89,58 @@ def rollout_rows(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, p
         core.train(was_training)
     lib = L.load()
     B, T = tokens.shape[0], core.num_tokens
-    TP = (T + 3) // 4 * 4
+    TP = (T + 31) // 32 * 32  # whole 32-key tiles: a query row's 128-B tile segments are line-aligned (T = 1654 -> 1664 floats = 52 lines per row)
     cfg = core._cfg
     H, DP = cfg.num_heads, core.padded_dim
     dev = tokens.device
-    A = torch.empty((B, T, TP), dtype=torch.float32, device=dev)
-    rowsum = torch.empty((B, T), dtype=torch.float32, device=dev)
+    # The head-max maps do not depend on the chain, only the vector-matrix products do: block k - 1's map (MFMA + exp work, writes at ~2 TB/s)
+    # is recomputed on a second stream while block k's product streams its 2.8 GB back in (HBM-read-bound) - two map buffers in turn
+    # (2 x 2.8 GB at batch 256 of the 288 GB), events both ways. `return_headmax` keeps the simple serial form (it clones every map).
+    pipelined = (not return_headmax) and cfg.num_blocks > 1 and tokens.is_cuda
+    nbuf = 2 if pipelined else 1
+    As = [torch.empty((B, T, TP), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    rss = [torch.empty((B, T), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     v: t.Optional[torch.Tensor] = None
     maps = []
     nqkv, nlse = B * T * 3 * H * DP * 2, B * H * T * 4
-    for k in reversed(range(cfg.num_blocks)):
+    main = torch.cuda.current_stream() if pipelined else None
+    side = core._rollout_stream if (pipelined and getattr(core, "_rollout_stream", None) is not None) else (torch.cuda.Stream() if pipelined else None)
+    if pipelined:
+        core._rollout_stream = side
+        side.wait_stream(main)  # the forward that produced q / k / lse
+    used = [None] * nbuf   # event: the product that last read this buffer has finished
+    for n_, k in enumerate(reversed(range(cfg.num_blocks))):
+        A, rowsum = As[n_ % nbuf], rss[n_ % nbuf]
         qkv = core.workspace_tensor("qkv", k)[:nqkv]
         lse2 = core.workspace_tensor("lse2", k)[:nlse]
         scale = core.transformer.blocks[k]["mha"].scale
-        L.check(lib.v1t_rollout_headmax(qkv.data_ptr(), lse2.data_ptr(), B, H, T, DP, scale.data_ptr(), int(cfg.use_lsa), int(cfg.use_lsa),
-                                        A.data_ptr(), TP, rowsum.data_ptr(), L.stream()), "rollout_headmax")
+        with (torch.cuda.stream(side) if pipelined else contextlib.nullcontext()):
+            if pipelined and used[n_ % nbuf] is not None:
+                side.wait_event(used[n_ % nbuf])
+            if v is None and n_ == 0 and not return_headmax:
+                # the chain starts from e_0: of the LAST block's matrix only row 0 (and its row sum) is read - one 128-query workgroup per image
+                # instead of 13 (a quarter of the rollout's head-max work at 4 blocks)
+                L.check(lib.v1t_rollout_headmax_rows(qkv.data_ptr(), lse2.data_ptr(), B, H, T, DP, scale.data_ptr(), int(cfg.use_lsa), int(cfg.use_lsa),
+                                                     A.data_ptr(), TP, rowsum.data_ptr(), 1, L.stream()), "rollout_headmax")
+            else:
+                L.check(lib.v1t_rollout_headmax(qkv.data_ptr(), lse2.data_ptr(), B, H, T, DP, scale.data_ptr(), int(cfg.use_lsa), int(cfg.use_lsa),
+                                                A.data_ptr(), TP, rowsum.data_ptr(), L.stream()), "rollout_headmax")
+            if pipelined:
+                ready = torch.cuda.Event()
+                ready.record(side)
+        if pipelined:
+            main.wait_event(ready)
         u = torch.empty((B, T), dtype=torch.float32, device=dev)
         L.check(lib.v1t_rollout_vecmat(A.data_ptr(), rowsum.data_ptr(), L.ptr(v), u.data_ptr(), B, T, TP, L.stream()), "rollout_vecmat")
+        if pipelined:
+            used[n_ % nbuf] = torch.cuda.Event()
+            used[n_ % nbuf].record(main)
         v = u
         if return_headmax:
             maps.append(A[:, :, :T].clone())
+    if pipelined:
+        for t_ in As + rss:
+            t_.record_stream(side)  # written on the side stream: the allocator must not hand the memory out before that stream is past it
     rows = v[:, 1:]
     return (rows, maps[::-1]) if return_headmax else rows
 

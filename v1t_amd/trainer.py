@@ -584,14 +584,20 @@ class Trainer:
                 for mouse_id in sh.shared_mice():
                     sh.reduce_mouse(mouse_id, model.mouse_arena(mouse_id))
         # optimizer: core (L1 once per mouse-batch of the global step), then the local mice's arenas
+        mice_left = [] if (native is not None and native.mice_stepped) else list(self.sharding.local_mice())  # (the native single-GPU step ran them beside the core's backward)
+        items = [(self.model.mouse_arena(m), [(o, n, c, self.opt.group_lr(g)) for o, n, c, g in self.model.mouse_step_ranges(m)]) for m in mice_left]
         if not core.frozen:
             ca = core._arena
             if self._core_l1 is None:  # the reg_scale buffer lives on the device: one read, not one sync per step
                 self._core_l1 = float(core.reg_scale) * len(self.mouse_ids)
-            self.opt.step_arena(ca, [(0, ca.param_floats, self._core_l1, self.opt.group_lr("core"))])
+            core_item = (ca, [(0, ca.param_floats, self._core_l1, self.opt.group_lr("core"))])
+            if items and "step_arena" not in self.opt.__dict__:
+                items.insert(0, core_item)  # a rank of a multi-GPU step: the core and its mice in ONE launch behind the exchange
+            else:
+                self.opt.step_arena(*core_item)
             core.mark_updated()
-        if not (native is not None and native.mice_stepped):  # (the native single-GPU step ran them beside the core's backward)
-            self.step_mice(list(self.sharding.local_mice()))
+        if items:
+            self.opt.step_arenas(items)
         if native is not None:
             return {"loss": losses[0]}  # the step's total, summed by the loss kernel
         return {"loss": torch.stack(losses).sum() if losses else torch.zeros((), device=core._arena.data.device)}
