@@ -100,6 +100,17 @@ def test_install_into_reference_builds_native_classes_in_reference_model(g12):
             assert [x["name"] for x in groups] == list(g12[f"g12/sm{sm}/group_names"])
             for x in groups:
                 assert [names[id(p)] for p in x["params"]] == list(g12[f"g12/sm{sm}/group/{x['name']}"])
+            # the reference's OWN Recorder finds what it hooks on the native core (attention_rollout.py:24-36: instances of its Attention
+            # class under core.transformer, each with an `.attend` child) - one per block, and they add no state-dict keys (checked above)
+            from v1t.models.core import vit as ref_vit
+            from v1t.utils.attention_rollout import Recorder as RefRecorder
+
+            rec = RefRecorder(model.core)
+            found = rec._find_modules(model.core.transformer, ref_vit.Attention)
+            assert len(found) == cfg.num_blocks and all(hasattr(m_, "attend") for m_ in found)
+            rec._register_hook()
+            assert len(rec.hooks) == cfg.num_blocks and len(model.core._hooked_taps()) == cfg.num_blocks
+            assert rec.eject() is model.core and model.core._hooked_taps() == []
             # weights written for the reference load into it (same keys and shapes) ...
             res = model.load_state_dict(W.make_state_dict(cfg, 3), strict=False)
             assert not res.unexpected_keys and set(res.missing_keys) <= {"image_cropper.grid", "elu1.one"}
@@ -109,3 +120,4 @@ def test_install_into_reference_builds_native_classes_in_reference_model(g12):
                 model(inputs=b["image"], mouse_id="A", behaviors=b["behavior"], pupil_centers=b["pupil_center"])
     finally:
         ref_core._CORES["vit"], ref_readout._READOUTS["gaussian2d"] = saved
+        v1t_amd.ViTCore._reference_attention_cls = None

@@ -523,6 +523,54 @@ def test_attention_rollout_vs_reference_golden(golden, dev):
     assert float((probs.amax(dim=2) - attn[:, :, 0]).abs().max()) < 1e-6
 
 
+def test_reference_recorder_mechanism_on_native_core(dev):
+    """The reference's own `Recorder` (utils/attention_rollout.py:15-77) on the native core, its mechanism restated (the reference is not on
+    the GPU box; tests/test_boundary.py runs the REAL Recorder's module search and hook registration against the native core on the CPU):
+    collect `isinstance(m, Attention)` modules under `core.transformer`, hook their `.attend`, clone what passes, stack over blocks.
+    With `install_into_reference()` the class is `v1t.models.core.vit.Attention`; here a stand-in class plays it."""
+    import v1t_amd
+    from torch import nn
+    from v1t_amd.rollout import attention_probabilities, rollout_rows
+
+    class Attention(nn.Module):  # stands for v1t.models.core.vit.Attention
+        def __init__(self):
+            raise AssertionError("the tap must not run the reference's constructor (it would allocate a second set of attention weights)")
+
+    v1t_amd.ViTCore._reference_attention_cls = Attention
+    try:
+        cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A",), num_neurons={"A": 64})
+        sd = W.make_state_dict(cfg, 99)
+        model, _ = build_native_model(cfg, sd, dev)
+        assert list(model.state_dict().keys()) == [k for k in model.state_dict().keys() if "recorder_tap" not in k]  # no keys from the taps
+        core = model.core.train(False)
+        b = {k: v.to(dev) for k, v in W.make_batch(cfg, "A", 2, 99).items()}
+        cache, hooks = [], []
+        mods = [m for m in core.transformer.modules() if isinstance(m, Attention)]  # Recorder._find_modules
+        assert len(mods) == cfg.num_blocks
+        for m in mods:
+            hooks.append(m.attend.register_forward_hook(lambda _, inputs, outputs: cache.append(outputs.clone().detach())))  # Recorder._hook
+        with torch.no_grad():
+            out = core(inputs=b["image"], behaviors=b["behavior"], pupil_centers=b["pupil_center"], mouse_id="A")  # Recorder.forward's call
+        attentions = torch.stack(cache, dim=1)
+        T = core.num_tokens
+        assert attentions.shape == (2, cfg.num_blocks, cfg.num_heads, T, T) and out.shape == (2, *core.output_shape)
+        assert torch.equal(attentions, attention_probabilities(core, b["image"], b["behavior"], b["pupil_center"], "A"))
+        assert float((attentions.sum(-1) - 1).abs().max()) < 2e-3
+        # the reference's rollout of the recorded tensor (restated by the oracle) == the native row chain
+        rows = rollout_rows(core, b["image"], b["behavior"], b["pupil_center"], "A")
+        for i in range(2):
+            check_rel("reference Recorder mechanism: rollout of the recorded probabilities vs native rows", O.attention_rollout_row(attentions[i].cpu()).numpy(), rows[i].cpu().numpy(), 1e-4)
+        # eject: hooks removed -> the forward emits nothing and keeps nothing
+        for h in hooks:
+            h.remove()
+        n = len(cache)
+        with torch.no_grad():
+            out2 = core(inputs=b["image"], behaviors=b["behavior"], pupil_centers=b["pupil_center"], mouse_id="A")
+        assert len(cache) == n and torch.equal(out2, out)
+    finally:
+        v1t_amd.ViTCore._reference_attention_cls = None
+
+
 def test_attention_rollout_vs_oracle_default_size(dev):
     """Default V1T size (4 blocks, D=155, T=1654), B=2: native rollout vs the oracle's full matrix chain."""
     from v1t_amd.rollout import rollout_rows

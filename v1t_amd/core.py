@@ -263,6 +263,15 @@ def l1_of_parameters(module: nn.Module, reg_scale: torch.Tensor):
     return _L1ParamsFn.apply(scale, *ps)
 
 
+class _AttendTap(nn.Module):
+    """Stands where the reference's `Attention.attend` (an nn.Softmax, vit.py:229) stands: the reference's `Recorder` registers a forward
+    hook on it (utils/attention_rollout.py:28-36). The fused attention never runs a softmax module; when a hook is registered, the core
+    recomputes the block's per-head probabilities after the forward (`v1t_attention_probs`) and passes them through this identity."""
+
+    def forward(self, probabilities: torch.Tensor) -> torch.Tensor:
+        return probabilities
+
+
 def _seq(*mods: nn.Module) -> nn.Sequential:
     return nn.Sequential(*mods)
 
@@ -329,6 +338,7 @@ class ViTCore(Core):
         self._block_events = None  # set by the data-parallel trainer (dist.MouseSharding.reduce_core_overlapped)
         self._path_scale_override = None  # tests: (num_blocks, 2, B) factors to replay instead of drawing them
         self.num_blocks = int(args.num_blocks)
+        self.attach_recorder_taps()  # no-op unless v1t_amd.install_into_reference() has named the reference's Attention class
         if not hasattr(self, "drop_path_rates"):  # ViT: one DropPath module for every block (vit.py:333)
             self.drop_path_rates = torch.full((self.num_blocks,), self.drop_path_rate, dtype=torch.float32)
         # the attention-probability dropout (vit.py:263) runs at round(256 p) / 256 (include/v1t_amd.h): say so when that is not p
@@ -519,6 +529,50 @@ class ViTCore(Core):
         need_bwd = (torch.is_grad_enabled() and self._anchor.requires_grad) or keep_workspace
         return _VitFn.apply(self, inputs, beh, midx, self._anchor, need_bwd)
 
+    # ------------------------------------------------------------------ the reference's own Recorder (utils/attention_rollout.py:15-77)
+    _reference_attention_cls: t.Optional[type] = None  # set by v1t_amd.install_into_reference(): v1t.models.core.vit.Attention
+
+    def attach_recorder_taps(self, attention_cls: t.Optional[type] = None) -> None:
+        """Give every block a parameter-free sub-module that IS an instance of `attention_cls` (the reference's `vit.Attention`) and has an
+        `attend` child, so that the reference's `Recorder` - which collects `isinstance(m, Attention)` modules under `core.transformer` and
+        hooks their `.attend` (attention_rollout.py:24-36) - finds what it looks for on the native core. The state-dict is unchanged (no
+        parameters, no buffers). While such a hook is registered, `forward` keeps q / k / log-sum-exp and emits each block's (B, H, T, T)
+        probabilities through the tap, in block order: `misc/extract_attention_maps.py` then runs unchanged. Memory and time are the
+        reference's (175 MB of probabilities per image and default model): meant for the handful of images that script processes."""
+        cls = attention_cls or type(self)._reference_attention_cls
+        if cls is None or not self.cls_tokens:
+            return
+        for blk in self.transformer.blocks:
+            mha = blk["mha"]
+            tap = getattr(mha, "recorder_tap", None)
+            if tap is None or not isinstance(tap, cls):
+                tap = cls.__new__(cls)   # no __init__: the reference's constructor would allocate a second set of attention parameters
+                nn.Module.__init__(tap)
+                tap.attend = _AttendTap()
+                mha.recorder_tap = tap
+
+    def _hooked_taps(self) -> t.List[nn.Module]:
+        taps = [getattr(blk["mha"], "recorder_tap", None) for blk in self.transformer.blocks]
+        return [t_ for t_ in taps if t_ is not None] if any(t_ is not None and len(t_.attend._forward_hooks) > 0 for t_ in taps) else []
+
+    @torch.no_grad()
+    def _emit_attention_probabilities(self, B: int) -> None:
+        lib = L.load()
+        cfg, T = self._cfg, self.num_tokens
+        H, DP = cfg.num_heads, self.padded_dim
+        TP = (T + 3) // 4 * 4
+        nqkv, nlse = B * T * 3 * H * DP * 2, B * H * T * 4
+        for k, blk in enumerate(self.transformer.blocks):
+            tap = getattr(blk["mha"], "recorder_tap", None)
+            if tap is None:
+                continue
+            qkv = self.workspace_tensor("qkv", k)[:nqkv]
+            lse2 = self.workspace_tensor("lse2", k)[:nlse]
+            P = torch.empty((B, H, T, TP), dtype=torch.float32, device=qkv.device)
+            L.check(lib.v1t_attention_probs(qkv.data_ptr(), lse2.data_ptr(), B, H, T, DP, blk["mha"].scale.data_ptr(), int(cfg.use_lsa), int(cfg.use_lsa),
+                                            P.data_ptr(), TP, L.stream()), "attention_probs")
+            tap.attend(P[..., :T])  # nn.Module.__call__: fires the registered forward hooks with outputs = the probabilities
+
     def tokens_to_output(self, tokens: torch.Tensor) -> torch.Tensor:
         c, h, w = self.output_shape
         # (B, C', h, w) exactly like vit.py:434-435, as a zero-copy strided view of the token-major buffer
@@ -527,6 +581,10 @@ class ViTCore(Core):
         return out
 
     def forward(self, inputs: torch.Tensor, mouse_id: str, behaviors: torch.Tensor, pupil_centers: torch.Tensor):
+        if self._hooked_taps():  # the reference's Recorder is listening
+            tokens = self.forward_tokens(inputs, mouse_id, behaviors, pupil_centers, keep_workspace=True)
+            self._emit_attention_probabilities(int(tokens.shape[0]))
+            return self.tokens_to_output(tokens)
         return self.tokens_to_output(self.forward_tokens(inputs, mouse_id, behaviors, pupil_centers))
 
     def forward_many(self, inputs: t.Sequence[torch.Tensor], mouse_ids: t.Sequence[str], behaviors: t.Sequence[torch.Tensor],

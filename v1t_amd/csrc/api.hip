@@ -169,11 +169,16 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
 // so it is the default. V1T_ATTN_BWD_DS=0 (dev) selects the fused recompute kernel, which LSA (mask_diag) always uses.
 static const int g_attn_ds = (std::getenv("V1T_ATTN_BWD_DS") && !atoi(std::getenv("V1T_ATTN_BWD_DS"))) ? 0 : 1;
 struct ScratchLayout {
-    long long G, dy, dy2, dhpre, dz, dO, delta, dqkv, dbeta, slab, pu, pgd, pdu, ds, total;
+    long long G, dy, dy2, dy3, dhpre, dz, dO, delta, dqkv, dqkv2, dbeta, slab, pu, pgd, pdu, ds, total;
 };
-// contraction rows per workgroup of the weight-gradient GEMMs: aim at >= ~512 workgroups
+// contraction rows per workgroup of the weight-gradient GEMMs: aim at >= ~512 workgroups at full-size launches. Launches under 65 536 rows (a
+// rank's share of a multi-GPU step, the 16-image launches of the per-mouse loop) run beside the dX GEMMs on the second stream and are bound by
+// their fixed parts - prologue, partial-tile stores and the slab reduction, which reads one partial tile per m-chunk - not by idle CUs: 256
+// there (half the m-chunks, half the slab traffic). A/B in one call at a 14-image share: 512: 3.67 / 3.69 ms per step, 256: 3.60 / 3.57,
+// 128: 3.62 / 3.56, 64: 3.61 / 3.68; the 7 x 16-image loop: 28.8 -> 28.3 ms (profiles/r05_small_launch_experiments.txt)
 int tn_mchunk(long long R, int tiles) {
-    static const int target = std::getenv("V1T_TN_WGS") ? atoi(std::getenv("V1T_TN_WGS")) : 512;  // dev switch
+    static const int forced = std::getenv("V1T_TN_WGS") ? atoi(std::getenv("V1T_TN_WGS")) : 0;  // dev switch
+    const int target = forced > 0 ? forced : (R < 65536 ? 256 : 512);
     const int want = std::max(1, target / std::max(tiles, 1));
     const int mc = (int)round_up((R + want - 1) / want, 64);
     return std::max(mc, 128);
@@ -224,12 +229,14 @@ ScratchLayout scratch_layout(const v1t_vit* h, int B) {
     };
     s.G = take(R * h->DP * 4);
     s.dy = take(R * h->DP * 2);
-    s.dy2 = take(R * h->DP * 2);  // the two residual branches' output gradients alternate between dy and dy2 (backward, below)
+    s.dy2 = take(R * h->DP * 2);  // the attention branch's output gradient (dyp, backward below)
+    s.dy3 = take(R * h->DP * 2);  // the MLP branch's output gradient of odd blocks (dy alternates by block parity, backward below)
     s.dhpre = take(R * h->MP * 2);
     s.dz = take(R * h->DP * 4);
     s.dO = take(R * h->HDP * 2);
     s.delta = take((long long)B * h->H * h->T * 4);
     s.dqkv = take(R * 3 * h->HDP * 2);
+    s.dqkv2 = take(dw_side_for(R) ? R * 3 * h->HDP * 2 : 0);  // odd blocks' dqkv where the weight-gradient GEMMs run a block behind (second stream)
     s.dbeta = take((long long)h->NB * B * h->DP * 4);
     // one region per weight-gradient GEMM of a block where they run beside the dX GEMMs (second stream), else one region they share in turn
     s.slab = take((dw_side_for(R) ? 4 : 1) * (((long long)tn_plan(h, R).slab + 255) / 256 * 256));
@@ -821,13 +828,16 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
     // that the kernel that writes the one (LN2 backward -> dyp, LN1 backward -> dy of the block before) never has to wait for the weight-
     // gradient GEMM that still reads the other on the second stream: with ONE buffer the main stream idled 25-36 us per block in front of
     // the LN2 backward at a rank's share of an 8-GPU step (join of dW2, launched three short kernels earlier)
-    bf16_t* dy = (bf16_t*)(sc + sl.dy);
+    // round 5, second-stream mode: dy alternates between two buffers by block parity and dqkv likewise, so that a block's four weight-gradient
+    // GEMMs can be handed to the second stream as ONE group (one event each way per block instead of four: every hipEventRecord in the main
+    // stream's queue cost ~11 us of dispatch gap at a 14-image share, 16 of them per backward)
+    bf16_t* dy_par[2] = {(bf16_t*)(sc + sl.dy), (bf16_t*)(sc + sl.dy3)};
     bf16_t* dyp = (bf16_t*)(sc + sl.dy2);
     bf16_t* dhpre = (bf16_t*)(sc + sl.dhpre);
     float* dz = (float*)(sc + sl.dz);
     bf16_t* dO = (bf16_t*)(sc + sl.dO);
     float* delta = (float*)(sc + sl.delta);
-    bf16_t* dqkv = (bf16_t*)(sc + sl.dqkv);
+    bf16_t* dqkv_par[2] = {(bf16_t*)(sc + sl.dqkv), (bf16_t*)(sc + (dw_side_for(R) ? sl.dqkv2 : sl.dqkv))};
     float* dbeta = (float*)(sc + sl.dbeta);
     if (h->inject) CHECK(launch_fill_zero(dbeta, (long long)h->NB * B * DP * 4, s));  // (a kernel of the library, not a runtime fill: nothing foreign in the step's trace)
     const TnPlan tp = tn_plan(h, R);
@@ -849,27 +859,43 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         for (int i = 0; i < 4; ++i)
             if (hipEventCreateWithFlags(&h->dw_ready[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->dw_done[i], hipEventDisableTiming) != hipSuccess) return V1T_ERR_LAUNCH;
     }
-    // GEMM j of a block (0 dW2, 1 dW1, 2 dWo, 3 dWqkv): on the second stream behind everything enqueued on `s` so far; join_dw(j) makes `s` wait for it
+    // Second-stream mode: GEMM j of a block (0 dW2, 1 dW1, 2 dWo, 3 dWqkv) is QUEUED by launch_dw and handed over by flush_dw(g) as a group -
+    // behind one event recorded on `s` - with the block's other weight-gradient GEMMs; join_dw(g) makes `s` wait for group g (parity
+    // events). Group k = {dWqkv of block k + 1, dW2 / dW1 / dWo of block k}, flushed behind block k's LN2 backward and joined at the start of
+    // block k - 1: every buffer a group reads stays untouched until then (dy and dqkv alternate by block parity, dyp and dhpre are rewritten
+    // only after that join). Single-stream mode (full-size launches): launch_dw launches at once on `s`, the rest are no-ops.
+    std::vector<GemmTNArgs> dw_queue;
     auto launch_dw = [&](GemmTNArgs& t, int j) -> int {
         t.slab = slab ? slab + (dw_side ? (size_t)j * slab_stride : 0) : nullptr;
         if (!dw_side) return launch_gemm_tn(t, s);
-        if (hipEventRecord(h->dw_ready[j], s) != hipSuccess || hipStreamWaitEvent(h->dw_stream, h->dw_ready[j], 0) != hipSuccess) return V1T_ERR_LAUNCH;
-        const int rc = launch_gemm_tn(t, h->dw_stream);
-        if (rc) return rc;
-        return hipEventRecord(h->dw_done[j], h->dw_stream) == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+        dw_queue.push_back(t);
+        return V1T_OK;
     };
-    bool dw_pending[4] = {false, false, false, false};
+    bool dw_pending[2] = {false, false};
+    auto flush_dw = [&](int g) -> int {
+        if (!dw_side || dw_queue.empty()) return V1T_OK;
+        const int e = g & 1;
+        if (hipEventRecord(h->dw_ready[e], s) != hipSuccess || hipStreamWaitEvent(h->dw_stream, h->dw_ready[e], 0) != hipSuccess) return V1T_ERR_LAUNCH;
+        for (GemmTNArgs& t : dw_queue) {
+            const int rc = launch_gemm_tn(t, h->dw_stream);
+            if (rc) return rc;
+        }
+        dw_queue.clear();
+        dw_pending[e] = true;
+        return hipEventRecord(h->dw_done[e], h->dw_stream) == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    };
     int join_err = V1T_OK;
-    auto join_dw = [&](int j) {
-        if (dw_side && dw_pending[j]) {
-            if (hipStreamWaitEvent(s, h->dw_done[j], 0) != hipSuccess) join_err = V1T_ERR_LAUNCH;
-            dw_pending[j] = false;
+    auto join_dw = [&](int g) {
+        const int e = g & 1;
+        if (dw_side && dw_pending[e]) {
+            if (hipStreamWaitEvent(s, h->dw_done[e], 0) != hipSuccess) join_err = V1T_ERR_LAUNCH;
+            dw_pending[e] = false;
         }
     };
     // a failed launch in mid-block must not leave second-stream work un-joined behind `s` (the caller may free or reuse the scratch)
     struct DwGuard {
         decltype(join_dw)& join;
-        ~DwGuard() { for (int j = 0; j < 4; ++j) join(j); }
+        ~DwGuard() { join(0); join(1); }
     } dw_guard{join_dw};
     const bool x16o = x16_attn_out(h, R), x16a = x16_gelu_out(h, R);  // the forward left only the fp16 planes of o / gelu(h)
 
@@ -878,7 +904,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         // entry of the last block's MLP branch: dy = dropout_bwd(gout) (bf16), db2 += colsum
         const BlockOff& b = h->blk[h->NB - 1];
         CastArgs ca{};
-        ca.g = gout; ca.dy = dy; ca.dbias = b.fc2b >= 0 ? grads + b.fc2b : nullptr;
+        ca.g = gout; ca.dy = dy_par[(h->NB - 1) & 1]; ca.dbias = b.fc2b >= 0 ? grads + b.fc2b : nullptr;
         ca.drop = make_drop(train, h->c.t_dropout, seed, 8 * (h->NB - 1) + 3);
         ca.scale = path_scale ? path_scale + (size_t)(2 * (h->NB - 1) + 1) * B : nullptr; ca.T = h->T;
         ca.rows = R; ca.D = D; ca.DP = DP;
@@ -895,6 +921,13 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         const bf16_t* z2 = (const bf16_t*)(wb + w.z2);
         const bf16_t* hpre = (const bf16_t*)(wb + w.hpre);
         const bf16_t* hact = (const bf16_t*)(wb + w.hact);
+        bf16_t* dy = dy_par[k & 1];          // gradient of this block's FC2 output (written by the block above, or by the entry cast)
+        bf16_t* dy_prev = dy_par[(k + 1) & 1];  // ... of block k - 1's, written by this block's LN1 backward
+        bf16_t* dqkv = dqkv_par[k & 1];
+        join_dw(k + 1);  // group k + 1 (read dhpre, dyp, this parity's dqkv ... of the blocks above): complete before this block rewrites them
+        if (block_done && k + 2 < h->NB && block_done[k + 2]) {  // block k + 2's gradients: its own group and, for dWqkv, group k + 1 - both joined
+            if (hipEventRecord((hipEvent_t)block_done[k + 2], s) != hipSuccess) return V1T_ERR_LAUNCH;
+        }
 
         // ---- MLP branch: dW2 += dy^T hact
         GemmTNArgs t{};
@@ -902,8 +935,6 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = MP; t.xseg_valid = M; t.alpha = 1.f;
         t.m_chunk = tp.mc_fc2;
         CHECK(launch_dw(t, 0));  // reads dy, hact
-        dw_pending[0] = true;
-        join_dw(1);              // the previous block's dW1 read dhpre, which the next GEMM overwrites
         // d_hpre = (dy . W2) * mask * gelu'(hpre); db1 += colsum
         GemmNTArgs g{};
         g.A = dy; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_fc2_t); g.ldb = DP; g.M = R; g.N = MP; g.K = DP; g.C = dhpre; g.ldc = MP;
@@ -918,8 +949,6 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         if (DP > D && b.fc1b >= 0) { t.dbias = grads + b.fc1b; t.ones_col = DP - 1; }  // z2[:, DP-1] == 1 (LN kernel)
         t.m_chunk = tp.mc_fc1;
         CHECK(launch_dw(t, 1));  // reads dhpre, z2
-        dw_pending[1] = true;
-        join_dw(2);              // the previous block's dWo read dyp, which the LayerNorm backward below overwrites (dy_next)
         // dz2 = d_hpre . W1
         g = GemmNTArgs{};
         g.A = dhpre; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc1_t); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = dz; g.ldc = DP;
@@ -940,8 +969,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->HEP; t.xseg_valid = h->HE; t.alpha = 1.f;
         t.m_chunk = tp.mc_proj;
         CHECK(launch_dw(t, 2));  // reads dyp, o
-        dw_pending[2] = true;
-        join_dw(3);              // the previous block's dWqkv read dqkv, which this block's attention backward overwrites
+        CHECK(flush_dw(k));      // group k: dWqkv of block k + 1 (queued there), dW2, dW1, dWo of this block - one event each way
         // dO = dy . Wo
         g = GemmNTArgs{};
         g.A = dyp; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_proj_t); g.ldb = DP; g.M = R; g.N = HDP; g.K = DP; g.C = dO; g.ldc = HDP;
@@ -971,9 +999,7 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         t.Y = dqkv; t.ldy = 3 * HDP; t.X = z1; t.ldx = DP; t.M = R; t.NY = 3 * HDP; t.NX = DP; t.dW = grads + b.qkv; t.ldw = D;
         t.yseg_pad = h->HEP; t.yseg_valid = h->HE; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
         t.m_chunk = tp.mc_qkv;
-        CHECK(launch_dw(t, 3));  // reads dqkv, z1
-        dw_pending[3] = true;
-        join_dw(0);              // dW2 read dy, which the LayerNorm backward below overwrites (dy_next of the block before)
+        CHECK(launch_dw(t, 3));  // reads dqkv, z1: queued for the next block's group (the last block's: flushed behind the loop)
         // dz1 = dqkv . Wqkv
         g = GemmNTArgs{};
         g.A = dqkv; g.lda = 3 * HDP; g.B = (const bf16_t*)(sh + b.s_qkv_t); g.ldb = 3 * HDP; g.M = R; g.N = DP; g.K = 3 * HDP; g.C = dz; g.ldc = DP;
@@ -983,21 +1009,26 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         lb.gin = G; lb.gout = G; lb.dgamma = grads + b.ln1w; lb.dbeta = grads + b.ln1b;
         lb.dinject = h->inject ? dbeta + (size_t)k * B * DP : nullptr;
         if (k > 0) {
-            lb.dy_next = dy;
+            lb.dy_next = dy_prev;
             lb.dbias_next = h->blk[k - 1].fc2b >= 0 ? grads + h->blk[k - 1].fc2b : nullptr;
             lb.drop_next = make_drop(train, h->c.t_dropout, seed, 8 * (k - 1) + 3);
             lb.scale_next = path_scale ? path_scale + (size_t)(2 * (k - 1) + 1) * B : nullptr;
         }
         lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
         CHECK(dx_then_ln_bwd(g, lb, s));
-        // every gradient of block k's attention / MLP parameters is now in `grads` (its BehaviorMLP's follow at the end)
-        if (block_done && block_done[k]) {  // the block's gradients are complete on `s`: its weight-gradient GEMMs joined
-            for (int j = 0; j < 4; ++j) join_dw(j);
+        // every gradient of block k's attention / MLP parameters is now enqueued (its BehaviorMLP's follow at the end); single-stream mode:
+        // they are complete on `s` here. Second-stream mode: the block's completion event is recorded once its groups are joined (above)
+        if (!dw_side && block_done && block_done[k]) {
             if (hipEventRecord((hipEvent_t)block_done[k], s) != hipSuccess) return V1T_ERR_LAUNCH;
         }
     }
-    for (int j = 0; j < 4; ++j) join_dw(j);  // everything of the second stream is behind `s` from here on (slab region 0 is reused below)
+    CHECK(flush_dw(1));  // what is left in the queue: dWqkv of block 0 ("group -1": parity 1, group 1's events - joined at the start of block 0)
+    join_dw(0);
+    join_dw(1);  // everything of the second stream is behind `s` from here on (slab region 0 is reused below)
     if (join_err) return join_err;
+    if (dw_side && block_done)
+        for (int k = std::min(h->NB - 1, 1); k >= 0; --k)
+            if (block_done[k] && hipEventRecord((hipEvent_t)block_done[k], s) != hipSuccess) return V1T_ERR_LAUNCH;
     // ---- patch embedding backward (gin = grad wrt x0)
     PatchArgs pa{};
     pa.img = images; pa.B = B; pa.C = h->C; pa.IH = h->IH; pa.IW = h->IW; pa.P = h->P; pa.stride = h->S; pa.NH = h->NH; pa.NW = h->NW;

@@ -317,6 +317,36 @@ DEVFN void decode_block(const AttnArgs& a, int bid, int nblk, int& rb, int& h, i
     b = bh / a.H;
 }
 
+// The same for the forward kernel, whose last row block of every (image, head) is SHORT when T leaves at most half a block (T = 1654: 118 of
+// 256 queries, waves 4-7 only stage K / V): inside each XCD's chunk of logical ids the full blocks are dispatched first and the short ones
+// last (longest-processing-time order), so the tail of the launch is made of half-length workgroups. The hardware hands out workgroups in
+// blockIdx order as CUs free up; with the short block in every seventh position the last round was mostly full-length ones - at a rank's
+// share of a 4-GPU step (784 workgroups for 256 CUs) 3.06 rounds ran as ~3.7 (round 5).
+DEVFN void decode_block_lpt(const AttnArgs& a, int bid, int nblk, int& rb, int& h, int& b, int rows_per_block) {
+    const int nrb = (a.T + rows_per_block - 1) / rows_per_block;
+    const int rem = a.T - (nrb - 1) * rows_per_block;
+    int lid;
+    if (nrb < 2 || 2 * rem > rows_per_block) {
+        lid = xcd_remap(bid, nblk);
+    } else {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;  // xcd_remap: this XCD owns logical ids [base, base + n)
+        const int n = q + (xcd < r ? 1 : 0);
+        const int s0 = base / nrb, s1 = (base + n) / nrb;  // short ids (== nrb - 1 mod nrb) below the chunk / below its end
+        const int nfull = n - (s1 - s0);
+        if (k < nfull) {
+            const int m = base - s0 + k;  // rank among ALL full ids
+            lid = m + m / (nrb - 1);
+        } else {
+            lid = (s0 + k - nfull) * nrb + nrb - 1;
+        }
+    }
+    rb = lid % nrb;
+    const int bh = lid / nrb;
+    h = bh % a.H;
+    b = bh / a.H;
+}
+
 // ------------------------------------------------------------------------------------------
 constexpr int FWD_WAVES = 8;  // 256 queries per workgroup share each K/V tile: half the LDS-DMA pieces per wave of a 4-wave workgroup
 template <int DP, bool DROP, bool DIAG, bool STAGGER = false>
@@ -330,7 +360,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     __shared__ __attribute__((aligned(16))) bf16_t sV[2][DmaV::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, h, b;
+#ifdef V1T_FWD_NO_LPT
     decode_block(a, blockIdx.x, gridDim.x, rb, h, b, 32 * FWD_WAVES);
+#else
+    decode_block_lpt(a, blockIdx.x, gridDim.x, rb, h, b, 32 * FWD_WAVES);
+#endif
     const int q = rb * (32 * FWD_WAVES) + 32 * wave + (lane & 31);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
@@ -2132,6 +2166,131 @@ __global__ __launch_bounds__(256, 1) void rollout_headmax_kernel(AttnArgs a, flo
     if (!PH && qok && h2 == 0) rowsum[(size_t)b * a.T + q] = rs + 1.0f;
 }
 
+// The head-max map with TWO waves per SIMD (round 5). The 4-wave kernel above keeps the Q fragments of all HH heads in registers (330 VGPRs
+// at head dim 160 and 4 heads): one wave per SIMD, whose 40 MFMAs, 64 exponentials, LDS-DMA issue and stores per 32-key tile run one after
+// the other (~5800 cycles per tile, 1.96 ms per 256-image launch, with the matrix pipe ~22 % busy). Here a workgroup still owns 128 query
+// rows but has 8 waves: waves 0-3 ("group 0") compute heads [0, HH/2), waves 4-7 heads [HH/2, HH) of the SAME 32 queries each - half the Q
+// fragments per wave, so two waves fit a SIMD and one group's exponentials overlap the other's MFMAs. Group 1 hands its partial maximum
+// (16 floats per lane) to its group-0 partner through a double-buffered LDS block; group 0 finishes tile kt - 1 (maximum, masking, row sum,
+// staged 128-B row stores) at the start of iteration kt, behind the barrier that published it. K tiles of all heads are staged by all 8
+// waves. Same results bit for bit (max is exact and order-free; the row sums add the same values in the same order).
+template <int DP, int HH>
+__global__ __launch_bounds__(512, 1) void rollout_headmax8_kernel(AttnArgs a, float* A, int TP, float* rowsum) {
+    static_assert(HH % 2 == 0, "two head groups");
+    using G = Geo<DP>;
+    using Dma = TileDma<DP, G::RSTR, 32, 8>;
+    constexpr int HG = HH / 2, HS = 36;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][HH][Dma::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) float sX[2][4][64 * 16];  // group 1 -> group 0: [tile parity][query wave][lane][16]
+    __shared__ __attribute__((aligned(16))) float sOut[4][32 * HS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 128 + 32 * w4 + (lane & 31);
+    const int h2 = lane >> 5;
+    const int HD = HH * DP;
+    const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
+    Dma dma;
+    dma.init(lane, wave, a.ldqkv);
+    const bool qok = q < a.T;
+    bf16x8 qf[HG][G::KS];
+    float cs[HG], nl[HG];
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh) {
+        const int h = grp * HG + hh;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            u32x4 t = qok ? *(const u32x4*)(qkv_b + (size_t)q * a.ldqkv + h * DP + 16 * ks + 8 * h2) : u32x4{0, 0, 0, 0};
+            qf[hh][ks] = *(bf16x8*)&t;
+        }
+        cs[hh] = a.scale[a.scale_per_head ? h : 0] * LOG2E;
+        nl[hh] = -a.lse2[((size_t)b * HH + h) * a.T + (qok ? q : 0)];
+    }
+    const int koff = (lane & 31) * G::RSTR + 8 * h2;
+    const int nt = (a.T + 31) / 32;
+    float rs = 0.f;
+    auto stage = [&](int t, int buf) {
+#pragma unroll
+        for (int h = 0; h < HH; ++h) dma.issue(qkv_b + HD + h * DP, 32 * t, a.T, sK[buf][h]);
+    };
+    // group 0: combine its own maximum of tile kt with group 1's, mask, add to the row sums, write the tile out as 128-B row segments
+    f32x16 mine;
+    zero16(mine);
+    auto finish = [&](int kt) {
+        const float* px = &sX[kt & 1][w4][lane * 16];
+        float* so = sOut[w4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 other = *(const f32x4*)(px + 4 * g);
+            const int key0 = 32 * kt + 8 * g + 4 * h2;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = key0 + j;
+                const bool dead = key >= a.T || (a.mask_diag && key == q);
+                o[j] = dead ? 0.f : fmaxf(mine[4 * g + j], other[j]);
+                rs += o[j];
+            }
+            *(f32x4*)(so + (lane & 31) * HS + 8 * g + 4 * h2) = o;
+        }
+        const int qw0 = blockIdx.x * 128 + 32 * w4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + (lane >> 3), kc = 32 * kt + 4 * (lane & 7);
+            const f32x4 o = *(const f32x4*)(so + row * HS + 4 * (lane & 7));
+#ifdef V1T_DEV_ABLATION_HM_NOSTORE  // timing-only ablation (garbage results): build.py refuses V1T_DEV_ABLATION* for the product library
+            if (qw0 + row < a.T && kc < TP && o[0] == 12345.f) *(f32x4*)(A + ((size_t)b * a.T + qw0 + row) * TP + kc) = o;
+#else
+            if (qw0 + row < a.T && kc < TP) *(f32x4*)(A + ((size_t)b * a.T + qw0 + row) * TP + kc) = o;
+#endif
+        }
+    };
+    stage(0, 0);
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh) {
+        touch(qf[hh]);
+        touch(cs[hh]);
+        touch(nl[hh]);
+    }
+    dma_wait_and_barrier();
+    for (int kt = 0; kt < nt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nt) stage(kt + 1, buf ^ 1);
+        if (grp == 0 && kt > 0) finish(kt - 1);  // published by the barrier that ended iteration kt - 1 (wave-uniform branch)
+        f32x16 amax;
+#pragma unroll
+        for (int hh = 0; hh < HG; ++hh) {
+            const int h = grp * HG + hh;
+            f32x16 sacc;
+            zero16(sacc);
+            const bf16_t* kp = &sK[buf][h][koff];
+            bf16x8 kfr[G::KS];
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) kfr[ks] = *(const bf16x8*)(kp + 16 * ks);
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) sacc = mfma32(kfr[ks], qf[hh][ks], sacc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = fast_exp2(fmaf(sacc[r], cs[hh], nl[hh]));
+                amax[r] = hh == 0 ? p : fmaxf(amax[r], p);
+            }
+        }
+        if (grp == 1) {
+            float* px = &sX[kt & 1][w4][lane * 16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(f32x4*)(px + 4 * g) = f32x4{amax[4 * g], amax[4 * g + 1], amax[4 * g + 2], amax[4 * g + 3]};
+        } else {
+            mine = amax;
+        }
+        dma_wait_and_barrier();
+    }
+    if (grp == 0) {
+        finish(nt - 1);
+        rs += __shfl_xor(rs, 32);
+        if (qok && h2 == 0) rowsum[(size_t)b * a.T + q] = rs + 1.0f;
+    }
+}
+
 // u[b][j] = sum_i w_i * (A[b][i][j] + delta_ij),  w_i = v[b][i] / rs[b][i]   (v == nullptr: v = e_0)
 __global__ __launch_bounds__(256) void rollout_vecmat_kernel(const float* A, const float* rowsum, const float* v, float* u, int T, int TP) {
     extern __shared__ __attribute__((aligned(16))) float sw[];
@@ -2300,6 +2459,16 @@ int launch_headmax_t(const AttnArgs& a, float* A, int TP, float* rowsum, int q_r
             default: return V1T_ERR_UNSUPPORTED;
         }
         return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+    }
+    // V1T_HEADMAX8=0 (dev, A/B): the 4-wave kernel also where the 8-wave one applies (an even head count at head dims >= 128, where the
+    // 4-wave kernel cannot fit two waves on a SIMD)
+    static const bool hm8 = !(std::getenv("V1T_HEADMAX8") && !atoi(std::getenv("V1T_HEADMAX8")));
+    if constexpr (DP >= 128) {
+        if (hm8 && (a.H == 2 || a.H == 4)) {
+            if (a.H == 2) hipLaunchKernelGGL((rollout_headmax8_kernel<DP, 2>), grid, dim3(512), 0, s, a, A, TP, rowsum);
+            else hipLaunchKernelGGL((rollout_headmax8_kernel<DP, 4>), grid, dim3(512), 0, s, a, A, TP, rowsum);
+            return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+        }
     }
     switch (a.H) {
         case 1: hipLaunchKernelGGL((rollout_headmax_kernel<DP, 1>), grid, dim3(256), 0, s, a, A, TP, rowsum); break;

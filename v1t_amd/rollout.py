@@ -138,9 +138,9 @@ def rollout_rows(core: ViTCore, images: torch.Tensor, behaviors: torch.Tensor, p
         v = u
         if return_headmax:
             maps.append(A[:, :, :T].clone())
-    if pipelined:
-        for t_ in As + rss:
-            t_.record_stream(side)  # written on the side stream: the allocator must not hand the memory out before that stream is past it
+    # (no record_stream for the buffers written on the side stream: the current stream has waited for every head-max launch - `ready` - so
+    # by stream order it is past all of the side stream's work when these tensors are freed; record_stream would make the caching allocator
+    # hold the 2 x 2.8 GB back until it has polled the side stream's events and map fresh segments meanwhile: 137-200 ms per call, measured)
     rows = v[:, 1:]
     return (rows, maps[::-1]) if return_headmax else rows
 
