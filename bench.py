@@ -339,14 +339,15 @@ class Watchdog:
     """Per-rank progress deadline. The 8-GPU run of this bench happens once, on hardware nobody can rehearse on: a rank
     that stops making progress - a collective that never completes, a rendezvous that never forms - must END the run instead of sitting in
     the library's timeout. `mark(phase)` records progress; a daemon thread exits the process with code 124 when no mark arrived for
-    V1T_BENCH_DEADLINE_S seconds (default 240: above the first RCCL initialisation of 8 ranks, far below the driver's budget). Under
+    V1T_BENCH_DEADLINE_S seconds (default 360: above a rendezvous of 8 ranks whose first `import torch` on a fresh box takes minutes and is not
+    equally fast on every rank, far below the driver's budget). Under
     torchrun or bench.py's own launcher a rank exiting non-zero terminates its siblings. `on_expire` (rank 0) gets a chance to print the
     failure line first."""
 
     def __init__(self, rank: int, on_expire=None):
         import threading
 
-        self.rank, self.deadline = rank, float(os.environ.get("V1T_BENCH_DEADLINE_S", "240"))
+        self.rank, self.deadline = rank, float(os.environ.get("V1T_BENCH_DEADLINE_S", "360"))
         self.phase, self.t, self.on_expire, self._stop = "start", time.monotonic(), on_expire, False
         self._th = threading.Thread(target=self._run, daemon=True)
         self._th.start()
@@ -442,7 +443,7 @@ def dry_run(a) -> int:
     if world > 1:
         import datetime
 
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(os.environ.get("V1T_DIST_TIMEOUT_S", "120"))))
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(os.environ.get("V1T_DIST_TIMEOUT_S", "300"))))
         wd.mark("all-reduce")
         dist.all_reduce(seen, op=dist.ReduceOp.SUM)
         dist.barrier()

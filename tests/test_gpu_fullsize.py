@@ -205,14 +205,16 @@ def test_gemm_nt_large_m(dev, M, N, K):
     check_rel("test_gemm_nt_large_m:2", Cb[-4096:].float(), A[-4096:].float() @ Bf, 4e-3)
 
 
-@pytest.mark.parametrize("p", [0.0, 0.2544])
-def test_attention_112_images(dev, p):
+@pytest.mark.parametrize("p,B", [(0.0, 112), (0.2544, 112), (0.2544, 14), (0.2544, 28)])
+def test_attention_112_images(dev, p, B):
     """The 112-image attention launches of the bench (B*H = 448, T = 1654, head dim 160) against fp32 torch attention with
-    the kernels' own dropout mask replayed (v1t_dropout_mask), forward and backward (materialised-dS' path)."""
+    the kernels' own dropout mask replayed (v1t_dropout_mask), forward and backward (materialised-dS' path). B = 14 / 28: a rank's
+    share of an 8- / 4-GPU step, where the forward covers an (image, head) with 4 full + 5 half row blocks / dispatches the natural
+    cover longest-first (attention.hip: choose_fwd_split, decode_fwd)."""
     from v1t_amd import lib as L
 
     lib = L.load()
-    B, H, T, DP = 112, 4, 1654, 160
+    H, T, DP = 4, 1654, 160
     g = torch.Generator().manual_seed(7)
     qkv = torch.zeros(B * T, 3 * H * DP)
     qkv.view(B * T, 3 * H, DP)[:, :, :155] = torch.randn(B * T, 3 * H, 155, generator=g) * 0.7  # pad columns are zero, as in the model
@@ -238,8 +240,9 @@ def test_attention_112_images(dev, p):
         mask = torch.empty(B * H * T, T, device=dev, dtype=torch.uint8)
         L.check(lib.v1t_dropout_mask(seed, sid, p, B * H * T, T, mask.data_ptr(), L.stream()))
         mask = mask.view(B, H, T, T)
-    CH = 8
-    for b0 in list(range(0, B, CH))[:: (1 if p == 0 else 2)]:  # every chunk without dropout, every other one with
+    CH0 = 8
+    for b0 in list(range(0, B, CH0))[:: (1 if (p == 0 or B < 112) else 2)]:  # every chunk without dropout / of the small launches, every other one else
+        CH = min(CH0, B - b0)
         x = qkv.view(B, T, 3 * H * DP)[b0:b0 + CH].float().requires_grad_(True)
         q, k, v = x.view(CH, T, 3, H, DP).permute(2, 0, 3, 1, 4)
         a = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1)
@@ -247,11 +250,11 @@ def test_attention_112_images(dev, p):
             a = a * mask[b0:b0 + CH].float() / (1 - p_eff)
         ref = (a @ v).permute(0, 2, 1, 3).reshape(CH, T, H * DP)
         got = o.view(B, T, H * DP)[b0:b0 + CH].float()
-        check_rel(f"test_attention_112_images:" + str(b0), got, ref.detach(), 1e-2)
+        check_rel(f"test_attention_112_images[B={B}]:" + str(b0), got, ref.detach(), 1e-2)
         (gx,) = torch.autograd.grad(ref, x, dO.view(B, T, H * DP)[b0:b0 + CH].float())
         gx, d = gx.view(CH * T, 3, H * DP), dqkv.view(B, T, 3 * H * DP)[b0:b0 + CH].float().view(CH * T, 3, H * DP)
         for i, nm in enumerate("qkv"):
-            check_rel(f"test_attention_112_images:" + str((b0, nm)), d[:, i], gx[:, i], 1e-2)
+            check_rel(f"test_attention_112_images[B={B}]:" + str((b0, nm)), d[:, i], gx[:, i], 1e-2)
         del x, q, k, v, a, ref, gx
 
 

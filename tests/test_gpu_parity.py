@@ -743,6 +743,60 @@ def test_native_step_losses_do_not_alias_and_fallback_warns(dev):
     assert tr2.last_step_path == "batched-autograd"
 
 
+def test_fused_adamw_for_model_equals_torch_adamw_in_the_reference_loop(dev):
+    """The opt-in optimizer of the drop-in path: the reference's loop (train.py:42-116: per mouse forward, criterion, (micro / batch) *
+    model.regularizer, backward; then optimizer.step(), zero_grad()) run twice from the same weights and the same dropout seeds - once with
+    `torch.optim.AdamW(model.get_parameters(core_lr), ...)` as train.py:216-223 builds it, once with `v1t_amd.FusedAdamW.for_model` - must
+    leave the same parameters after 3 steps (same fp32 arithmetic; 1e-6 relative to each tensor's max), including a step in which one mouse
+    is NOT visited (torch skips parameters without a gradient; the fused optimizer skips the mouse through the readout's visit mark)."""
+    import v1t_amd
+    from v1t_amd.losses import PoissonLoss
+    from v1t_amd.synthetic import make_ds
+
+    cfg = O.Config(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=2, mouse_ids=("A", "B", "C"), num_neurons={"A": 150, "B": 77, "C": 64}, patch_stride=2)
+    sd = W.make_state_dict(cfg, 31)
+    finals = []
+    for kind in ("torch", "fused"):
+        model, args = build_native_model(cfg, sd, dev)
+        model.train(True)
+        core_lr = float(args.lr) * 0.5
+        if kind == "torch":
+            opt = torch.optim.AdamW(params=model.get_parameters(core_lr=core_lr), lr=args.lr, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_eps, weight_decay=0)
+        else:
+            opt = v1t_amd.FusedAdamW.for_model(model, lr=args.lr, core_lr=core_lr, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_eps)
+        crit = PoissonLoss(args, make_ds(cfg.num_neurons))
+        opt.zero_grad()
+        for step in range(3):
+            mice = ("A", "B") if step == 1 else cfg.mouse_ids  # step 1 leaves mouse C untouched
+            for m in mice:
+                b = {k: v.to(dev) for k, v in W.make_batch(cfg, m, 4, 500 + step).items()}
+                eps = W.make_eps(cfg, m, 4, 500 + step).to(dev)
+                ro = model.readouts[m]
+                z = model.core(model.image_cropper(b["image"], m, b["behavior"], b["pupil_center"])[0], mouse_id=m, behaviors=b["behavior"], pupil_centers=b["pupil_center"])
+                y = model.elu1(ro(z, shifts=model.core_shifter(b["pupil_center"], mouse_id=m), eps=eps))
+                loss = crit(y_true=b["response"], y_pred=y, mouse_id=m, batch_size=4)
+                (loss + 1.0 * model.regularizer(m)).backward()
+            opt.step()
+            opt.zero_grad()
+        torch.cuda.synchronize()
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items() if v.is_floating_point()})
+    a, b_ = finals
+    moved, worst_frac, worst_mean = 0, 0.0, 0.0
+    lr = float(args.lr)
+    for k in a:
+        d = (b_[k] - a[k]).abs().float()
+        # Adam's normalised update moves an element by ~lr per step whatever its gradient's size, so an element whose gradient sits at the
+        # level of the float-atomic summation order (the two runs execute the same kernels, but atomics commute only up to rounding) may step
+        # the other way: bound the FRACTION of such elements and the mean deviation instead of the maximum
+        frac, mean = float((d > 0.25 * lr).float().mean()), float(d.mean())
+        worst_frac, worst_mean = max(worst_frac, frac), max(worst_mean, mean)
+        assert frac <= 5e-3 and mean <= 0.02 * lr, f"{k}: {100 * frac:.3f} % of the elements differ by more than lr / 4, mean deviation {mean:.3e}"
+        moved += int(float((a[k].cpu() - sd[k]).abs().max()) > 0) if k in sd else 0
+    record_margin("FusedAdamW.for_model vs torch.optim.AdamW: worst fraction of elements off by > lr/4", worst_frac, 5e-3)
+    record_margin("FusedAdamW.for_model vs torch.optim.AdamW: worst mean deviation", worst_mean, 0.02 * lr)
+    assert moved >= 30, moved  # the steps really moved the parameters
+
+
 def test_native_step_eps_statistics(dev):
     """The in-kernel position noise (v1t_normal_fill, Box-Muller over the counter hash) is standard normal, differs from step to
     step and from mouse to mouse, and is reproducible for a given (seed, stream)."""

@@ -37,13 +37,18 @@ def step_time(sh, steps=6, warm=2):
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.train_step(batches)
+    HOST.append((time.perf_counter() - t0) / steps * 1e3)  # the host's own time per step (enqueue only: nothing in a step synchronises)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+HOST = []
+
+
 if os.environ.get("SIM_ONLY"):  # "world,rank": that rank's share only, 7 steps (for rocprofv3 --kernel-trace --stats / tools/prof_top.py)
     w_, r_ = (int(x) for x in os.environ["SIM_ONLY"].split(","))
-    print(f"world {w_} rank {r_}: {step_time(NoComm(MICE, r_, w_, args.batch_size, make_groups=False), steps=5, warm=2):.2f} ms")
+    t_ = step_time(NoComm(MICE, r_, w_, args.batch_size, make_groups=False), steps=int(os.environ.get("SIM_STEPS", "5")), warm=2)
+    print(f"world {w_} rank {r_}: {t_:.2f} ms (host enqueue time per step {HOST[-1]:.2f} ms)")
     sys.exit(0)
 base = step_time(NoComm(MICE, 0, 1, args.batch_size, make_groups=False))
 print(f"world 1: {base:.2f} ms")

@@ -45,7 +45,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # dev: V1T_BUILD_LIB=libv1t_amd_x.so builds a second library next to the product one (its own objects; V1T_HIPCC_EXTRA flags),
     # loaded with V1T_LIB=libv1t_amd_x.so - A/B experiments and the in-kernel probe builds
     alt = os.environ.get("V1T_BUILD_LIB", "")
-    if not alt and any("V1T_DEV_ABLATION" in f for f in EXTRA):
+    ablation = ("V1T_DEV_ABLATION", "V1T_F3_", "V1T_B2_")
+    if not alt and any(any(a in f for a in ablation) for f in EXTRA):
         # timing-only ablations compile pieces of kernels out and return garbage: never into the product library
         raise RuntimeError("V1T_DEV_ABLATION* flags build experiment libraries only: set V1T_BUILD_LIB=libv1t_amd_<name>.so")
     lib_path = os.path.join(LIBDIR, alt) if alt else LIB

@@ -18,6 +18,10 @@ struct AttnArgs {
     int scale_per_head;
     int mask_diag;                 // LSA: exclude key == query
     AttnDrop adrop;                // P dropout (2x2-block hash, 8-bit rate; common.h)
+    // forward only, set by its launcher: the queries of an (image, head) are covered by fwd_full 256-query row blocks followed by fwd_half
+    // 128-query ones (half blocks: waves 4-7 hold no query and only stage K / V); fwd_lpt: full blocks dispatched before half blocks inside
+    // each XCD's chunk of the grid
+    int fwd_full, fwd_half, fwd_lpt;
     // backward only
     const bf16_t* dO; int lddo;    // [rows][H*DP]
     const float* delta;            // [B][H][T] keep_prob * rowsum(dO * O)

@@ -27,6 +27,13 @@
 #include <cstdlib>
 #include "attention.h"
 
+// Timing-only ablations compile pieces of kernels out and return GARBAGE (V1T_F3_* of the 16-wave forward experiment, V1T_B2_* of the dK/dV
+// kernel, V1T_DEV_ABLATION_* of round 5): they are accepted only together with -DV1T_DEV_ABLATION, which v1t_amd/build.py refuses to pass
+// when it builds the product library (only `V1T_BUILD_LIB=libv1t_amd_<experiment>.so` builds may carry it).
+#if (defined(V1T_F3_NODMA) || defined(V1T_F3_NOLDS) || defined(V1T_F3_STUB) || defined(V1T_B2_NODMA) || defined(V1T_B2_NOFRAG) || defined(V1T_B2_NOVALU) || \
+     defined(V1T_B2_NOSTORE) || defined(V1T_B2_NOKEEP) || defined(V1T_DEV_ABLATION_HM_NOSTORE)) && !defined(V1T_DEV_ABLATION)
+#error "timing-only ablation macros need -DV1T_DEV_ABLATION (experiment libraries only: V1T_BUILD_LIB=... python -m v1t_amd.build)"
+#endif
 #ifdef V1T_KPROF
 // dev-only in-kernel timeline (tools/kprof.py): s_memtime stamps of one workgroup's waves, KP_T0 <= tile < KP_T0 + KP_NT
 #define KP_T0 8
@@ -317,34 +324,40 @@ DEVFN void decode_block(const AttnArgs& a, int bid, int nblk, int& rb, int& h, i
     b = bh / a.H;
 }
 
-// The same for the forward kernel, whose last row block of every (image, head) is SHORT when T leaves at most half a block (T = 1654: 118 of
-// 256 queries, waves 4-7 only stage K / V): inside each XCD's chunk of logical ids the full blocks are dispatched first and the short ones
-// last (longest-processing-time order), so the tail of the launch is made of half-length workgroups. The hardware hands out workgroups in
-// blockIdx order as CUs free up; with the short block in every seventh position the last round was mostly full-length ones - at a rank's
-// share of a 4-GPU step (784 workgroups for 256 CUs) 3.06 rounds ran as ~3.7 (round 5).
-DEVFN void decode_block_lpt(const AttnArgs& a, int bid, int nblk, int& rb, int& h, int& b, int rows_per_block) {
-    const int nrb = (a.T + rows_per_block - 1) / rows_per_block;
-    const int rem = a.T - (nrb - 1) * rows_per_block;
-    int lid;
-    if (nrb < 2 || 2 * rem > rows_per_block) {
-        lid = xcd_remap(bid, nblk);
+// Forward kernel: the 1654 queries of an (image, head) as F full row blocks (256 queries, 8 waves) followed by Hh half blocks (128 queries:
+// waves 4-7 hold no query and only stage K / V, so the block takes ~2/3 of a full one's time). The launcher (choose_fwd_split) picks (F, Hh):
+// by default the natural cover (T = 1654: 6 full + the 118-query remainder as one half block); for small launches the cover whose
+// list-scheduled makespan on the 32 CUs of an XCD is shortest (14 images: 4 full + 5 half per (image, head) = 1.67 rounds instead of 2).
+// With `lpt` the full blocks of an XCD's chunk of logical ids are dispatched before its half blocks (longest processing time first): the
+// hardware hands out workgroups in blockIdx order as CUs free up, so the tail of the launch is then made of the short workgroups.
+// Logical id = (image * H + head) * (F + Hh) + block; XCD-aware as decode_block (each XCD owns a contiguous chunk of ids).
+DEVFN void decode_fwd(const AttnArgs& a, int bid, int nblk, int& q0, int& q_end, int& h, int& b) {
+    const int F = a.fwd_full, Hh = a.fwd_half, nrb = F + Hh;
+    int bh, i;
+    if (!a.fwd_lpt || Hh == 0 || F == 0) {
+        const int lid = xcd_remap(bid, nblk);
+        bh = lid / nrb;
+        i = lid - bh * nrb;
     } else {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
         const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;  // xcd_remap: this XCD owns logical ids [base, base + n)
         const int n = q + (xcd < r ? 1 : 0);
-        const int s0 = base / nrb, s1 = (base + n) / nrb;  // short ids (== nrb - 1 mod nrb) below the chunk / below its end
-        const int nfull = n - (s1 - s0);
+        auto fulls_below = [&](int x) { return (x / nrb) * F + min(x % nrb, F); };  // full blocks among the logical ids [0, x)
+        const int f0 = fulls_below(base), nfull = fulls_below(base + n) - f0;
         if (k < nfull) {
-            const int m = base - s0 + k;  // rank among ALL full ids
-            lid = m + m / (nrb - 1);
+            const int m = f0 + k;  // the m-th full block of the launch
+            bh = m / F;
+            i = m - bh * F;
         } else {
-            lid = (s0 + k - nfull) * nrb + nrb - 1;
+            const int j = (base - f0) + (k - nfull);  // the j-th half block of the launch
+            bh = j / Hh;
+            i = F + (j - bh * Hh);
         }
     }
-    rb = lid % nrb;
-    const int bh = lid / nrb;
     h = bh % a.H;
     b = bh / a.H;
+    q0 = i < F ? 256 * i : 256 * F + 128 * (i - F);
+    q_end = min(a.T, q0 + (i < F ? 256 : 128));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -359,13 +372,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][DmaK::LDS_ELEMS];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2][DmaV::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int rb, h, b;
-#ifdef V1T_FWD_NO_LPT
-    decode_block(a, blockIdx.x, gridDim.x, rb, h, b, 32 * FWD_WAVES);
-#else
-    decode_block_lpt(a, blockIdx.x, gridDim.x, rb, h, b, 32 * FWD_WAVES);
-#endif
-    const int q = rb * (32 * FWD_WAVES) + 32 * wave + (lane & 31);
+    int q0, q_end, h, b;
+    decode_fwd(a, blockIdx.x, gridDim.x, q0, q_end, h, b);
+    const int q = q0 + 32 * wave + (lane & 31);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     bf16x8 qf[G::KS];
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) {
-        u32x4 t = (q < a.T) ? *(const u32x4*)(qkv_b + (size_t)q * a.ldqkv + h * DP + 16 * ks + 8 * h2) : u32x4{0, 0, 0, 0};
+        u32x4 t = (q < q_end) ? *(const u32x4*)(qkv_b + (size_t)q * a.ldqkv + h * DP + 16 * ks + 8 * h2) : u32x4{0, 0, 0, 0};
         qf[ks] = *(bf16x8*)&t;
     }
     f32x16 o[G::DB];
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     // A wave whose 32 queries all lie beyond T (T = 1654: waves 4-7 of every (image, head)'s 7th workgroup) only stages its share of
     // K / V and keeps the barriers: its SIMD partner then has the matrix pipe and the issue port to itself, the ragged workgroup
     // finishes in ~2/3 of the time and the grid (12.25 rounds of equal workgroups = 13) desynchronises into ~12.
-    const bool dead_wave = rb * (32 * FWD_WAVES) + 32 * wave >= a.T;  // wave-uniform
+    const bool dead_wave = q0 + 32 * wave >= q_end;  // wave-uniform
     KP_DECL;
     // A 32-key tile in two parts. part_a: S^T = K Q^T (all K fragments in flight, then the chain) and the transposed V fragments,
     // issued behind the chain's MFMAs so that they land while the softmax runs; everything it reads from LDS is in registers when
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
 
     const float ltot = lsum + __shfl_xor(lsum, 32);
     const float inv = (DROP ? a.adrop.inv_keep : 1.0f) / ltot;
-    if (q < a.T) {
+    if (q < q_end) {
         if (h2 == 0) a.lse2[((size_t)b * a.H + h) * a.T + q] = m2 + log2f(ltot);
         const size_t orow = ((size_t)b * a.T + q) * a.ldo + h * DP;
 #pragma unroll
@@ -1266,9 +1275,63 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
     }
 }
 
+// How the forward kernel covers the queries of an (image, head): `full` 256-query row blocks + `half` 128-query ones (decode_fwd).
+// Natural cover: floor(T / 256) full blocks and the remainder as one more full block, or as ONE half block when it is at most 128 queries
+// (T = 1654: 6 + 1). Small launches (at most 1152 workgroups that way) may do better with fewer full and more half blocks: the launch is a few
+// rounds of one-workgroup-per-CU workgroups and ends when the last CU does; candidates (F, ceil((T - 256 F) / 128)) are list-scheduled,
+// longest first, on the 32 CUs of the fullest XCD with a half block at 0.67 of a full one (measured: the ragged block of round 3), and the
+// shortest makespan wins when it beats the natural cover by 5 % (ties: fewer half blocks - each stages the whole K / V for half the queries).
+// 14 images x 4 heads: natural 6 + 1 = two rounds; 4 + 5 = 1.67 (attn_fwd 138 -> 128 us per launch, profiles/r05_small_launch_experiments.txt);
+// 16 and 28 images keep the natural cover (16: 2.0 either way; 28: 3.0 with LPT order against 3.34). V1T_FWD_SPLIT=0 (dev): natural cover.
+static void choose_fwd_split_uncached(int B, int H, int T, int& F, int& Hh, int& lpt);
+static void choose_fwd_split(int B, int H, int T, int& F, int& Hh, int& lpt) {
+    // one decision per launch shape and thread (the list scheduling below costs the host ~40 us, four launches per step)
+    thread_local int key[3] = {-1, -1, -1}, val[3] = {0, 0, 0};
+    if (key[0] != B || key[1] != H || key[2] != T) {
+        choose_fwd_split_uncached(B, H, T, val[0], val[1], val[2]);
+        key[0] = B; key[1] = H; key[2] = T;
+    }
+    F = val[0]; Hh = val[1]; lpt = val[2];
+}
+static void choose_fwd_split_uncached(int B, int H, int T, int& F, int& Hh, int& lpt) {
+    const int rem = T % 256;
+    const int F0 = T / 256 + (rem > 128 ? 1 : 0), H0 = (rem >= 1 && rem <= 128) ? 1 : 0;
+    F = F0; Hh = H0;
+    const int nblk0 = B * H * (F0 + H0);
+    lpt = (H0 && nblk0 >= 640 && nblk0 <= 1152) ? 1 : 0;  // measured (round 5): helps a 28-image launch, hurts at 14 and at 112 images
+    static const bool allow = !(std::getenv("V1T_FWD_SPLIT") && !atoi(std::getenv("V1T_FWD_SPLIT")));
+    if (!allow || nblk0 > 1152 || T <= 256) return;
+    const int nbh = (B * H + 7) / 8;  // (image, head) pairs of the fullest XCD
+    auto makespan = [&](int f, int hh) {
+        float cu[32];
+        for (float& x : cu) x = 0.f;
+        auto put = [&](int n, float cost) {
+            for (int i = 0; i < n; ++i) {
+                int m = 0;
+                for (int c = 1; c < 32; ++c) if (cu[c] < cu[m]) m = c;
+                cu[m] += cost;
+            }
+        };
+        put(nbh * f, 1.0f);
+        put(nbh * hh, 0.67f);
+        float ms = 0.f;
+        for (float x : cu) ms = std::max(ms, x);
+        return ms;
+    };
+    float best = makespan(F0, H0);
+    for (int f = F0 - 1; f >= std::max(0, F0 - 4); --f) {
+        const int hh = (T - 256 * f + 127) / 128;
+        const float ms = makespan(f, hh);
+        if (ms < 0.95f * best) { best = ms; F = f; Hh = hh; lpt = 1; }
+    }
+}
+
 template <int DP, bool DROP, bool DIAG>
-int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
-    dim3 grid(((a.T + 32 * FWD_WAVES - 1) / (32 * FWD_WAVES)) * a.H * a.B);
+int launch_fwd_t(const AttnArgs& a_in, hipStream_t s) {
+    AttnArgs a = a_in;
+    dim3 grid(((a.T + 32 * FWD_WAVES - 1) / (32 * FWD_WAVES)) * a.H * a.B);  // the natural cover (the experiment kernels below)
+    choose_fwd_split(a.B, a.H, a.T, a.fwd_full, a.fwd_half, a.fwd_lpt);
+    const dim3 grid_main((a.fwd_full + a.fwd_half) * a.H * a.B);
     prof_begin(PROF_ATTN_FWD, s);
     static const bool v3 = std::getenv("V1T_ATTN_FWD_V3") != nullptr;  // dev: the 16-wave S / PV role kernel
     if constexpr (DP >= 128 && !DIAG) {
@@ -1281,12 +1344,12 @@ int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
     static const bool stagger = std::getenv("V1T_ATTN_FWD_STAGGER") != nullptr;  // dev: A/B of the rotated second half
     if constexpr (DP >= 128 && !DIAG) {
         if (stagger) {
-            hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG, true>), grid, dim3(64 * FWD_WAVES), 0, s, a);
+            hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG, true>), grid_main, dim3(64 * FWD_WAVES), 0, s, a);
             prof_end(PROF_ATTN_FWD, s);
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG>), grid, dim3(64 * FWD_WAVES), 0, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG>), grid_main, dim3(64 * FWD_WAVES), 0, s, a);
     prof_end(PROF_ATTN_FWD, s);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
@@ -2178,7 +2241,11 @@ template <int DP, int HH>
 __global__ __launch_bounds__(512, 1) void rollout_headmax8_kernel(AttnArgs a, float* A, int TP, float* rowsum) {
     static_assert(HH % 2 == 0, "two head groups");
     using G = Geo<DP>;
-    using Dma = TileDma<DP, G::RSTR, 32, 8>;
+    // K tiles are staged by group 1's four waves ALONE: group 0 writes the finished tiles to HBM, and on this target loads and stores
+    // pending together retire vmcnt out of order, so a wave that does both can only wait with vmcnt(0) - i.e. for its STORES' round trip to
+    // HBM - at every tile end (44 % of the wave cycles were waits, SQ counters profiles/r05_pmc_headmax.txt). Split this way group 1's
+    // vmcnt(0) covers LDS-DMA only and group 0 never waits for memory: a store's data has left the registers when it is issued.
+    using Dma = TileDma<DP, G::RSTR, 32, 4>;
     constexpr int HG = HH / 2, HS = 36;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][HH][Dma::LDS_ELEMS];
     __shared__ __attribute__((aligned(16))) float sX[2][4][64 * 16];  // group 1 -> group 0: [tile parity][query wave][lane][16]
@@ -2191,7 +2258,7 @@ __global__ __launch_bounds__(512, 1) void rollout_headmax8_kernel(AttnArgs a, fl
     const int HD = HH * DP;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
     Dma dma;
-    dma.init(lane, wave, a.ldqkv);
+    dma.init(lane, w4, a.ldqkv);
     const bool qok = q < a.T;
     bf16x8 qf[HG][G::KS];
     float cs[HG], nl[HG];
@@ -2210,8 +2277,14 @@ __global__ __launch_bounds__(512, 1) void rollout_headmax8_kernel(AttnArgs a, fl
     const int nt = (a.T + 31) / 32;
     float rs = 0.f;
     auto stage = [&](int t, int buf) {
+        if (grp == 1) {  // wave-uniform
 #pragma unroll
-        for (int h = 0; h < HH; ++h) dma.issue(qkv_b + HD + h * DP, 32 * t, a.T, sK[buf][h]);
+            for (int h = 0; h < HH; ++h) dma.issue(qkv_b + HD + h * DP, 32 * t, a.T, sK[buf][h]);
+        }
+    };
+    auto tile_end = [&]() {
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this group's LDS-DMA of the next tile has landed
+        __syncthreads();
     };
     // group 0: combine its own maximum of tile kt with group 1's, mask, add to the row sums, write the tile out as 128-B row segments
     f32x16 mine;
@@ -2252,7 +2325,7 @@ __global__ __launch_bounds__(512, 1) void rollout_headmax8_kernel(AttnArgs a, fl
         touch(cs[hh]);
         touch(nl[hh]);
     }
-    dma_wait_and_barrier();
+    tile_end();
     for (int kt = 0; kt < nt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nt) stage(kt + 1, buf ^ 1);
@@ -2282,7 +2355,7 @@ __global__ __launch_bounds__(512, 1) void rollout_headmax8_kernel(AttnArgs a, fl
         } else {
             mine = amax;
         }
-        dma_wait_and_barrier();
+        tile_end();
     }
     if (grp == 0) {
         finish(nt - 1);

@@ -80,6 +80,7 @@ size_t gemm_tn_slab_bytes(int M, int NY, int NX, int m_chunk);
 
 int launch_gemm_nt(const GemmNTArgs& a, int epi, hipStream_t s);
 int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s);
+int launch_gemm_tn_group(const GemmTNArgs* a, int n, hipStream_t s);  // the GEMMs back to back, their slab reductions as ONE launch
 // LayerNorm(l) fused into C = LN(x) . B^T (fp16 operands, K = l.DP <= 160, N % 128 == 0; epi = EPI_BF16 | EPI_BIAS_GELU): g.A is
 // not read, l.z (bf16 plane), l.mean, l.rstd and l.xout are written, l.z_lo is not. V1T_ERR_UNSUPPORTED: use ln_fwd + gemm_nt.
 struct LnFwdArgs;

@@ -620,8 +620,12 @@ int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
     // its 83 KB of LDS leave one workgroup per CU. Measured on the whole step: 16-image launches (M = 26 k rows) 41.8 ->
     // 41.3 ms with the 64-wide tile, 112-image launches (M = 185 k) 3987 -> 4032 images/s with the 32-wide one (three
     // workgroups per CU hide more latency once there are enough of them): chosen by M.
+    // Round 5: "few rows" means AT MOST ONE ROUND of one-workgroup-per-CU launches. A 28-image launch (a rank's share of a 4-GPU step: 362
+    // row tiles) is under 65 536 rows too, but at one workgroup per CU it ran as two rounds, 106 of them in the second (proj 63 us against
+    // 25 us at 14 images and 110 us at 112): the 32-wide tile, three workgroups per CU, holds all of it at once.
     static const int force_bk = std::getenv("V1T_GEMM_BK") ? atoi(std::getenv("V1T_GEMM_BK")) : 0;  // dev switch
-    const bool bk64 = a.K % 64 == 0 && force_bk != 32 && (force_bk == 64 || a.M < 65536);
+    const long long tiles = (long long)((a.M + 127) / 128) * (a.N / (32 * NBLK));
+    const bool bk64 = a.K % 64 == 0 && force_bk != 32 && (force_bk == 64 || tiles <= 256);
     return bk64 ? launch_nt_nw<NBLK, 4, 64>(a, epi, s) : launch_nt_nw<NBLK, 4, 32>(a, epi, s);
 }
 
@@ -1065,10 +1069,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs g) {
 // read-modify-write: exactly one thread owns each output element). Thread = 4 accumulator registers of one
 // lane of one block: consecutive threads read consecutive 16 B of each chunk's slab.
 template <int YB, int XB>
-__global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTNArgs g, int gx, int gy, int gz) {
+DEVFN void tn_reduce_body(const GemmTNArgs& g, int gx, int gy, int gz, int bx_) {
     constexpr int WY = (YB == 1) ? 4 : 1, WX = 4 / WY;
     constexpr int YW = 32 * YB * WY, XW = 32 * XB * WX;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = bx_ * 256 + threadIdx.x;
     const int total = gx * gy * 4 * YB * XB * 256;
     if (t >= total) return;
     const int r4 = t & 3, lane = (t >> 2) & 63, rest = t >> 8;
@@ -1103,6 +1107,26 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTNArgs g, int gx, in
             else if (isb) g.dbias[ys * g.yseg_valid + yy] += s0[i] * g.alpha;
         }
     }
+}
+template <int YB, int XB>
+__global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTNArgs g, int gx, int gy, int gz) {
+    tn_reduce_body<YB, XB>(g, gx, gy, gz, blockIdx.x);
+}
+// The slab reductions of several weight-gradient GEMMs in ONE launch (round 5): a group of a block's GEMMs runs back to back on the second
+// stream (api.hip, flush_dw), so their reductions can follow as one launch instead of one behind every GEMM - 17 -> 5 launches per backward.
+constexpr int TN_MULTI = 4;
+struct TnReduceMulti {
+    GemmTNArgs g[TN_MULTI];
+    int gx[TN_MULTI], gy[TN_MULTI], gz[TN_MULTI], shape[TN_MULTI];  // shape 0: <5, 1>, 1: <1, 5>
+    int start[TN_MULTI + 1];                                        // prefix sums of the units' workgroup counts
+    int n;
+};
+__global__ __launch_bounds__(256) void tn_reduce_multi_kernel(TnReduceMulti m) {
+    int u = 0;
+    while (u + 1 < m.n && (int)blockIdx.x >= m.start[u + 1]) ++u;  // wave-uniform
+    const int bx = blockIdx.x - m.start[u];
+    if (m.shape[u] == 0) tn_reduce_body<5, 1>(m.g[u], m.gx[u], m.gy[u], m.gz[u], bx);
+    else tn_reduce_body<1, 5>(m.g[u], m.gx[u], m.gy[u], m.gz[u], bx);
 }
 
 
@@ -1476,22 +1500,35 @@ size_t gemm_tn_slab_bytes(int M, int NY, int NX, int m_chunk) {
 
 bool gemm_tn_takes_f16_x(int NY, int NX, int m_chunk) { return m_chunk % TN2_ROWS == 0 && NY % 160 == 0 && NX % 128 == 0 && NY <= 320; }
 
-int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s) {
+// `defer`: launch the GEMM only and describe its slab reduction in *defer (the caller runs launch_tn_reduce_group over several of them);
+// GEMMs without a slab, or of a shape without one, ignore it.
+static int launch_gemm_tn_impl(const GemmTNArgs& a, hipStream_t s, TnReduceMulti* defer) {
     if (a.NY % 32 != 0 || a.NX % 32 != 0 || a.m_chunk % 32 != 0 || (a.ldy % 8) || (a.ldx % 8)) return V1T_ERR_ARG;
     if (a.x_f16 && !gemm_tn_takes_f16_x(a.NY, a.NX, a.m_chunk)) return V1T_ERR_UNSUPPORTED;
     if (a.M <= 0) return V1T_OK;
     const int gz = (a.M + a.m_chunk - 1) / a.m_chunk;
+    auto reduce = [&](int shape, int gx, int gy2) {
+        if (!a.slab) return;
+        if (defer && defer->n < TN_MULTI) {
+            const int u = defer->n++;
+            defer->g[u] = a; defer->gx[u] = gx; defer->gy[u] = gy2; defer->gz[u] = gz; defer->shape[u] = shape;
+            defer->start[u + 1] = defer->start[u] + gx * gy2 * 20;
+            return;
+        }
+        if (shape == 0) hipLaunchKernelGGL((tn_reduce_kernel<5, 1>), dim3(gx * gy2 * 20), dim3(256), 0, s, a, gx, gy2, gz);
+        else hipLaunchKernelGGL((tn_reduce_kernel<1, 5>), dim3(gx * gy2 * 20), dim3(256), 0, s, a, gx, gy2, gz);
+    };
     if (a.m_chunk % TN2_ROWS == 0 && a.NY % 160 == 0 && a.NX % 128 == 0 && a.NY <= 320) {
         const int gx = a.NY / 160, gy2 = a.NX / 128;
         if (a.x_f16) hipLaunchKernelGGL((gemm_tn2_kernel<5, 1, true>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_tn2_kernel<5, 1>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
-        if (a.slab) hipLaunchKernelGGL((tn_reduce_kernel<5, 1>), dim3(gx * gy2 * 20), dim3(256), 0, s, a, gx, gy2, gz);
+        reduce(0, gx, gy2);
         return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
     }
     if (a.m_chunk % TN2_ROWS == 0 && a.NX % 160 == 0) {
         const int gx = (a.NY + 127) / 128, gy2 = a.NX / 160;
         hipLaunchKernelGGL((gemm_tn2_kernel<1, 5>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
-        if (a.slab) hipLaunchKernelGGL((tn_reduce_kernel<1, 5>), dim3(gx * gy2 * 20), dim3(256), 0, s, a, gx, gy2, gz);
+        reduce(1, gx, gy2);
         return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
     }
     const int gy = (a.NY + 127) / 128;
@@ -1503,4 +1540,20 @@ int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s) {
     else TN_LAUNCH(1);
 #undef TN_LAUNCH
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s) { return launch_gemm_tn_impl(a, s, nullptr); }
+// n GEMMs (distinct slab regions) back to back on `s`, then ONE launch for all their slab reductions
+int launch_gemm_tn_group(const GemmTNArgs* a, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += TN_MULTI) {
+        TnReduceMulti m{};
+        for (int i = i0; i < std::min(n, i0 + TN_MULTI); ++i) {
+            const int rc = launch_gemm_tn_impl(a[i], s, &m);
+            if (rc) return rc;
+        }
+        if (m.n > 0) {
+            hipLaunchKernelGGL(tn_reduce_multi_kernel, dim3(m.start[m.n]), dim3(256), 0, s, m);
+            if (hipGetLastError() != hipSuccess) return V1T_ERR_LAUNCH;
+        }
+    }
+    return V1T_OK;
 }
