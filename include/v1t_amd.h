@@ -13,7 +13,7 @@
  * memory is allocated inside a launch function (workspaces are sized by the *_bytes queries and passed in; the measurement aid
  * v1t_mfma_peak_probe is the one exception); all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
  * v1t_vit_backward(_events) additionally owns one internal stream per plan (created by its first small launch, destroyed with the plan) on which
- * the weight-gradient GEMMs of launches below 65 536 rows run, joined to `stream` by events before the call returns its last launch.
+ * the weight-gradient GEMMs of launches below 131 072 rows run, joined to `stream` by events before the call returns its last launch.
  * Return value 0 = ok, negative = error code below (the Python shim raises RuntimeError, which the reference's OOM probe utils/utils.py:460
  * relies on). Thread-safe for distinct handles; calls on ONE handle must be serialised by the caller (the plan owns the second stream and
  * the events of its backward, created on first use on the device that is current then: two backward calls on the same plan from two threads

@@ -111,6 +111,16 @@ def test_install_into_reference_builds_native_classes_in_reference_model(g12):
             rec._register_hook()
             assert len(rec.hooks) == cfg.num_blocks and len(model.core._hooked_taps()) == cfg.num_blocks
             assert rec.eject() is model.core and model.core._hooked_taps() == []
+            # the opt-in fused optimizer binds to the REFERENCE's Model (which has none of v1t_amd.Model's helper methods): same groups,
+            # in the same order, as torch.optim.AdamW over model.get_parameters() (train.py:216-223); zero_grad() attaches every parameter's
+            # .grad as a view of its flat gradient arena
+            fo = v1t_amd.FusedAdamW.for_model(model, lr=1e-3, core_lr=5e-4)
+            to = torch.optim.AdamW(params=model.get_parameters(core_lr=5e-4), lr=1e-3)
+            assert [g_["name"] for g_ in fo.param_groups] == [g_["name"] for g_ in to.param_groups]
+            assert [len(g_["params"]) for g_ in fo.param_groups] == [len(g_["params"]) for g_ in to.param_groups]
+            assert [g_["lr"] for g_ in fo.state_dict()["param_groups"]] == [g_["lr"] for g_ in to.state_dict()["param_groups"]]
+            fo.zero_grad()
+            assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in model.parameters() if p.requires_grad)
             # weights written for the reference load into it (same keys and shapes) ...
             res = model.load_state_dict(W.make_state_dict(cfg, 3), strict=False)
             assert not res.unexpected_keys and set(res.missing_keys) <= {"image_cropper.grid", "elu1.one"}

@@ -211,11 +211,15 @@ static bool x16_gelu_out(const v1t_vit* h, long long R) {
     return !g_keep_bf16 && g_fwd_f16 && !(g_nosplit & 8) && gemm_tn_takes_f16_x(h->DP, h->MP, tn_plan(h, R).mc_fc2);
 }
 
-// Weight-gradient GEMMs beside the dX GEMMs on a second stream (backward, below): for launches under 65 536 rows, or as V1T_DW_SIDE=0 / 1
-// forces (dev). One place decides for the scratch layout (four slab regions instead of one) and for the backward.
+// Weight-gradient GEMMs on a second stream beside the main stream's kernels (backward, below): for launches under 131 072 rows, or as
+// V1T_DW_SIDE=0 / 1 forces (dev). One place decides for the scratch layout (four slab regions, second dqkv) and for the backward.
+// Round 5, with the hand-over once per block (same call, on / off): 14 images 3.46-3.49 vs 3.63-3.64 ms per step, 28 images 6.05-6.15 vs
+// 6.20-6.22, 56 images 11.08-11.23 vs 11.29-11.38, 112 images 20.79-20.89 vs 20.99-21.00 (bench.py, three runs each). At 112 images the
+// 0.7 % come with the dK/dV kernel sharing the chip (1.63 -> 1.82 ms per launch live): the single-GPU step keeps one stream, so that the
+// bench line's dominant-kernel time stays that kernel's own.
 static bool dw_side_for(long long R) {
     static const int dw_force = std::getenv("V1T_DW_SIDE") ? atoi(std::getenv("V1T_DW_SIDE")) : -1;
-    return dw_force >= 0 ? dw_force > 0 : R < 65536;
+    return dw_force >= 0 ? dw_force > 0 : R < 131072;
 }
 
 ScratchLayout scratch_layout(const v1t_vit* h, int B) {

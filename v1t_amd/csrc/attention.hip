@@ -1941,16 +1941,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
 // order), K tiles are shared by the workgroup and read transposed as the B operand. Bound by reading dS' once from HBM
 // (2 B per (query, key)) through the LDS-DMA path: 32-key stages in a 3-deep ring behind a counted vmcnt. Accumulator rows are queries in the permuted
 // order the stored blocks imply (see the epilogue).
-template <int DP>
-__global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
+// DEEP (round 5): separate ring depths for the two operands - FOUR dS' stages (three in flight, 96 KB) and three K stages - instead of one
+// 3-deep ring of (dS' + K) stages (two in flight: 64 KB of dS' + 21 KB of K). The kernel streams 2.48 GB of dS' per 112-image launch and a CU
+// fetches what it keeps in flight per memory latency (~11.7 B per clock with 85 KB outstanding): the K tile is a quarter of a stage and comes out
+// of L2, so its depth buys nothing, while a fourth dS' stage fits the 160 KB exactly (4 x 32 KB + 3 x 10 KB = 161 792 B). Issue order per
+// step: K(st + 2), then dS'(st + 3); the counted vmcnt in front of the barrier lets dS'(st + 1), K(st + 1) and dS'(st + 2) fly.
+template <int DP, bool DEEP = false>
+__global__ __launch_bounds__(512, 1) void attn_bwd_dq2_kernel(AttnArgs a) {
     using G = Geo<DP>;
     // QPW query blocks per wave: a workgroup covers 8 x QPW x 32 = 512 queries, so a head's K tiles are streamed by 4 workgroups
     // instead of 7 (at 256 queries K re-reads from L2 were 40 % of the bytes the LDS-DMA path moved, and that path - ~24 GB/s per
     // CU - is what bounds this kernel)
     constexpr int KT = 32, NBUF = 3, QPW = 2;  // 3 x 43 KB of LDS: two stages in flight while one is consumed
+    constexpr int NBS = DEEP ? 4 : NBUF, NBK = NBUF;  // ring depths of the dS' blocks / the K tiles
     using DmaK = TileDma<DP, G::TSTR, KT, 8>;  // read transposed only: the 64 B x odd row stride (RSTR's 336 B: 2-way conflicts on a quarter of the banks)
-    __shared__ __attribute__((aligned(16))) bf16_t sS[NBUF][8][QPW][1024];
-    __shared__ __attribute__((aligned(16))) bf16_t sK[NBUF][DmaK::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) bf16_t sS[NBS][8][QPW][1024];
+    __shared__ __attribute__((aligned(16))) bf16_t sK[NBK][DmaK::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, h, b;
     decode_block(a, blockIdx.x, gridDim.x, rb, h, b, 256 * QPW);
@@ -1991,31 +1997,51 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
         aoffs[c] = (gi & 1) * 512 + ahalf * 256 + ((akey + 16 * (c >> 1) + 4 * (c & 1) - 4 * ahalf) & 31) * 8 + (li & 1) * 4;
     const int nst = nkb;  // 32-key stages
     // vector-memory operations this wave issues per stage: its own dS' blocks (2 pieces each) + its share of the K tile
-    const int nops = 2 * nact + min(DmaK::PW, max(0, DmaK::NINST - wave * DmaK::PW));
-    auto stage = [&](int st) {
-        const int buf = st % NBUF;
+    const int nk_ops = min(DmaK::PW, max(0, DmaK::NINST - wave * DmaK::PW)), ns_ops = 2 * nact;
+    const int nops = ns_ops + nk_ops;
+    auto stage_s = [&](int st) {
+        const int buf = st % NBS;
 #pragma unroll
         for (int u = 0; u < QPW; ++u)
             if (u < nact) {
                 const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&sS[buf][wave][u][0]);
                 TileDma<DP, G::RSTR>::template group<2>(sbase[u] + (size_t)st * 2048, l0, svoff, svoff, 0, 0);
             }
-        dmaK.issue(kbase, KT * st, a.T, sK[buf]);
     };
-    stage(0);
-    if (nst > 1) stage(1);
+    auto stage_k = [&](int st) { dmaK.issue(kbase, KT * st, a.T, sK[st % NBK]); };
+    auto stage = [&](int st) {
+        stage_s(st);
+        stage_k(st);
+    };
+    if constexpr (DEEP) {  // issue sequence S(0) K(0) S(1) K(1) S(2) | K(2) S(3) | K(3) S(4) | ...
+        stage(0);
+        if (nst > 1) stage(1);
+        if (nst > 2) stage_s(2);
+    } else {
+        stage(0);
+        if (nst > 1) stage(1);
+    }
     for (int st = 0; st < nst; ++st) {
-        const int buf = st % NBUF;
-        // stage st has landed for this wave (the younger stage may fly), then for the workgroup
-        const int younger = min(NBUF - 2, nst - 1 - st);
-        wait_vmcnt_dyn(younger * nops);
-        __builtin_amdgcn_s_barrier();  // also: every wave is past stage st - 1, whose buffer the next DMA overwrites
-        if (st + NBUF - 1 < nst) stage(st + NBUF - 1);
+        const int buf = st % NBS, kbuf = st % NBK;
+        if constexpr (DEEP) {
+            // everything up to K(st) has landed for this wave; behind it in the queue: dS'(st + 1), K(st + 1), dS'(st + 2) may fly
+            const int fly = (st + 1 < nst ? nops : 0) + (st + 2 < nst ? ns_ops : 0);
+            wait_vmcnt_dyn(fly);
+            __builtin_amdgcn_s_barrier();  // also: every wave is past stage st - 1, whose dS' / K slots the next DMAs overwrite
+            if (st + 2 < nst) stage_k(st + 2);
+            if (st + 3 < nst) stage_s(st + 3);
+        } else {
+            // stage st has landed for this wave (the younger stage may fly), then for the workgroup
+            const int younger = min(NBUF - 2, nst - 1 - st);
+            wait_vmcnt_dyn(younger * nops);
+            __builtin_amdgcn_s_barrier();  // also: every wave is past stage st - 1, whose buffer the next DMA overwrites
+            if (st + NBUF - 1 < nst) stage(st + NBUF - 1);
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 kfr[G::DB];
 #pragma unroll
-            for (int d = 0; d < G::DB; ++d) kfr[d] = lds_tr_frag_nat(sK[buf], G::TSTR, 16 * kk, 32 * d, lane);
+            for (int d = 0; d < G::DB; ++d) kfr[d] = lds_tr_frag_nat(sK[kbuf], G::TSTR, 16 * kk, 32 * d, lane);
 #pragma unroll
             for (int u = 0; u < QPW; ++u)
                 if (u < nact) {
@@ -2061,7 +2087,9 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
-            hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP>), dim3(((a.T + 511) / 512) * a.H * a.B), dim3(512), 0, s, a);
+            static const bool dq_deep = !(std::getenv("V1T_DQ2_DEEP") && !atoi(std::getenv("V1T_DQ2_DEEP")));  // dev (A/B): 0 = the one 3-deep ring
+            if (dq_deep) hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP, true>), dim3(((a.T + 511) / 512) * a.H * a.B), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP, false>), dim3(((a.T + 511) / 512) * a.H * a.B), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DQ, s);
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }

@@ -329,55 +329,68 @@ class Model(nn.Module):
 
     # ------------------------------------------------------------------ flat per-mouse arenas (fused optimizer / DDP)
     def mouse_arena(self, mouse_id: str) -> FlatArena:
-        """All per-mouse parameters (readout + core shifter + image shifter) in one flat arena; `features` first, in
-        neuron-major storage, so the L1 term and the feature kernel see one contiguous [N][FS] block."""
-        a = self._mouse_arenas.get(mouse_id)
-        if a is None:
-            ro = self.readouts[mouse_id]
-            params = [ro.features] + [p for p in ro.parameters() if p is not ro.features]
-            if self.core_shifter is not None:
-                params += list(self.core_shifter[mouse_id].parameters())
-            if self.image_cropper.image_shifter is not None:
-                params += list(self.image_cropper.image_shifter[mouse_id].parameters())
-            special = {}
-            if isinstance(ro, Gaussian2DReadout):
-                special[id(ro.features)] = (ro.feature_storage_numel(), ro._feature_view)
-            a = FlatArena.from_params(params, special)
-            self._mouse_arenas[mouse_id] = a
-        a.ensure()
-        return a
+        return mouse_arena(self, mouse_id)
 
     def mouse_step_ranges(self, mouse_id: str) -> t.List[t.Tuple[int, int, float, str]]:
-        """(start, n, L1 coefficient, optimizer group) runs over the mouse arena for the fused L1 + AdamW step. The
-        coefficients are the terms Model.regularizer adds for this mouse (readout features gaussian2d.py:99-100, core
-        shifter core_shifter.py:21-22, image shifter image_cropper.py:38-39; 0 elsewhere); the group name selects the
-        learning rate (model.py:112-139: readouts / image_cropper / core_shifter are separate optimizer groups)."""
-        a = self.mouse_arena(mouse_id)
-        cached = self._mouse_l1.get(mouse_id)
-        if cached is not None and cached[0] == a.generation:
-            return cached[1]
-        ro = self.readouts[mouse_id]
-        tag = {id(p): (0.0, "readouts") for p in ro.parameters()}
-        tag[id(ro.features)] = (float(ro.reg_scale), "readouts")  # reg_scale buffers live on the device: read once, not per step
-        if self.core_shifter is not None:
-            cs = self.core_shifter[mouse_id]
-            c = float(cs.reg_scale)
-            tag.update({id(p): (c, "core_shifter") for p in cs.parameters()})
-        if self.image_cropper.image_shifter is not None:
-            sh = self.image_cropper.image_shifter[mouse_id]
-            c = float(sh.reg_scale)
-            tag.update({id(p): (c, "image_cropper") for p in sh.parameters()})
-        runs: t.List[list] = []
-        for s in a.slots:
-            c, grp = tag[id(s.tensor)]
-            if runs and runs[-1][2] == c and runs[-1][3] == grp and runs[-1][0] + runs[-1][1] == s.offset:
-                runs[-1][1] += s.numel
-            else:
-                runs.append([s.offset, s.numel, c, grp])
-        out = [(int(o), int(n), float(c), str(g)) for o, n, c, g in runs]
-        self._mouse_l1[mouse_id] = (a.generation, out)
-        return out
+        return mouse_step_ranges(self, mouse_id)
 
     def mouse_l1_ranges(self, mouse_id: str) -> t.List[t.Tuple[int, int, float]]:
         """(start, n, L1 coefficient) runs of `mouse_step_ranges`."""
         return [(o, n, c) for o, n, c, _ in self.mouse_step_ranges(mouse_id)]
+
+
+# ---------------------------------------------------------------------- flat per-mouse arenas: module-level, so that they also serve the
+# REFERENCE's own `Model` (model.py:50-177) built over the native classes by install_into_reference() - it has the same attributes
+# (`readouts`, `core_shifter`, `image_cropper.image_shifter`) but none of this class's methods; `FusedAdamW.for_model` goes through these
+def mouse_arena(model: nn.Module, mouse_id: str) -> FlatArena:
+    """All per-mouse parameters (readout + core shifter + image shifter) in one flat arena; `features` first, in
+    neuron-major storage, so the L1 term and the feature kernel see one contiguous [N][FS] block."""
+    arenas = model.__dict__.setdefault("_mouse_arenas", {})
+    a = arenas.get(mouse_id)
+    if a is None:
+        ro = model.readouts[mouse_id]
+        params = [ro.features] + [p for p in ro.parameters() if p is not ro.features]
+        if getattr(model, "core_shifter", None) is not None:
+            params += list(model.core_shifter[mouse_id].parameters())
+        if model.image_cropper.image_shifter is not None:
+            params += list(model.image_cropper.image_shifter[mouse_id].parameters())
+        special = {}
+        if isinstance(ro, Gaussian2DReadout):
+            special[id(ro.features)] = (ro.feature_storage_numel(), ro._feature_view)
+        a = FlatArena.from_params(params, special)
+        arenas[mouse_id] = a
+    a.ensure()
+    return a
+
+
+def mouse_step_ranges(model: nn.Module, mouse_id: str) -> t.List[t.Tuple[int, int, float, str]]:
+    """(start, n, L1 coefficient, optimizer group) runs over the mouse arena for the fused L1 + AdamW step. The
+    coefficients are the terms Model.regularizer adds for this mouse (readout features gaussian2d.py:99-100, core
+    shifter core_shifter.py:21-22, image shifter image_cropper.py:38-39; 0 elsewhere); the group name selects the
+    learning rate (model.py:112-139: readouts / image_cropper / core_shifter are separate optimizer groups)."""
+    a = mouse_arena(model, mouse_id)
+    cache = model.__dict__.setdefault("_mouse_l1", {})
+    cached = cache.get(mouse_id)
+    if cached is not None and cached[0] == a.generation:
+        return cached[1]
+    ro = model.readouts[mouse_id]
+    tag = {id(p): (0.0, "readouts") for p in ro.parameters()}
+    tag[id(ro.features)] = (float(ro.reg_scale), "readouts")  # reg_scale buffers live on the device: read once, not per step
+    if getattr(model, "core_shifter", None) is not None:
+        cs = model.core_shifter[mouse_id]
+        c = float(cs.reg_scale)
+        tag.update({id(p): (c, "core_shifter") for p in cs.parameters()})
+    if model.image_cropper.image_shifter is not None:
+        sh = model.image_cropper.image_shifter[mouse_id]
+        c = float(sh.reg_scale)
+        tag.update({id(p): (c, "image_cropper") for p in sh.parameters()})
+    runs: t.List[list] = []
+    for s in a.slots:
+        c, grp = tag[id(s.tensor)]
+        if runs and runs[-1][2] == c and runs[-1][3] == grp and runs[-1][0] + runs[-1][1] == s.offset:
+            runs[-1][1] += s.numel
+        else:
+            runs.append([s.offset, s.numel, c, grp])
+    out = [(int(o), int(n), float(c), str(g)) for o, n, c, g in runs]
+    cache[mouse_id] = (a.generation, out)
+    return out

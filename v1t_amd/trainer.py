@@ -25,7 +25,7 @@ import torch
 from . import lib as L
 from .dist import MouseSharding
 from .losses import elu1_poisson_loss
-from .model import Model
+from .model import Model, mouse_arena, mouse_step_ranges
 
 
 class FusedAdamW:
@@ -89,14 +89,14 @@ class FusedAdamW:
         items = []
         for m in model.readouts.keys():
             ro = model.readouts[m]
-            a = model.mouse_arena(m)
+            a = mouse_arena(model, m)
             if not (getattr(ro, "_visited", False) or any(s.tensor.grad is not None and s.tensor.grad.data_ptr() != a.grad.data_ptr() + 4 * s.offset
                                                            for s in a.slots if s.is_param)):
                 continue
             ro._visited = False
             a.attach_grads()
             self._adopt_grads(a)
-            items.append((a, [(o, n, 0.0, self.group_lr(g)) for o, n, _, g in model.mouse_step_ranges(m)]))
+            items.append((a, [(o, n, 0.0, self.group_lr(g)) for o, n, _, g in mouse_step_ranges(model, m)]))
             a._clean = True
         self.step_arenas(items, zero_grad=True)
 
@@ -106,7 +106,7 @@ class FusedAdamW:
         `set_to_none` is accepted for signature compatibility; a mouse that is not visited is skipped by `step` through the readout's mark,
         which is what `None` gradients achieve in torch.optim."""
         model = self.model
-        arenas = [model.core._arena] + [model.mouse_arena(m) for m in model.readouts.keys()]
+        arenas = [model.core._arena] + [mouse_arena(model, m) for m in model.readouts.keys()]
         for a in arenas:
             a.ensure()
             if not getattr(a, "_clean", False):
@@ -126,7 +126,7 @@ class FusedAdamW:
         """id(parameter) -> (arena, slot) over the core arena and every mouse arena"""
         m = self.model
         m.core._arena.ensure()  # flat storage only: no kernel launch, works on a CPU model too
-        arenas = [m.core._arena] + [m.mouse_arena(k) for k in m.readouts.keys()]
+        arenas = [m.core._arena] + [mouse_arena(m, k) for k in m.readouts.keys()]
         return {id(s.tensor): (a, s) for a in arenas for s in a.slots}
 
     def state_dict(self) -> t.Dict[str, t.Any]:
