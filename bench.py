@@ -520,6 +520,8 @@ def run_training(a, wd, state):
     from v1t_amd.synthetic import MOUSE_IDS, default_args, make_batch, make_ds, sensorium_config
     from v1t_amd.trainer import Trainer
 
+    if os.environ.get("V1T_BENCH_RAISE"):  # test hook (tests/test_bench_launch.py): an error inside the run -> the failure line, rc != 0
+        raise RuntimeError(os.environ["V1T_BENCH_RAISE"])
     rank, local, world = init_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")

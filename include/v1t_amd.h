@@ -90,7 +90,10 @@ int v1t_vit_pack(const v1t_vit* h, const float* arena, void* shadow, void* strea
  * concatenated with pupil centers for behavior_mode 3/4 (vit.py:431-432), NULL for mode 0.
  * out: token-major residual stream (B, T, DP) fp32, CLS at t = 0, columns >= emb_dim are 0; the
  * reference's (B, C', h, w) output is the strided view out[:, 1:, :emb_dim] (vit.py:434-435).
- * training != 0 enables the three dropouts with the counter-based mask keyed by `seed`. */
+ * training != 0 enables the three dropouts with the counter-based mask keyed by `seed`.
+ * save_for_backward: 1 = keep everything v1t_vit_backward reads (one workspace region per block); 0 = inference, the blocks share one
+ * region; 2 = inference that keeps every block's qkv and log-sum-exp (v1t_rollout_headmax / v1t_attention_probs). 0 and 2 do not write
+ * the planes only the backward reads (LayerNorm outputs and statistics, gelu'); workspace sizes: v1t_vit_workspace_bytes(h, batch, mode). */
 int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, const float* images,
                     const float* behaviors, int mouse_idx, int batch, void* workspace,
                     long long workspace_bytes, int save_for_backward, int training, uint64_t seed,

@@ -74,6 +74,19 @@ def test_launch_deadline_terminates_all_ranks():
     assert "launch deadline" in r.stderr
 
 
+def test_an_error_inside_the_run_still_prints_the_line_with_the_failure():
+    # an RCCL / HIP error on a rank (here: a test hook that raises inside run_training, before anything touches the GPU): rank 0 prints ONE JSON
+    # line whose value is null and whose config.exchange says what failed, and the exit code is not 0
+    r = _run("--gpus", "1", "--steps", "1", "--warmup", "0", env={"V1T_BENCH_RAISE": "simulated collective failure"})
+    assert r.returncode == 1, (r.returncode, r.stderr[-800:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["ms_per_step"] is None and "simulated collective failure" in d["failed"]
+    assert d["config"]["exchange"].startswith("failed: ") and d["n_gpus"] == 1 and d["unit"] == "images/s"
+    assert "simulated collective failure" in r.stderr  # the traceback goes to stderr
+
+
 import pytest  # noqa: E402
 
 

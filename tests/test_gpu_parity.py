@@ -471,6 +471,30 @@ def test_full_size_properties(dev):
     assert y1.shape == (16, 8000) and bool(torch.isfinite(y1).all()) and float(y1.min()) >= 0.0
 
 
+def test_inference_forward_skips_backward_planes_bit_identically(dev):
+    """`v1t_vit_forward` modes (include/v1t_amd.h): 1 = everything the backward reads, 0 = inference, 2 = inference keeping q / k / lse. Modes 0
+    and 2 do not write the LayerNorm planes / statistics and gelu' (read by the backward only): the predictions must be BIT-identical in all
+    three, at the default V1T size (the fused LayerNorm + GEMM kernels) and at a small one (the two-kernel fallback)."""
+    from v1t_amd.synthetic import make_batch, sensorium_config
+    import v1t_amd
+
+    for cfg_kw in (dict(), dict(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=2, patch_stride=2)):
+        args, ds = sensorium_config({"A": 500}, **cfg_kw)
+        model = v1t_amd.Model(args, ds).to(dev).train(False)
+        b = make_batch(args, "A", 500, 3, dev, seed=11)
+        img = model.image_cropper(b["image"], "A", b["behavior"], b["pupil_center"])[0]
+        core = model.core
+        t1 = core.forward_tokens(img, "A", b["behavior"], b["pupil_center"]).detach().clone()  # grad mode: mode 1
+        assert core._last_ws[2]
+        lse1 = core.workspace_tensor("lse2", 0)[: 3 * args.num_heads * core.num_tokens * 4].clone()
+        with torch.no_grad():
+            t0 = core.forward_tokens(img, "A", b["behavior"], b["pupil_center"]).clone()  # mode 0
+            t2 = core.forward_tokens(img, "A", b["behavior"], b["pupil_center"], keep_workspace=True).clone()  # mode 2
+            lse2 = core.workspace_tensor("lse2", 0)[: 3 * args.num_heads * core.num_tokens * 4].clone()
+        assert torch.equal(t0, t1) and torch.equal(t2, t1)
+        assert torch.equal(lse1, lse2)  # what the rollout reads is there in mode 2
+
+
 def test_attention_rollout_vs_reference_golden(golden, dev):
     """G5: Recorder + attention_rollouts of the reference (2 blocks, D=64, B=2) vs the native rollout."""
     from v1t_amd.rollout import attention_rollouts, rollout_rows

@@ -88,8 +88,8 @@ class _VitFn(torch.autograd.Function):
     (their .grad views), so the node returns no gradients."""
 
     @staticmethod
-    def forward(ctx, core: "ViTCore", images, behaviors, mouse_idx: int, anchor, need_bwd: bool):
-        # need_bwd is decided by the caller: grad mode is always off inside Function.forward
+    def forward(ctx, core: "ViTCore", images, behaviors, mouse_idx: int, anchor, need_bwd: int):
+        # need_bwd (the workspace mode 0 / 1 / 2) is decided by the caller: grad mode is always off inside Function.forward
         B = images.shape[0]
         training = core.training
         seed = core._next_seed() if training else 0
@@ -526,7 +526,9 @@ class ViTCore(Core):
             beh = behaviors.to(torch.float32).contiguous()
         midx = self.mouse_ids.index(mouse_id) if self.behavior_mode == 4 else 0
         self._anchor.requires_grad_(next(self.parameters()).requires_grad and not self.frozen)  # freeze() flips every parameter
-        need_bwd = (torch.is_grad_enabled() and self._anchor.requires_grad) or keep_workspace
+        # workspace mode of v1t_vit_forward: 1 = everything the backward reads; 2 = inference that keeps every block's q / k / log-sum-exp
+        # (rollout, attention probabilities); 0 = inference. Modes 0 and 2 skip the planes only the backward reads (include/v1t_amd.h)
+        need_bwd = 1 if (torch.is_grad_enabled() and self._anchor.requires_grad) else (2 if keep_workspace else 0)
         return _VitFn.apply(self, inputs, beh, midx, self._anchor, need_bwd)
 
     # ------------------------------------------------------------------ the reference's own Recorder (utils/attention_rollout.py:15-77)

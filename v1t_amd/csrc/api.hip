@@ -641,6 +641,10 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
     const bool train = training != 0;
     const int bm = (h->c.behavior_mode == 4) ? mouse_idx : 0;
     if (bm < 0 || bm >= h->nbmlp) return V1T_ERR_ARG;
+    // save: 0 = inference (blocks share one workspace region), 1 = everything the backward reads, 2 = inference that keeps every block's
+    // qkv and log-sum-exp (attention rollout / probabilities). 0 and 2 are LEAN: the planes only the backward reads - LayerNorm outputs and
+    // statistics, gelu' - are not written by the fused LayerNorm + GEMM kernels (1.1 GB per block at batch 256; round 5)
+    const int lean = (save != 1 && !train) ? 1 : 0;
 
     // patch embedding -> x0
     PatchArgs pa{};
@@ -739,7 +743,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         l1.x = xcur; l1.inject = h->inject ? (float*)(ws + w.beta) + (size_t)k * B * DP : nullptr; l1.xout = xa;
         l1.gamma = arena + b.ln1w; l1.beta = arena + b.ln1b; l1.z = z1; l1.z_lo = (bf16_t*)(wb + w.z1_lo); l1.lo_f16 = g_fwd_f16;
         l1.mean = (float*)(wb + w.mean1); l1.rstd = (float*)(wb + w.rstd1);
-        l1.rows = R; l1.T = h->T; l1.D = D; l1.DP = DP; l1.eps = h->c.ln_eps; l1.ones_col = -1;
+        l1.rows = R; l1.T = h->T; l1.D = D; l1.DP = DP; l1.eps = h->c.ln_eps; l1.ones_col = -1; l1.lean = lean;
         GemmNTArgs g{};
         g.A = z1; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_qkv); g.ldb = DP; g.M = R; g.N = 3 * HDP; g.K = DP; g.C = qkv; g.ldc = 3 * HDP;
         g.A_lo = (const bf16_t*)(wb + w.z1_lo); g.B_lo = (const bf16_t*)(sh + b.s_qkv_lo);
@@ -766,7 +770,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         LnFwdArgs l2{};
         l2.x = xm; l2.inject = nullptr; l2.xout = nullptr; l2.gamma = arena + b.ln2w; l2.beta = arena + b.ln2b; l2.z = z2; l2.z_lo = (bf16_t*)(wb + w.z2_lo); l2.lo_f16 = g_fwd_f16;
         l2.mean = (float*)(wb + w.mean2); l2.rstd = (float*)(wb + w.rstd2);
-        l2.rows = R; l2.T = h->T; l2.D = D; l2.DP = DP; l2.eps = h->c.ln_eps;
+        l2.rows = R; l2.T = h->T; l2.D = D; l2.DP = DP; l2.eps = h->c.ln_eps; l2.lean = lean;
         l2.ones_col = (DP > D && h->blk[k].fc1b >= 0) ? DP - 1 : -1;  // d(fc1 bias) comes out of the dW1 GEMM
         g = GemmNTArgs{};
         g.A = z2; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_fc1); g.ldb = DP; g.M = R; g.N = MP; g.K = DP; g.C = hpre; g.ldc = MP;
@@ -775,6 +779,7 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         fwd_operands(g);
         g.C2 = x16a ? nullptr : hact; g.ldc2 = MP; g.bias = b.s_fc1b >= 0 ? (const float*)(sh + b.s_fc1b) : nullptr;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
+        g.lean = lean;
         CHECK(ln_then_gemm(l2, g, EPI_BIAS_GELU, s));
 
         g = GemmNTArgs{};

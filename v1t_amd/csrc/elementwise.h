@@ -91,6 +91,7 @@ struct LnFwdArgs {
     int rows, T, D, DP;
     float eps;
     int ones_col;        // >= D: z[:, ones_col] = 1 (bias-gradient column for the weight-gradient GEMM), < 0: none
+    int lean;            // inference: the fused LayerNorm + GEMM kernel keeps z in registers only (z / mean / rstd feed nothing but the backward)
 };
 int launch_ln_fwd(const LnFwdArgs& a, hipStream_t s);
 

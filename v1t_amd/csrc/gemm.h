@@ -53,6 +53,7 @@ struct GemmNTArgs {
     const float* pos; const float* cls; int T;  // EPI_PATCH: natural [T][n_valid] position table, [n_valid] class token
     const float* row_scale;       // EPI_BIAS_RES: per-image factor on the branch (stochastic depth), index row / T, or nullptr
     RowDotArgs rd;                // EPI_BF16, N % 160 == 0: see RowDotArgs
+    int lean;                     // EPI_BIAS_GELU, inference: gelu' (C, read by the backward only) is not written
 };
 bool gemm_nt_takes_row_dot(const GemmNTArgs& a, int epi);
 

@@ -106,9 +106,11 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
             }
         }
         if constexpr (EPI == EPI_BIAS_GELU) {
-            bf16_t* fp = (bf16_t*)g.C + frag_index(g, m0, n0, nb, wave, lane);
-            *(bf16x8*)fp = gp0;
-            *(bf16x8*)(fp + 8) = gp1;
+            if (!g.lean) {  // kernel-uniform: inference forwards skip the gelu' plane (433 MB per block at batch 256)
+                bf16_t* fp = (bf16_t*)g.C + frag_index(g, m0, n0, nb, wave, lane);
+                *(bf16x8*)fp = gp0;
+                *(bf16x8*)(fp + 8) = gp1;
+            }
         }
     }
 }
@@ -743,7 +745,8 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
         }
     q += __shfl_xor(q, 32);
     const float rstd = rsqrtf(q / l.D + l.eps);
-    if (wln && h2 == 0) {
+    const bool wz = wln && !l.lean;  // the LayerNorm plane and its statistics: read by the backward only
+    if (wz && h2 == 0) {
         l.mean[row] = mean;
         l.rstd[row] = rstd;
     }
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
             zh[e] = (bf16_t)z;
             afrag[u][ks][e] = aux_plane(z, zh[e], 1);
         }
-        if (wln) *(bf16x8*)(l.z + (size_t)row * DP + c0) = zh;
+        if (wz) *(bf16x8*)(l.z + (size_t)row * DP + c0) = zh;
     }
     }  // row sets
 
