@@ -152,6 +152,94 @@ DEVFN void dma_wait_and_barrier() {
     __syncthreads();
 }
 
+// Global -> LDS tile staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
+// The LDS image of a [ROWS][STR] bf16 tile is a linear array of 16-B chunks (STR/8 per row, the last
+// (STR-DP)/8 of each row are padding); one wave-instruction ("piece") fills 64 consecutive chunks (1 KiB) with
+// each lane's own global source address, so the row padding costs nothing but a dummy fetch.
+// Issue cost is what matters (in-kernel s_memtime timeline, tools/kprof.py): with per-piece 64-bit address
+// arithmetic, M0 juggling and EXEC masking a piece cost its wave ~150 cycles, 850 per 32-key tile of the forward
+// kernel. Here a piece is ONE instruction: wave w owns PW consecutive pieces, the tile's row-0 address is a
+// scalar base (saddr form), the lane's byte offset is loop-invariant, and pieces 1..3 of a group of four reuse
+// the group's M0 through the instruction offset (it advances the LDS and the global address alike, so the lane
+// offset carries 3072 - imm and the base is biased by -3072). The last piece of a tile may be partial: its
+// surplus lanes re-fetch the last row into slack behind the tile (size buffers with LDS_ELEMS).
+// Rows beyond T are clamped to row T-1 (finite data; every consumer masks them): only the ragged last tile
+// takes that path, recomputing its offsets.
+template <int DP, int STR, int ROWS = 32, int NWAVES = 4>
+struct TileDma {
+    static constexpr int CPR = STR / 8;                 // chunks per LDS row
+    static constexpr int NCH = ROWS * CPR;              // chunks per tile
+    static constexpr int NINST = (NCH + 63) / 64;       // pieces per tile
+    static constexpr int PW = (NINST + NWAVES - 1) / NWAVES;  // pieces per wave
+    static constexpr int NG = (PW + 3) / 4;             // M0 groups per wave
+    static constexpr int LDS_ELEMS = NINST * 512;       // tile + slack of the partial last piece
+    static constexpr int BIAS = 3072;
+    unsigned voff[PW];
+    int wave, lane, ld;
+    DEVFN unsigned lane_off(int i, int max_row) const {
+        const int p = 64 * (wave * PW + i) + lane;
+        const int r = min(p / CPR, max_row), cc = min(p % CPR, DP / 8 - 1);
+        return (unsigned)((r * ld + 8 * cc) * 2 + BIAS - 1024 * (i & 3));
+    }
+    DEVFN void init(int lane_, int wave_uniform, int ld_elems) {
+        wave = wave_uniform; lane = lane_; ld = ld_elems;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) voff[i] = lane_off(i, ROWS - 1);
+    }
+    template <int CNT>
+    DEVFN static void group(const char* base, unsigned m0v, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+        unsigned keep;
+        if constexpr (CNT == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\tglobal_load_lds_dwordx4 %3, %6 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %4, %6 offset:2048\n\tglobal_load_lds_dwordx4 %5, %6 offset:3072\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base) : "memory");
+        else if constexpr (CNT == 3)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\tglobal_load_lds_dwordx4 %3, %5 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %4, %5 offset:2048\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "v"(v2), "s"(base) : "memory");
+        else if constexpr (CNT == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %3, %4 offset:1024\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "s"(base) : "memory");
+        else if constexpr (CNT == 1)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "s"(base) : "memory");
+    }
+    // img: element (row 0, col 0) of this (image, head) slice; t0: first row of the tile; lds: tile base (LDS_ELEMS elements)
+    DEVFN void issue(const bf16_t* img, int t0_, int T, bf16_t* lds) const {
+        // a tile that lies WHOLLY beyond T (the dQ GEMM walks the 128-key padded width of dS': up to three such 32-key tiles when T % 128 <= 96 -
+        // first met at T = 34 114, tests/test_gpu_longseq.py; T = 1654 has none) is fetched as T - 1 repeated: without the clamp the row clamp below
+        // turned negative and the 32-bit lane offset, which the hardware zero-extends, pointed 4 GB behind the tile
+        const int t0 = min(t0_, T - 1);
+        // (wave-uniform by construction; the explicit readfirstlanes keep the "s" asm operands in SGPRs where hipcc's uniformity
+        // analysis gives up - a tile index that comes out of a loop rotated per wave half)
+        const unsigned long long bb = (unsigned long long)(uintptr_t)((const char*)(img + (size_t)t0 * ld) - BIAS);
+        const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)), b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bb);
+        const char* base = (const char*)(uintptr_t)(((unsigned long long)b_hi << 32) | (unsigned long long)b_lo);
+        const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds);
+        const bool ragged = t0 + ROWS > T;  // wave-uniform
+        unsigned v[PW];
+#pragma unroll
+        for (int i = 0; i < PW; ++i) v[i] = voff[i];
+        if (ragged) {
+            asm volatile("; ragged tile: clamp rows" ::: "memory");  // keeps this a branch (no if-conversion into the hot path)
+#pragma unroll
+            for (int i = 0; i < PW; ++i) v[i] = lane_off(i, T - 1 - t0);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int n0 = wave * PW + 4 * g;                       // wave-uniform
+            const int cnt = min(min(4, PW - 4 * g), NINST - n0);    // pieces of this group that exist
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(l0 + 1024u * (unsigned)n0);
+            auto at = [&](int k) { return v[4 * g + k < PW ? 4 * g + k : PW - 1]; };
+            if (cnt >= 4) group<4>(base, m0v, at(0), at(1), at(2), at(3));
+            else if (cnt == 3) group<3>(base, m0v, at(0), at(1), at(2), 0);
+            else if (cnt == 2) group<2>(base, m0v, at(0), at(1), 0, 0);
+            else if (cnt == 1) group<1>(base, m0v, at(0), 0, 0, 0);
+        }
+    }
+};
+
 // ---- counter-based dropout ------------------------------------------------------------
 // keep(seed, stream, row, col): stateless 32-bit mix; the SAME function is evaluated by the
 // forward and the backward kernels and is exported through the C-ABI (v1t_dropout_mask) so that

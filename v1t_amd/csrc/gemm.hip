@@ -976,8 +976,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs g) {
         dyc[i] = min(n0 + 8 * min(cc, YW / 8 - 1), g.NY - 8);
         dxc[i] = min(x0 + 8 * min(cc, XW / 8 - 1), g.NX - 8);
     }
+    // Round 5: whole tiles go through TileDma (common.h) - one instruction per 1-KB piece with a scalar base and loop-invariant lane offsets,
+    // four pieces per M0 set-up - instead of one lds_dma16 per piece (64-bit address arithmetic + an M0 save / set / restore each: ~10 x 90 issue
+    // cycles per stage and wave against 20 MFMAs = 640). Same LDS image ([64][160], pieces in row order), same row clamp (rows past the
+    // m-chunk re-read its last row and are masked in the one-block operand). Tiles that overhang the matrix keep the per-piece form.
+    using DmaY = TileDma<YW, TN2_STR, TN2_ROWS, 4>;
+    using DmaX = TileDma<XW, TN2_STR, TN2_ROWS, 4>;
+    static_assert(DmaY::LDS_ELEMS == TN2_ROWS * TN2_STR && DmaY::NINST == 4 * NI, "the image the per-piece form fills");
+#ifdef V1T_TN2_NO_TILEDMA  // A/B builds (V1T_BUILD_LIB)
+    const bool whole = false;
+#else
+    const bool whole = n0 + YW <= g.NY && x0 + XW <= g.NX;  // workgroup-uniform
+#endif
+    DmaY dmaY;
+    DmaX dmaX;
+    dmaY.init(lane, wave, g.ldy);
+    dmaX.init(lane, wave, g.ldx);
     auto issue = [&](int t, int buf) {
         const int mt = mb + TN2_ROWS * t;
+        if (whole) {
+            dmaY.issue(g.Y + n0, mt, me, sY[buf]);
+            dmaX.issue(g.X + x0, mt, me, sX[buf]);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const size_t m = (size_t)min(mt + drow[i], me - 1);
@@ -1429,6 +1450,9 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
         const float cost = (float)((rt * ns + slots - 1) / slots) * unit * ((shape ? 3.0f : 1.5f) + (float)((ntn + ns - 1) / ns));
         if (cost < best - 1e-3f) { best = cost; nsplit = ns; }
     }
+    // between one and two workgroups per CU the model's "one round" is lopsided (362 row tiles at a 4-GPU share: 106 CUs hold two workgroups
+    // that each walk all 30 column tiles): two column halves per row tile measured 6.17 / 6.16 against 6.21 / 6.23 ms per step (round 5)
+    if (shape == 1 && nsplit == 1 && rt > 256 && rt <= 512 && ntn >= 2) nsplit = 2;
     if (force_split > 0) nsplit = std::min(force_split, ntn);
     const dim3 grid(rt * nsplit), blk(shape ? 256 : 512);
 #define LNG_CASE(DPV)                                                                                                       \
