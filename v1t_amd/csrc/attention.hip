@@ -1212,9 +1212,10 @@ static void choose_fwd_split_uncached(int B, int H, int T, int& F, int& Hh, int&
     const int F0 = T / 256 + (rem > 128 ? 1 : 0), H0 = (rem >= 1 && rem <= 128) ? 1 : 0;
     F = F0; Hh = H0;
     const int nblk0 = B * H * (F0 + H0);
-    lpt = (H0 && nblk0 >= 640 && nblk0 <= 1152) ? 1 : 0;  // measured (round 5): helps a 28-image launch, hurts at 14 and at 112 images
+    static const int lpt_max = std::getenv("V1T_FWD_LPT_MAX") ? atoi(std::getenv("V1T_FWD_LPT_MAX")) : 1152;  // dev (A/B)
+    lpt = (H0 && nblk0 >= 640 && nblk0 <= lpt_max) ? 1 : 0;  // measured (round 5): helps a 28-image launch, hurts at 14 and at 112 images
     static const bool allow = !(std::getenv("V1T_FWD_SPLIT") && !atoi(std::getenv("V1T_FWD_SPLIT")));
-    if (!allow || nblk0 > 1152 || T <= 256) return;
+    if (!allow || nblk0 > lpt_max || T <= 256) return;
     const int nbh = (B * H + 7) / 8;  // (image, head) pairs of the fullest XCD
     auto makespan = [&](int f, int hh) {
         float cu[32];
