@@ -125,10 +125,11 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
  * (rows B*T, cols = feature index), 0xFFFF: patch embedding. out: rows*cols bytes (1 = keep). */
 int v1t_dropout_mask(uint64_t seed, uint32_t stream_id, float p, long long rows, long long cols,
                      uint8_t* out, void* stream);
-/* The attention-P dropout (vit.py:263) is evaluated B*H*T*T times inside three MFMA kernels; its mask uses
- * one hash per 2x2 (query,key) block with 8-bit thresholds, so its rate is quantised to round(256 p)/256
- * (0.2544 -> 0.25390625; p < 1/512 -> 0 = no dropout at this site, p > 255/256 -> 255/256) and 1/(1-rate) uses the quantised
- * rate. This returns the effective rate. */
+/* The attention-P dropout (vit.py:263) is evaluated B*H*T*T times inside three MFMA kernels; its mask uses one 32-bit hash per
+ * 2x2 (query,key) block with byte decisions against a threshold that is dithered per 32x32 tile (thresh8 + 1 in a fraction
+ * frac8/256 of the tiles, thresh8 in the others; csrc/common.h), so an element's drop probability is round(65536 p)/65536
+ * (0.2544 -> 0.25439453, 2e-5 relative; p < 2^-17 -> 0 = no dropout at this site, p > 65535/65536 -> 65535/65536) and 1/(1-rate)
+ * uses that rate. (Rounds 1-4: a fixed byte threshold, round(256 p)/256 = 0.25390625.) This returns the effective rate. */
 float v1t_attention_dropout_rate(float p);
 
 /* ------------------------------------------------ Gaussian2d readout (readout/gaussian2d.py:237-278) */
@@ -212,6 +213,14 @@ int v1t_resize_bilinear(const float* in, int planes, int IH, int IW, float* out,
  * yhat/du/loss may be NULL; y may be NULL (inference: only yhat). loss is += (zero it first). */
 int v1t_elu1_poisson(const float* u, const float* y, long long n, float loss_scale, float gscale,
                      float* yhat, float* du, float* loss, void* stream);
+
+/* PoissonLoss as the reference's criterion calls it, on the model's output (losses.py:141-166: add eps to targets and predictions,
+ * sum(y_pred - y_true log y_pred); scale_ds :114-119 = loss_scale): loss += the scaled sum (zero it first); dy (may be NULL) =
+ * dLoss/dy_pred = loss_scale (1 - (y_true + eps) / (y_pred + eps)). One launch for the criterion's seven. */
+int v1t_poisson_loss(const float* y_pred, const float* y_true, long long n, float eps, float loss_scale, float* dy, float* loss,
+                     void* stream);
+/* Backward of ELU + 1 (models/utils.py:109-118) from its input u and output y: du = g * (u > 0 ? 1 : y). */
+int v1t_elu1_backward(const float* u, const float* y, const float* g, long long n, float* du, void* stream);
 
 /* ------------------------------------------------------------------ input pipeline (packed per-mouse store in HBM) */
 /* MiceDataset.__getitem__ (data.py:419-434) for a whole batch: gather trials index[B] from a packed [trials][E] array

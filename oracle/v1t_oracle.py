@@ -227,7 +227,7 @@ def attention(
     attn = softmax_lastdim(dots)
     if record is not None:
         record.append(attn.detach().clone())  # Recorder hook: P before dropout (attention_rollout.py:28-36)
-    # "attn_p": effective rate of a replayed mask (the HIP kernels quantise the attention-P rate to 1/256)
+    # "attn_p": effective rate of a replayed mask (the HIP kernels run the attention-P dropout at round(65536 p) / 65536)
     attn = apply_mask(attn, masks.get(f"attn{k}"), masks.get("attn_p", cfg.t_dropout))
     o = (attn @ v).permute(0, 2, 1, 3).reshape(b, n, h * d)
     o = linear(o, sd[p + "projection.0.weight"], sd.get(p + "projection.0.bias"))

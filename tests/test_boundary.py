@@ -82,10 +82,25 @@ def test_install_into_reference_builds_native_classes_in_reference_model(g12):
 
     import v1t_amd
 
+    from v1t import losses as ref_losses
+
     saved = (ref_core._CORES["vit"], ref_readout._READOUTS["gaussian2d"])
+    saved_criterion = ref_losses._CRITERION["poisson"]
     try:
         assert v1t_amd.install_into_reference() is True
         assert ref_core.get_core(SimpleNamespace(core="vit")) is v1t_amd.ViTCore
+        # the criterion registry (losses.py:9-17, 193-197): get_criterion() builds the fused PoissonLoss with the reference's own call, and on CPU
+        # tensors it computes what the reference's class computes (the fused launch needs fp32 GPU tensors)
+        from v1t_amd.losses import PoissonLoss
+
+        ds_c = {"A": SimpleNamespace(dataset=range(4500))}
+        crit = ref_losses.get_criterion(SimpleNamespace(criterion="poisson", ds_scale=1, device="cpu"), ds=ds_c)
+        assert type(crit) is PoissonLoss
+        ref_crit = saved_criterion(SimpleNamespace(ds_scale=1), ds=ds_c)
+        gen = torch.Generator().manual_seed(0)
+        yt, yp = torch.rand(4, 30, generator=gen) * 3, torch.rand(4, 30, generator=gen) + 0.1
+        assert torch.allclose(crit(y_true=yt, y_pred=yp, mouse_id="A", batch_size=4), ref_crit(y_true=yt, y_pred=yp, mouse_id="A", batch_size=4), rtol=1e-6)
+        assert torch.allclose(crit(y_true=yt, y_pred=yp, mouse_id="A"), ref_crit(y_true=yt, y_pred=yp, mouse_id="A"), rtol=1e-6)
         for sm, extra in ((2, {}), (4, dict(center_crop=0.8, raw_input_shape=(1, 36, 64), input_shape=(1, 28, 51)))):
             cfg = O.Config(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 40, "B": 23}, shift_mode=sm, **extra)
             ds = {m: G.FakeDS(W.make_coordinates(3, m, cfg.num_neurons[m]), cfg.num_neurons[m]) for m in cfg.mouse_ids}
@@ -130,4 +145,5 @@ def test_install_into_reference_builds_native_classes_in_reference_model(g12):
                 model(inputs=b["image"], mouse_id="A", behaviors=b["behavior"], pupil_centers=b["pupil_center"])
     finally:
         ref_core._CORES["vit"], ref_readout._READOUTS["gaussian2d"] = saved
+        ref_losses._CRITERION["poisson"] = saved_criterion
         v1t_amd.ViTCore._reference_attention_cls = None

@@ -97,7 +97,7 @@ def test_attention_forward_backward(ctx, B, H, T, DP, p, lsa):
         L.check(lib.v1t_dropout_mask(seed, sid, p, B * H * T, T, mask.data_ptr(), L.stream()))
         if mask.numel() > 10000:
             assert abs(float(mask.float().mean()) - (1 - float(lib.v1t_attention_dropout_rate(p)))) < 5e-3  # keep rate of the counter-based mask
-    p_eff = float(lib.v1t_attention_dropout_rate(p))  # rate quantised to 1/256 (include/v1t_amd.h)
+    p_eff = float(lib.v1t_attention_dropout_rate(p))  # round(65536 p) / 65536 (include/v1t_amd.h)
     ref = _attn_ref(qkv, B, H, T, DP, scale_r if lsa else scale_r.expand(H), mask, p_eff, diag=lsa)
     assert rel_to_max(o.float().cpu(), ref.detach().cpu()) < 1e-2  # bf16 P and bf16 output
     dO = (torch.randn(B * T, H * DP, generator=g) * 0.5).to(dev).bfloat16()
@@ -497,15 +497,40 @@ def test_rollout_matmul_vs_fp64(B, T):
 
 
 def test_attention_dropout_rate_quantisation():
-    """The attention-P dropout runs at round(256 p) / 256: tiny rates round to OFF (not up to 1 / 256), the top is 255 / 256."""
+    """The attention-P dropout runs at round(65536 p) / 65536 (byte decisions against a per-tile dithered threshold): the default 0.2544
+    within 2e-5 relative, a sweep near 0 follows p down to 2^-17, below which the site is OFF; the top is 65535 / 65536."""
     from v1t_amd import lib as L
 
     lib = L.load()
     assert float(lib.v1t_attention_dropout_rate(0.0)) == 0.0
-    assert float(lib.v1t_attention_dropout_rate(0.001)) == 0.0          # < 1 / 512
-    assert float(lib.v1t_attention_dropout_rate(0.003)) == 1.0 / 256.0  # rounds to 1
-    assert abs(float(lib.v1t_attention_dropout_rate(0.2544)) - 65.0 / 256.0) < 1e-7
-    assert float(lib.v1t_attention_dropout_rate(0.9999)) == 255.0 / 256.0
+    assert float(lib.v1t_attention_dropout_rate(2.0 ** -18)) == 0.0
+    for p in (1e-4, 0.001, 0.003, 0.01, 0.1, 0.2544, 0.5, 0.9):
+        got = float(lib.v1t_attention_dropout_rate(p))
+        assert abs(got - p) <= 2.0 ** -17 + 1e-9, (p, got)
+    assert abs(float(lib.v1t_attention_dropout_rate(0.2544)) - 16672.0 / 65536.0) < 1e-7
+    assert float(lib.v1t_attention_dropout_rate(0.99999999)) == 65535.0 / 65536.0
+
+
+@pytest.mark.parametrize("p", [0.003, 0.2544])
+def test_attention_dropout_mask_statistics(ctx, p):
+    """The exported mask of the attention-P site (v1t_dropout_mask on an attention stream = the decisions the kernels take, compared bit
+    for bit by the parity tests) keeps 1 - p of the elements - also at a rate the fixed byte threshold of rounds 1-4 could not express - with
+    no row / column structure and no correlation between neighbours."""
+    lib, L, dev = ctx
+    BH, T = 8, 1654
+    m = torch.empty(BH * T, T, dtype=torch.uint8, device=dev)
+    L.check(lib.v1t_dropout_mask(1234, 8, p, BH * T, T, m.data_ptr(), L.stream()))
+    k = m.view(BH, T, T).float()
+    p_eff = float(lib.v1t_attention_dropout_rate(p))
+    n = k.numel()
+    sd = (p_eff * (1 - p_eff) / n) ** 0.5
+    assert abs(float(1 - k.mean()) - p_eff) < 5 * sd + 1e-6
+    sd_line = (p_eff * (1 - p_eff) / T) ** 0.5  # a row's / column's drop rate: binomial over T elements
+    assert 0.85 * sd_line < float(k.mean(2).std()) < 1.15 * sd_line and 0.85 * sd_line < float(k.mean(1).std()) < 1.15 * sd_line
+    c = k - k.mean()
+    var = float((c * c).mean())
+    for a_, b_ in ((c[:, :, :-1], c[:, :, 1:]), (c[:, :-1], c[:, 1:]), (c[:, :-1, :-1], c[:, 1:, 1:]), (c[:-1], c[1:])):
+        assert abs(float((a_ * b_).mean()) / var) < 0.01
 
 
 def test_attention_forward_extreme_scores(ctx):
@@ -642,3 +667,34 @@ def test_attention_random_shapes(ctx):
     from tests.helpers import record_margin
 
     record_margin("test_attention_random_shapes: worst error / bound over 34 shapes", worst, 1.0)
+
+
+def test_fused_poisson_criterion_and_elu1_backward_vs_torch(ctx):
+    """The criterion with the reference's call signature (losses.py:141-166, scale_ds :114-119) as one launch and the backward of ELU + 1
+    (models/utils.py:109-118) as one launch, against the same arithmetic in plain torch ops (fp64)."""
+    from types import SimpleNamespace
+
+    from v1t_amd.losses import PoissonLoss
+    from v1t_amd.model import ELU1
+
+    lib, L, dev = ctx
+    g = torch.Generator().manual_seed(5)
+    B, N = 16, 8000
+    u = (torch.randn(B, N, generator=g) * 1.5).to(dev).requires_grad_(True)
+    y_true = torch.rand(B, N, generator=g).mul(3.0).to(dev)
+    y_true[0, :7] = 0.0  # targets of exactly 0: (0 + eps) log(.)
+    ds = {"A": SimpleNamespace(dataset=range(4500))}
+    crit = PoissonLoss(SimpleNamespace(ds_scale=1), ds).to(dev)
+    y_pred = ELU1().to(dev)(u)
+    loss = crit(y_true=y_true, y_pred=y_pred, mouse_id="A", batch_size=B)
+    (2.0 * loss).backward()
+    u64 = u.detach().double().requires_grad_(True)
+    eps = float(torch.finfo(torch.float32).eps)
+    yp = torch.nn.functional.elu(u64) + 1 + eps
+    ref = math.sqrt(4500 / B) * torch.sum(yp - (y_true.double() + eps) * torch.log(yp))
+    (2.0 * ref).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    check_rel("fused_poisson:du", u.grad, u64.grad.float(), 2e-5)
+    # no-grad call (validation): no gradient buffer, same value
+    with torch.no_grad():
+        assert abs(float(crit(y_true=y_true, y_pred=y_pred.detach(), mouse_id="A")) - float(ref)) <= 2e-6 * abs(float(ref))

@@ -12,8 +12,9 @@ __all__ = ["Core", "ViTCore", "CCTCore", "get_core", "register_core", "Gaussian2
 
 def install_into_reference() -> bool:
     """If the reference package `v1t` is importable, overwrite its registry entries "vit", "cct" and
-    "gaussian2d" (core/core.py:8-16, readout/readout.py:10-18) with the native classes, so that the
-    reference's own `train.py --core vit --readout gaussian2d` (or `--core cct`) picks them up unchanged."""
+    "gaussian2d" (core/core.py:8-16, readout/readout.py:10-18) with the native classes - and the "poisson" entry of its criterion
+    registry (losses.py:9-17) with the fused PoissonLoss - so that the reference's own `train.py --core vit --readout gaussian2d`
+    (or `--core cct`) picks them up unchanged."""
     try:
         from v1t.models.core import core as ref_core  # type: ignore
         from v1t.models.readout import readout as ref_readout  # type: ignore
@@ -22,6 +23,14 @@ def install_into_reference() -> bool:
     ref_core.register("vit")(ViTCore)
     ref_core.register("cct")(CCTCore)
     ref_readout.register("gaussian2d")(Gaussian2DReadout)
+    try:  # the criterion registry (losses.py:9-17, 141-166): the same PoissonLoss as one fused launch on fp32 GPU tensors
+        from v1t import losses as ref_losses  # type: ignore
+
+        from .losses import PoissonLoss
+
+        ref_losses.register("poisson")(PoissonLoss)
+    except Exception:
+        pass
     try:  # the reference's Recorder looks for instances of ITS Attention class and hooks their `.attend` (utils/attention_rollout.py:24-36)
         from v1t.models.core import vit as ref_vit  # type: ignore
 

@@ -341,13 +341,14 @@ class ViTCore(Core):
         self.attach_recorder_taps()  # no-op unless v1t_amd.install_into_reference() has named the reference's Attention class
         if not hasattr(self, "drop_path_rates"):  # ViT: one DropPath module for every block (vit.py:333)
             self.drop_path_rates = torch.full((self.num_blocks,), self.drop_path_rate, dtype=torch.float32)
-        # the attention-probability dropout (vit.py:263) runs at round(256 p) / 256 (include/v1t_amd.h): say so when that is not p
+        # the attention-probability dropout (vit.py:263) runs at round(65536 p) / 65536 (include/v1t_amd.h): say so when that is not p within 2 %
+        # (rates below 2^-17 run as 0)
         self.attention_dropout_rate = float(lib.v1t_attention_dropout_rate(float(args.t_dropout))) if float(args.t_dropout) > 0 else 0.0
         if float(args.t_dropout) > 0 and abs(self.attention_dropout_rate - float(args.t_dropout)) > 0.02 * float(args.t_dropout):
             import warnings
 
             warnings.warn(f"v1t_amd: attention-probability dropout runs at {self.attention_dropout_rate:.5f} (t_dropout = {float(args.t_dropout):.5f} "
-                          f"quantised to 1/256); the proj / MLP dropouts use the exact rate", stacklevel=2)
+                          f"quantised to 1/65536); the proj / MLP dropouts use the exact rate", stacklevel=2)
 
     def __del__(self):
         try:

@@ -291,17 +291,19 @@ static const bool g_debug_sync = std::getenv("V1T_DEBUG_SYNC") != nullptr;
  AttnDrop make_adrop(bool training, float p, uint64_t seed, uint32_t stream) {
     AttnDrop d;
     d.key = drop_key(seed, stream);
-    d.thresh8 = 0;
+    d.thresh16 = d.thresh8 = d.frac8 = 0;
     d.inv_keep = 1.f;
     d.keep_prob = 1.f;
     if (training && p > 0.f) {
-        // rate quantised to t / 256; a rate below 1 / 512 rounds to "no dropout at this site" (0 is closer to it than 1 / 256:
-        // a sweep over t_dropout near 0 would otherwise train at 2-4x the requested rate), above 255.5 / 256 to 255 / 256
-        const int t = std::min((int)std::floor((double)p * 256.0 + 0.5), 255);
+        // rate = t / 65536 (byte decisions against a per-tile dithered threshold, common.h); a rate below 2^-17 rounds to "no dropout at this
+        // site", above 1 - 2^-17 to 65535 / 65536
+        const int t = std::min((int)std::floor((double)p * 65536.0 + 0.5), 65535);
         if (t > 0) {
-            d.thresh8 = (uint32_t)t;
-            d.inv_keep = 256.0f / (float)(256 - t);
-            d.keep_prob = (float)(256 - t) / 256.0f;
+            d.thresh16 = (uint32_t)t;
+            d.thresh8 = (uint32_t)t >> 8;
+            d.frac8 = (uint32_t)t & 255u;
+            d.inv_keep = (float)(65536.0 / (double)(65536 - t));
+            d.keep_prob = (float)((double)(65536 - t) / 65536.0);
         }
     }
     return d;
@@ -1152,7 +1154,7 @@ int v1t_dropout_mask(uint64_t seed, uint32_t stream_id, float p, long long rows,
 
 float v1t_attention_dropout_rate(float p) {
     const AttnDrop d = make_adrop(p > 0.f, p, 0, 0);
-    return (float)d.thresh8 / 256.0f;
+    return (float)((double)d.thresh16 / 65536.0);
 }
 
 int v1t_gaussian2d_forward(const float* z, long long zsb, long long zsc, int B, int C, int H, int W, int N, const float* grid,
@@ -1254,6 +1256,15 @@ int v1t_elu1_poisson(const float* u, const float* y, long long n, float loss_sca
     LossArgs a{};
     a.u = u; a.y = y; a.yhat = yhat; a.du = du; a.loss = loss; a.n = n; a.loss_scale = loss_scale; a.gscale = gscale;
     return launch_elu1_poisson(a, (hipStream_t)stream);
+}
+
+int v1t_poisson_loss(const float* y_pred, const float* y_true, long long n, float eps, float loss_scale, float* dy, float* loss, void* stream) {
+    if (!y_pred || !y_true || !loss || n < 0) return V1T_ERR_ARG;
+    return launch_poisson_loss(y_pred, y_true, n, eps, loss_scale, dy, loss, (hipStream_t)stream);
+}
+int v1t_elu1_backward(const float* u, const float* y, const float* g, long long n, float* du, void* stream) {
+    if (!u || !y || !g || !du || n < 0) return V1T_ERR_ARG;
+    return launch_elu1_bwd(u, y, g, n, du, (hipStream_t)stream);
 }
 
 int v1t_adamw_step(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,

@@ -319,8 +319,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     const uint32_t T2 = (uint32_t)(a.T + 1) >> 1;
     const uint32_t dbase = a.adrop.key + ((uint32_t)(b * a.H + h) * T2 + ((uint32_t)q >> 1)) * ADROP_K1 + (uint32_t)(2 * h2) * ADROP_K2;
     const uint32_t sh_even = 16 * (q & 1), sh_odd = sh_even + 8;
-    const uint32_t thr8v = a.adrop.thresh8;
-    (void)sh_odd; (void)thr8v;
+    const uint32_t tile_bh = (uint32_t)(b * a.H + h), tile_nqb = (uint32_t)(a.T + 31) >> 5, tile_qb = (uint32_t)(q0 >> 5) + (uint32_t)wave;  // wave-uniform
+    (void)sh_odd; (void)tile_bh; (void)tile_nqb; (void)tile_qb;
 
     const int koff = (lane & 31) * G::RSTR + 8 * h2;
     const int voff = tr_lane_off(lane, G::TSTR);
@@ -397,6 +397,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
             dmaV.issue(vbase, 64 * next_stage, a.T, sV[next_stage & 1]);
         }
         KP_STAMP(3);
+        uint32_t thr8v = 0;  // byte threshold of this 32 x 32 tile (common.h: dithered per tile, scalar arithmetic)
+        if constexpr (DROP) thr8v = attn_tile_thresh(a.adrop, tile_bh, tile_nqb, tile_qb, (uint32_t)kt);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint32_t wq[2] = {0u, 0u};
@@ -414,9 +416,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
                 if constexpr (DROP) {
                     float pd;
                     if ((j & 1) == 0)
-                        asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(wq[j >> 1]), "v"(thr8v), "v"(p) : "vcc");
+                        asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(wq[j >> 1]), "s"(thr8v), "v"(p) : "vcc");
                     else
-                        asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(wq[j >> 1]), "v"(thr8v), "v"(p) : "vcc");
+                        asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(wq[j >> 1]), "s"(thr8v), "v"(p) : "vcc");
                     s[4 * g + j] = pd;
                 } else {
                     s[4 * g + j] = p;
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(128 * F3_PAIRS, 4) void attn_fwd3_kernel(AttnArgs a
         const float p = fast_exp2(fmaf(s[r], c, negm));
         lsum += p;
         if constexpr (DROP) {
-            const bool keep = __builtin_amdgcn_ubfe(jx < 2 ? w0 : w1, (jx & 1) ? sh_odd : sh_even, 8u) >= a.adrop.thresh8;
+            const bool keep = __builtin_amdgcn_ubfe(jx < 2 ? w0 : w1, (jx & 1) ? sh_odd : sh_even, 8u) >= attn_tile_thresh(a.adrop, (uint32_t)(b * a.H + h), (uint32_t)(a.T + 31) >> 5, (uint32_t)q >> 5, (uint32_t)t);
             s[r] = keep ? p : 0.f;
         } else {
             s[r] = p;
@@ -876,7 +878,7 @@ DEVFN void attn_bwd_dq_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& ld
         for (int g = 0; g < 4; ++g) {
             bool keep[4] = {true, true, true, true};
             if constexpr (DROP)
-                drop4(dbase + (uint32_t)(32 * kt + 16 * hf + 4 * g) * ADROP_K2, ADROP_K2, sh_even, sh_odd, a.adrop.thresh8, keep);
+                drop4(dbase + (uint32_t)(32 * kt + 16 * hf + 4 * g) * ADROP_K2, ADROP_K2, sh_even, sh_odd, attn_tile_thresh(a.adrop, (uint32_t)(b * a.H + h), (uint32_t)(a.T + 31) >> 5, (uint32_t)q >> 5, (uint32_t)(2 * kt + hf)), keep);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * g + j;
@@ -1050,7 +1052,7 @@ DEVFN void attn_bwd_dkv_body(const AttnArgs& a, int bid, int nblk, BwdLds<DP>& l
             const f32x4 dl = *(const f32x4*)(&sDl[buf][32 * hf + 8 * g + 4 * h2]);
             bool keep[4] = {true, true, true, true};
             if constexpr (DROP)
-                drop4(dbase + (uint32_t)(32 * qt + 16 * hf + 4 * g) * ADROP_K1, ADROP_K1, sh_even, sh_odd, a.adrop.thresh8, keep);
+                drop4(dbase + (uint32_t)(32 * qt + 16 * hf + 4 * g) * ADROP_K1, ADROP_K1, sh_even, sh_odd, attn_tile_thresh(a.adrop, (uint32_t)(b * a.H + h), (uint32_t)(a.T + 31) >> 5, (uint32_t)(2 * qt + hf), (uint32_t)key >> 5), keep);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * g + j;
@@ -1500,7 +1502,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     // (v_cmp_ge_u32_sdwa): compare + select per element. (Rounds 2-3: a 9-bit SWAR preparation per word - and / or / sub - then a 1-bit v_bfe_i32
     // and a v_and per element; same decisions bit for bit, 24 vector instructions fewer per 32 x 32 block: backward pair 2519 / 2530 -> 2480 / 2484 us,
     // profiles/r04_attn_experiments.txt #6.)
-    const uint32_t dthr8 = a.adrop.thresh8;
+    const uint32_t tile_nqb = (uint32_t)nq, tile_kb = (uint32_t)(rb * 4 + pw);  // per-tile byte threshold (common.h): wave-uniform, scalar arithmetic
     auto keep_word = [&](int blk, int wi) { return mix1(dbase + (uint32_t)(16 * blk + 4 * (wi >> 1) + (wi & 1)) * ADROP_K1) >> dshift; };
 
     if (wave < 4) {
@@ -1590,6 +1592,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
 #pragma unroll
             for (int m = 0; m < LA; ++m) fr[m] = frag(m);
             u32x4 kw[2] = {};
+            uint32_t dthr8 = 0;
+            if constexpr (DROP) dthr8 = attn_tile_thresh(a.adrop, (uint32_t)bh, tile_nqb, (uint32_t)i, tile_kb);
             u32x4* hb = lds.hand[i & 1][pw][0];
             KP_STAMP(1);
             KS_MARK(2);
@@ -1618,9 +1622,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
                             if ((j & 1) == 0) kw[wi >> 2][wi & 3] = keep_word(i, wi);
                             float pd;
                             if ((j & 1) == 0)
-                                asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(kw[wi >> 2][wi & 3]), "v"(dthr8), "v"(p) : "vcc");
+                                asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(kw[wi >> 2][wi & 3]), "s"(dthr8), "v"(p) : "vcc");
                             else
-                                asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(kw[wi >> 2][wi & 3]), "v"(dthr8), "v"(p) : "vcc");
+                                asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(pd) : "v"(kw[wi >> 2][wi & 3]), "s"(dthr8), "v"(p) : "vcc");
                             dp[r] = fmaf(pd, dp[r], p * nd[r]);
                             s[r] = pd;
                         } else {
@@ -1970,7 +1974,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq2_kernel(AttnArgs a) {
                 }
         }
     }
-    const float f = a.scale[a.scale_per_head ? h : 0] * (a.adrop.thresh8 ? a.adrop.inv_keep : 1.0f);
+    const float f = a.scale[a.scale_per_head ? h : 0] * (a.adrop.thresh16 ? a.adrop.inv_keep : 1.0f);
     const int dcol = lane & 31;
 #pragma unroll
     for (int u = 0; u < QPW; ++u)
@@ -2042,13 +2046,13 @@ int launch_delta_t(const AttnArgs& a, float* delta, hipStream_t s) {
 
 template <int DP>
 int fwd_flags(const AttnArgs& a, hipStream_t s) {
-    const bool drop = a.adrop.thresh8 != 0, diag = a.mask_diag != 0;
+    const bool drop = a.adrop.thresh16 != 0, diag = a.mask_diag != 0;
     if (drop) return diag ? launch_fwd_t<DP, true, true>(a, s) : launch_fwd_t<DP, true, false>(a, s);
     return diag ? launch_fwd_t<DP, false, true>(a, s) : launch_fwd_t<DP, false, false>(a, s);
 }
 template <int DP>
 int bwd_flags(const AttnArgs& a, hipStream_t s) {
-    const bool drop = a.adrop.thresh8 != 0, diag = a.mask_diag != 0;
+    const bool drop = a.adrop.thresh16 != 0, diag = a.mask_diag != 0;
     if (drop) return diag ? launch_bwd_t<DP, true, true>(a, s) : launch_bwd_t<DP, true, false>(a, s);
     return diag ? launch_bwd_t<DP, false, true>(a, s) : launch_bwd_t<DP, false, false>(a, s);
 }

@@ -269,24 +269,45 @@ struct DropCfg {
 // Attention-P dropout: B*H*T*T decisions per block and pass, evaluated inside three MFMA kernels, so the
 // mask must be cheap. One 32-bit word serves a 2x2 block of (query, key): word(bh, q>>1, k>>1) =
 // mix1(key + (bh*T2 + (q>>1))*K1 + (k>>1)*K2), T2 = (T+1)/2; element (q,k) keeps iff
-// byte[2*(q&1) + (k&1)] >= thresh8. The rate is therefore quantised to thresh8/256 (0.2544 -> 65/256 =
-// 0.2539) and 1/keep uses the quantised rate, so the estimator stays unbiased. mix1 is one
-// xorshift-multiply-xorshift round (byte uniformity / neighbour correlation checked).
+// byte[2*(q&1) + (k&1)] >= thr. Byte decisions alone quantise the rate to 1/256 (rounds 1-4: 0.2544 -> 65/256 =
+// 0.2539); since round 5 the threshold is dithered per 32 x 32 tile of (query, key): with the rate as
+// thresh16 / 65536 a tile compares against thr = (thresh16 + f) >> 8, f = the top byte of the Weyl sum
+// key + TILE + (bh*nqb + (q>>5))*K1 + (k>>5)*K2 - i.e. against thresh8 + 1 in a fraction frac8 / 256 of the tiles
+// (equidistributed over the rows and columns of tiles: an additive golden-ratio recurrence, lower variance than
+// a hash; `key` moves the pattern every step, block and (image, head)) and against thresh8 = thresh16 >> 8 in
+// the others. Five scalar instructions per tile on wave-uniform values. An element's keep probability (over
+// the keys) is then exactly 1 - thresh16/65536 (0.2544 -> 0.25439453, 2e-5 relative) at the cost of the byte
+// scheme; elements of a tile share the choice, which correlates two of them by
+// frac (1 - frac) / 65536 / (p (1 - p)), frac = frac8 / 256: 9e-6 at the default rate. 1/keep uses the 16-bit
+// rate, so the estimator stays unbiased. (Tried in round 5, profiles/r05_small_launch_experiments.txt #21:
+// 16-bit decisions, one word per query and key pair - dK/dV kernel + 5 %, + 3 % with DPP-shared words; a hashed
+// per-tile dither behind a wave-uniform branch - forward + 5 %; branch-free - step + 0.5 %.)
+// mix1 is one xorshift-multiply-xorshift round (byte uniformity / neighbour correlation checked).
 DEVFN uint32_t mix1(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
     return x;
 }
 #define ADROP_K1 0x9E3779B1u
 #define ADROP_K2 0x85EBCA77u
+#define ADROP_TILE 0x68E31DA4u  // key offset of the per-tile threshold words
 struct AttnDrop {
-    uint32_t key;      // drop_key(seed, stream)
-    uint32_t thresh8;  // 0 => disabled; keep iff byte >= thresh8
-    float inv_keep;    // 256 / (256 - thresh8)
-    float keep_prob;   // (256 - thresh8) / 256
+    uint32_t key;       // drop_key(seed, stream)
+    uint32_t thresh16;  // 0 => disabled; rate = thresh16 / 65536
+    uint32_t thresh8;   // thresh16 >> 8: a tile keeps iff byte >= thresh8 (+ 1 in a dithered tile)
+    uint32_t frac8;     // thresh16 & 255: the fraction of dithered tiles, in 1/256
+    float inv_keep;     // 65536 / (65536 - thresh16)
+    float keep_prob;    // (65536 - thresh16) / 65536
 };
-DEVFN bool attn_drop_keep(uint32_t key, uint32_t bh, uint32_t T2, uint32_t q, uint32_t k, uint32_t thresh8) {
-    const uint32_t w = mix1(key + (bh * T2 + (q >> 1)) * ADROP_K1 + (k >> 1) * ADROP_K2);
-    return ((w >> (8 * (2 * (q & 1) + (k & 1)))) & 0xFFu) >= thresh8;
+// byte threshold of the 32 x 32 tile (qblk, kblk) = (q >> 5, k >> 5) of (image, head) bh; nqb = ceil(T / 32). Branch-free on purpose: a
+// wave-uniform branch here splits the softmax stretch of the attention kernels into basic blocks (forward + 5 %).
+DEVFN uint32_t attn_tile_thresh(const AttnDrop& d, uint32_t bh, uint32_t nqb, uint32_t qblk, uint32_t kblk) {
+    const uint32_t f = (d.key + ADROP_TILE + (bh * nqb + qblk) * ADROP_K1 + kblk * ADROP_K2) >> 24;
+    return (d.thresh16 + f) >> 8;
+}
+DEVFN bool attn_drop_keep(const AttnDrop& d, uint32_t bh, uint32_t T, uint32_t q, uint32_t k) {
+    const uint32_t T2 = (T + 1) >> 1, nqb = (T + 31) >> 5;
+    const uint32_t w = mix1(d.key + (bh * T2 + (q >> 1)) * ADROP_K1 + (k >> 1) * ADROP_K2);
+    return ((w >> (8 * (2 * (q & 1) + (k & 1)))) & 0xFFu) >= attn_tile_thresh(d, bh, nqb, q >> 5, k >> 5);
 }
 
 DEVFN float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32

@@ -166,6 +166,8 @@ struct LossArgs {
     float gscale;        // upstream gradient of the loss (1 for plain training)
 };
 int launch_elu1_poisson(const LossArgs& a, hipStream_t s);
+int launch_poisson_loss(const float* yp, const float* yt, long long n, float eps, float scale, float* dy, float* loss, hipStream_t s);
+int launch_elu1_bwd(const float* u, const float* y, const float* g, long long n, float* du, hipStream_t s);
 constexpr int LOSS_MAX_UNITS = 8, ADAM_MAX_RANGES = 24;
 int launch_elu1_poisson_multi(const LossArgs* a, int n, hipStream_t s);  // n <= LOSS_MAX_UNITS units in one launch
 int launch_adamw_multi(const AdamArgs* a, int n, hipStream_t s);         // any n: one launch per ADAM_MAX_RANGES pieces

@@ -856,6 +856,26 @@ __global__ void elu1_poisson_multi_kernel(LossMulti m) {
     while (u + 1 < m.n && (int)blockIdx.x >= m.start[u + 1]) ++u;
     elu1_poisson_body(m.a[u], blockIdx.x - m.start[u], m.start[u + 1] - m.start[u], sred);
 }
+// PoissonLoss on the model's output (losses.py:141-166 + scale_ds :114-119): the reference criterion's call - add eps to both, sum(y_pred -
+// y_true log y_pred), x sqrt(ds_size / batch) - as ONE launch that also leaves dLoss/dy_pred (the reference's graph: add, add, log, mul, sub,
+// sum, mul = 7 launches forward and as many backward on a (16, 8000) tensor, in a loop whose small launches the host can barely keep fed).
+__global__ void poisson_loss_kernel(const float* __restrict__ yp_, const float* __restrict__ yt_, long long n, float eps, float scale, float* dy, float* loss) {
+    __shared__ float sred[4];
+    float ls = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float yt = yt_[i] + eps, yp = yp_[i] + eps;
+        ls += yp - yt * logf(yp);
+        if (dy) dy[i] = scale * (1.f - yt / yp);
+    }
+    ls = wave_sum(ls);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = ls;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (sred[0] + sred[1] + sred[2] + sred[3]) * scale);
+}
+// backward of ELU + 1 (models/utils.py:109-118): du = g (u > 0 ? 1 : exp(u) = y) - compare, ones, where, mul as one launch
+__global__ void elu1_bwd_kernel(const float* __restrict__ u, const float* __restrict__ y, const float* __restrict__ g, long long n, float* du) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) du[i] = g[i] * (u[i] > 0.f ? 1.f : y[i]);
+}
 // zero fill (the step's token-gradient buffer and small accumulators): 16 B per lane, tail by bytes
 __global__ __launch_bounds__(256) void fill_zero_kernel(char* p, long long bytes) {
     const long long n16 = bytes >> 4;
@@ -873,11 +893,10 @@ __global__ void dropout_mask_kernel(uint8_t* out, long long rows, long long cols
 
 __global__ void attn_dropout_mask_kernel(uint8_t* out, long long rows, long long T, AttnDrop d) {
     const long long total = rows * T;
-    const uint32_t T2 = (uint32_t)(T + 1) >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const uint32_t row = (uint32_t)(i / T), k = (uint32_t)(i % T);
         const uint32_t bh = row / (uint32_t)T, q = row % (uint32_t)T;
-        out[i] = (d.thresh8 == 0 || attn_drop_keep(d.key, bh, T2, q, k, d.thresh8)) ? 1 : 0;
+        out[i] = (d.thresh16 == 0 || attn_drop_keep(d, bh, (uint32_t)T, q, k)) ? 1 : 0;
     }
 }
 
@@ -1152,6 +1171,16 @@ int launch_fill_zero(void* p, long long bytes, hipStream_t s) {
 int launch_elu1_poisson(const LossArgs& a, hipStream_t s) {
     if (a.n <= 0) return V1T_OK;
     hipLaunchKernelGGL(elu1_poisson_kernel, dim3(nblocks(a.n, 1024)), dim3(256), 0, s, a);
+    return ok();
+}
+int launch_poisson_loss(const float* yp, const float* yt, long long n, float eps, float scale, float* dy, float* loss, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(poisson_loss_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, yp, yt, n, eps, scale, dy, loss);
+    return ok();
+}
+int launch_elu1_bwd(const float* u, const float* y, const float* g, long long n, float* du, hipStream_t s) {
+    if (n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(elu1_bwd_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, u, y, g, n, du);
     return ok();
 }
 int launch_attn_dropout_mask(uint8_t* out, long long rows, long long T, AttnDrop d, hipStream_t s) {

@@ -103,6 +103,8 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_core_shifter_forward": (c_int, [c_int] + [c_void_p] * 9),
     "v1t_core_shifter_backward": (c_int, [c_int] + [c_void_p] * 15),
     "v1t_elu1_poisson": (c_int, [c_void_p, c_void_p, c_ll, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "v1t_poisson_loss": (c_int, [c_void_p, c_void_p, c_ll, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "v1t_elu1_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p]),
     "v1t_readout_grid_backward_ws_bytes": (c_ll, [c_int, c_int]),
     "v1t_readout_grid_backward_ws": (c_int, [c_int, c_int, c_int] + [c_void_p] * 16 + [c_void_p, c_ll, c_void_p]),
     "v1t_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),

@@ -44,8 +44,11 @@ class _Elu1Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        u, y = ctx.saved_tensors
-        return g * torch.where(u > 0, torch.ones_like(u), y)  # d/du (elu(u)+1) = 1 | exp(u) = y (u<=0)
+        u, y = ctx.saved_tensors  # d/du (elu(u) + 1) = 1 | exp(u) = y (u <= 0)
+        g = g.contiguous()
+        du = torch.empty_like(u)
+        L.check(L.load().v1t_elu1_backward(u.data_ptr(), y.data_ptr(), g.data_ptr(), u.numel(), du.data_ptr(), L.stream()), "elu1_backward")
+        return du
 
 
 class _ShifterFn(torch.autograd.Function):
