@@ -281,8 +281,15 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     using G = Geo<DP>;
     // K/V are staged 64 keys at a time (one barrier and one burst of LDS-DMA pieces per 64 keys) and consumed as two
     // 32-key tiles
-    using DmaK = TileDma<DP, G::RSTR, 64, FWD_WAVES>;
-    using DmaV = TileDma<DP, G::TSTR, 64, FWD_WAVES>;
+    // (UNIFORM: every wave issues three K and three V pieces per stage; with the per-wave piece counts - 21 K and 20 V pieces over 8 waves -
+    // and the ragged check the issue was a chain of 13 wave-uniform branches in the middle of part_b's softmax stretch)
+#ifdef V1T_FWD_DMA_BRANCHY  // dev (A/B): the round-4 form
+    constexpr bool DMA_UNI = false;
+#else
+    constexpr bool DMA_UNI = true;
+#endif
+    using DmaK = TileDma<DP, G::RSTR, 64, FWD_WAVES, DMA_UNI>;
+    using DmaV = TileDma<DP, G::TSTR, 64, FWD_WAVES, DMA_UNI>;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][DmaK::LDS_ELEMS];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2][DmaV::LDS_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -372,7 +379,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
             }
         }
     };
-    auto part_b = [&](int kt, int next_stage, f32x16& s, const bf16x8 (&vfr)[2 * G::DB]) __attribute__((always_inline)) {
+    auto part_b = [&](auto rag_tag, int kt, int next_stage, f32x16& s, const bf16x8 (&vfr)[2 * G::DB]) __attribute__((always_inline)) {
+        constexpr bool MAY_RAG = decltype(rag_tag)::value;  // may the stage issued here reach beyond T (only the last one can)
         mfma_result_fence();
         float pmax = vmax3(s[0], s[1], s[2]);
 #pragma unroll
@@ -393,8 +401,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
         // the next stage's LDS-DMA is issued HERE, in the VALU-only stretch: a piece costs its wave 100-185 cycles of
         // issue while ds_reads are in flight (tile start) but 25-60 when the LDS is quiet (kprof timeline)
         if (next_stage >= 0) {  // wave-uniform
-            dmaK.issue(kbase, 64 * next_stage, a.T, sK[next_stage & 1]);
-            dmaV.issue(vbase, 64 * next_stage, a.T, sV[next_stage & 1]);
+            dmaK.template issue<MAY_RAG>(kbase, 64 * next_stage, a.T, sK[next_stage & 1]);
+            dmaV.template issue<MAY_RAG>(vbase, 64 * next_stage, a.T, sV[next_stage & 1]);
         }
         KP_STAMP(3);
         uint32_t thr8v = 0;  // byte threshold of this 32 x 32 tile (common.h: dithered per tile, scalar arithmetic)
@@ -437,12 +445,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
         KP_FLUSH(kt, wave, lane);
 #endif
     };
-    auto tile = [&](auto tail_tag, int kt, int buf, int next_stage) __attribute__((always_inline)) {
+    auto tile = [&](auto tail_tag, auto rag_tag, int kt, int buf, int next_stage) __attribute__((always_inline)) {
         f32x16 s;
         bf16x8 vfr[2 * G::DB];
         part_a(tail_tag, kt, buf, s, vfr);
-        part_b(kt, next_stage, s, vfr);
+        part_b(rag_tag, kt, next_stage, s, vfr);
     };
+    constexpr std::true_type RAG{};
+    constexpr std::false_type NORAG{};
 
     touch(qf);
     touch(c);
@@ -464,28 +474,36 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
         // Same work per stage, same barriers, same two buffers - only the phase differs, by the length of a softmax + P.V.
         f32x16 sc;
         bf16x8 vc[2 * G::DB];
-        tile(std::false_type{}, 0, 0, 1);
+        tile(std::false_type{}, RAG, 0, 0, 1);
         part_a(std::false_type{}, 1, 0, sc, vc);
         dma_wait_and_barrier();
         for (int st = 1; st < ns - 1; ++st) {
             const int buf = st & 1;
-            part_b(2 * st - 1, st + 1, sc, vc);
-            tile(std::false_type{}, 2 * st, buf, -1);
+            part_b(RAG, 2 * st - 1, st + 1, sc, vc);
+            tile(std::false_type{}, RAG, 2 * st, buf, -1);
             part_a(std::false_type{}, 2 * st + 1, buf, sc, vc);
             dma_wait_and_barrier();
         }
-        part_b(2 * (ns - 1) - 1, -1, sc, vc);
+        part_b(RAG, 2 * (ns - 1) - 1, -1, sc, vc);
     } else {
-        for (int st = 0; st < ns - 1; ++st) {
+        // only the LAST stage can reach beyond T (64 (ns - 1) < T): the steady loop issues stages 1 .. ns - 2 without the ragged check, the
+        // peeled last iteration issues stage ns - 1 with it
+        auto stage = [&](auto rag_tag, int st) __attribute__((always_inline)) {
             const int buf = st & 1;
-            tile(std::false_type{}, 2 * st, buf, st + 1);
-            tile(std::false_type{}, 2 * st + 1, buf, -1);
+            tile(std::false_type{}, rag_tag, 2 * st, buf, st + 1);
+            tile(std::false_type{}, rag_tag, 2 * st + 1, buf, -1);
             dma_wait_and_barrier();
             KP_STAMP(7);
+        };
+        if constexpr (DMA_UNI) {
+            for (int st = 0; st < ns - 2; ++st) stage(NORAG, st);
+            if (ns >= 2) stage(RAG, ns - 2);
+        } else {
+            for (int st = 0; st < ns - 1; ++st) stage(RAG, st);
         }
     }
-    tile(std::true_type{}, 2 * (ns - 1), (ns - 1) & 1, -1);
-    if (2 * (ns - 1) + 1 < nt) tile(std::true_type{}, 2 * (ns - 1) + 1, (ns - 1) & 1, -1);
+    tile(std::true_type{}, RAG, 2 * (ns - 1), (ns - 1) & 1, -1);
+    if (2 * (ns - 1) + 1 < nt) tile(std::true_type{}, RAG, 2 * (ns - 1) + 1, (ns - 1) & 1, -1);
 
     const float ltot = lsum + __shfl_xor(lsum, 32);
     const float inv = (DROP ? a.adrop.inv_keep : 1.0f) / ltot;

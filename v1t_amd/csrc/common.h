@@ -165,14 +165,17 @@ DEVFN void dma_wait_and_barrier() {
 // surplus lanes re-fetch the last row into slack behind the tile (size buffers with LDS_ELEMS).
 // Rows beyond T are clamped to row T-1 (finite data; every consumer masks them): only the ragged last tile
 // takes that path, recomputing its offsets.
-template <int DP, int STR, int ROWS = 32, int NWAVES = 4>
+// UNIFORM: EVERY wave issues all of its PW pieces, no branch on which of them exist (a wave-uniform branch chain per issue otherwise:
+// `cnt` depends on the wave) - pieces beyond the tile re-fetch the tile's last chunk into slack behind it (LDS_ELEMS grows to NWAVES x PW
+// pieces). For issues that sit inside a hand-scheduled stretch, where every branch splits the compiler's scheduling region.
+template <int DP, int STR, int ROWS = 32, int NWAVES = 4, bool UNIFORM = false>
 struct TileDma {
     static constexpr int CPR = STR / 8;                 // chunks per LDS row
     static constexpr int NCH = ROWS * CPR;              // chunks per tile
     static constexpr int NINST = (NCH + 63) / 64;       // pieces per tile
     static constexpr int PW = (NINST + NWAVES - 1) / NWAVES;  // pieces per wave
     static constexpr int NG = (PW + 3) / 4;             // M0 groups per wave
-    static constexpr int LDS_ELEMS = NINST * 512;       // tile + slack of the partial last piece
+    static constexpr int LDS_ELEMS = (UNIFORM ? NWAVES * PW : NINST) * 512;  // tile + slack of the partial last piece (UNIFORM: of the pieces beyond the tile)
     static constexpr int BIAS = 3072;
     unsigned voff[PW];
     int wave, lane, ld;
@@ -206,6 +209,8 @@ struct TileDma {
                          : "=&s"(keep) : "s"(m0v), "v"(v0), "s"(base) : "memory");
     }
     // img: element (row 0, col 0) of this (image, head) slice; t0: first row of the tile; lds: tile base (LDS_ELEMS elements)
+    // MAY_RAG = false: the caller knows that the tile lies wholly inside T (no ragged check in the issue)
+    template <bool MAY_RAG = true>
     DEVFN void issue(const bf16_t* img, int t0_, int T, bf16_t* lds) const {
         // a tile that lies WHOLLY beyond T (the dQ GEMM walks the 128-key padded width of dS': up to three such 32-key tiles when T % 128 <= 96 -
         // first met at T = 34 114, tests/test_gpu_longseq.py; T = 1654 has none) is fetched as T - 1 repeated: without the clamp the row clamp below
@@ -217,7 +222,7 @@ struct TileDma {
         const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)), b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bb);
         const char* base = (const char*)(uintptr_t)(((unsigned long long)b_hi << 32) | (unsigned long long)b_lo);
         const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds);
-        const bool ragged = t0 + ROWS > T;  // wave-uniform
+        const bool ragged = MAY_RAG && t0 + ROWS > T;  // wave-uniform
         unsigned v[PW];
 #pragma unroll
         for (int i = 0; i < PW; ++i) v[i] = voff[i];
@@ -229,7 +234,7 @@ struct TileDma {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int n0 = wave * PW + 4 * g;                       // wave-uniform
-            const int cnt = min(min(4, PW - 4 * g), NINST - n0);    // pieces of this group that exist
+            const int cnt = UNIFORM ? min(4, PW - 4 * g) : min(min(4, PW - 4 * g), NINST - n0);  // pieces of this group that exist (UNIFORM: compile-time)
             const unsigned m0v = __builtin_amdgcn_readfirstlane(l0 + 1024u * (unsigned)n0);
             auto at = [&](int k) { return v[4 * g + k < PW ? 4 * g + k : PW - 1]; };
             if (cnt >= 4) group<4>(base, m0v, at(0), at(1), at(2), at(3));
