@@ -271,6 +271,7 @@ DropCfg make_drop(bool training, float p, uint64_t seed, uint32_t stream) {
 // LayerNorm followed by the GEMM that reads it: one fused A-stationary launch where the shape allows (gemm.h, launch_ln_gemm;
 // fp16 operands, K = DP <= 160, N % 128 == 0), else the two kernels. V1T_LN_FUSE=0 (dev): always the two kernels.
 static const int g_ln_fuse = (std::getenv("V1T_LN_FUSE") && !atoi(std::getenv("V1T_LN_FUSE"))) ? 0 : 1;
+static const int g_mlp_fuse = (std::getenv("V1T_MLP_FUSE") && !atoi(std::getenv("V1T_MLP_FUSE"))) ? 0 : 1;
 static inline int ln_then_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t s) {
     if (g_ln_fuse) {
         const int rc = launch_ln_gemm(l, g, epi, s);
@@ -782,17 +783,24 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         g.C2 = x16a ? nullptr : hact; g.ldc2 = MP; g.bias = b.s_fc1b >= 0 ? (const float*)(sh + b.s_fc1b) : nullptr;
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
         g.lean = lean;
-        CHECK(ln_then_gemm(l2, g, EPI_BIAS_GELU, s));
 
-        g = GemmNTArgs{};
-        g.A = hact; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc2); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = xo; g.ldc = DP;
-        g.A_lo = (const bf16_t*)(wb + w.hact_lo); g.B_lo = (const bf16_t*)(sh + b.s_fc2_lo);
-        if (g_nosplit & 8) g.A_lo = g.B_lo = nullptr;
-        fwd_operands(g);
-        g.bias = b.s_fc2b >= 0 ? (const float*)(sh + b.s_fc2b) : nullptr; g.res = xm; g.ldres = DP;
-        g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 3);
-        g.row_scale = path_scale ? path_scale + (size_t)(2 * k + 1) * B : nullptr; g.T = h->T;
-        CHECK(launch_gemm_nt(g, EPI_BIAS_RES, s));
+        GemmNTArgs g2{};
+        g2.A = hact; g2.lda = MP; g2.B = (const bf16_t*)(sh + b.s_fc2); g2.ldb = MP; g2.M = R; g2.N = DP; g2.K = MP; g2.C = xo; g2.ldc = DP;
+        g2.A_lo = (const bf16_t*)(wb + w.hact_lo); g2.B_lo = (const bf16_t*)(sh + b.s_fc2_lo);
+        if (g_nosplit & 8) g2.A_lo = g2.B_lo = nullptr;
+        fwd_operands(g2);
+        g2.bias = b.s_fc2b >= 0 ? (const float*)(sh + b.s_fc2b) : nullptr; g2.res = xm; g2.ldres = DP;
+        g2.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 3);
+        g2.row_scale = path_scale ? path_scale + (size_t)(2 * k + 1) * B : nullptr; g2.T = h->T;
+        // the whole MLP branch as one launch where the shape allows (gemm.h, launch_mlp_fwd: fp16 operands, DP = 160); V1T_MLP_FUSE=0 (dev, A/B): never
+        int rc_mlp = V1T_ERR_UNSUPPORTED;
+        if (g_mlp_fuse && g_ln_fuse) rc_mlp = launch_mlp_fwd(l2, g, g2, s);
+        if (rc_mlp == V1T_ERR_UNSUPPORTED) {
+            CHECK(ln_then_gemm(l2, g, EPI_BIAS_GELU, s));
+            CHECK(launch_gemm_nt(g2, EPI_BIAS_RES, s));
+        } else {
+            CHECK(rc_mlp);
+        }
         xcur = xo;
     }
     return V1T_OK;

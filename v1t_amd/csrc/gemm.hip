@@ -116,6 +116,52 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
 }
 
 
+// C = res + dropout(acc + bias) * row_scale over a workgroup's BM x 32 NBLK tile whose accumulators hold rows 32 wave + acc_row(r, lane), columns
+// n0 + 32 nb + (lane & 31) (the proj / FC2 epilogue of gemm_nt_kernel; also the tail of mlp_fwd_kernel):
+template <int NBLK, int BM>
+DEVFN void epi_bias_res(const GemmNTArgs& g, f32x16 (&acc)[NBLK], int m0, int n0, int wave, int lane) {
+    const int rows_here = min(BM, g.M - m0);  // < BM in the last row tile only: rows past M then get an out-of-range offset (reads 0, stores dropped)
+    const __amdgpu_buffer_rsrc_t rr = buf_rsrc(g.res ? g.res + (size_t)m0 * g.ldres + n0 : nullptr, g.res ? (uint32_t)rows_here * (uint32_t)g.ldres * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t cr = buf_rsrc((float*)g.C + (size_t)m0 * g.ldc + n0, (uint32_t)rows_here * (uint32_t)g.ldc * 4u);
+    const uint32_t lrow = (uint32_t)(32 * wave + 4 * (lane >> 5));
+    const uint32_t dthr = g.drop.thresh;  // 0 keeps everything (hash >= 0)
+    const float dinv = g.drop.thresh ? g.drop.inv_keep : 1.0f;
+    const uint32_t vres = (lrow * (uint32_t)g.ldres + (uint32_t)(lane & 31)) * 4u, vout = (lrow * (uint32_t)g.ldc + (uint32_t)(lane & 31)) * 4u;
+    auto body = [&](auto ragged_c) __attribute__((always_inline)) {
+        constexpr bool RAGGED = decltype(ragged_c)::value;
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) {
+            if (nb) {  // one column block at a time
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int col = n0 + 32 * nb + (lane & 31);
+            const float bias = g.bias ? g.bias[col] : 0.f;
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ar = (r & 3) + 8 * (r >> 2);
+                uint32_t vo = vres;
+                if (RAGGED && (int)lrow + ar >= rows_here) vo |= BUF_OOB;
+                rv[r] = buf_load_f32(rr, vo, (ar * g.ldres + 32 * nb) * 4);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ar = (r & 3) + 8 * (r >> 2);
+                const uint32_t grow = (uint32_t)m0 + lrow + (uint32_t)ar;
+                const bool keep = drop_hash(g.drop.key, grow, col) >= dthr;
+                float v = keep ? (acc[nb][r] + bias) * dinv : 0.f;
+                if (g.row_scale) v *= g.row_scale[min((int)grow, g.M - 1) / g.T];
+                uint32_t vo = vout;
+                if (RAGGED && (int)lrow + ar >= rows_here) vo |= BUF_OOB;
+                buf_store_f32(cr, vo, (ar * g.ldc + 32 * nb) * 4, rv[r] + v);
+            }
+        }
+    };
+    if (rows_here == BM) body(std::false_type{});  // workgroup-uniform
+    else body(std::true_type{});
+}
+
 // ---- LDS-DMA ring K loop (round 5): launches with at most ONE workgroup per CU ---------------------------------------------------------
 // A launch of <= 256 workgroups (a rank's share of a multi-GPU step, a 16-image launch of the per-mouse loop) runs one 4-wave workgroup per
 // CU, i.e. one wave per SIMD: nothing overlaps a workgroup's K loop, and with the register-staged double buffer a CU has ONE K tile of
@@ -405,46 +451,7 @@ __global__ __launch_bounds__(64 * NW, ((EPI == EPI_BIAS_GELU && BK == 32 && NBLK
         // rows: scalar base, ONE per-lane offset register (row 32 wave + 4 (lane >> 5), column lane & 31), the accumulator row (r & 3) + 8 (r >> 2)
         // and the column block in the scalar offset - no 64-bit address pair per access, the residual of one column block (16 loads) in flight
         // at a time instead of all 16 NBLK values held through the last K tile (152 VGPRs -> two workgroups per CU)
-        const int rows_here = min(BM, g.M - m0);  // < BM in the last row tile only: rows past M then get an out-of-range offset (reads 0, stores dropped)
-        const __amdgpu_buffer_rsrc_t rr = buf_rsrc(g.res ? g.res + (size_t)m0 * g.ldres + n0 : nullptr, g.res ? (uint32_t)rows_here * (uint32_t)g.ldres * 4u : 0u);
-        const __amdgpu_buffer_rsrc_t cr = buf_rsrc((float*)g.C + (size_t)m0 * g.ldc + n0, (uint32_t)rows_here * (uint32_t)g.ldc * 4u);
-        const uint32_t lrow = (uint32_t)(32 * wave + 4 * (lane >> 5));
-        const uint32_t dthr = g.drop.thresh;  // 0 keeps everything (hash >= 0)
-        const float dinv = g.drop.thresh ? g.drop.inv_keep : 1.0f;
-        const uint32_t vres = (lrow * (uint32_t)g.ldres + (uint32_t)(lane & 31)) * 4u, vout = (lrow * (uint32_t)g.ldc + (uint32_t)(lane & 31)) * 4u;
-        auto body = [&](auto ragged_c) __attribute__((always_inline)) {
-            constexpr bool RAGGED = decltype(ragged_c)::value;
-#pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) {
-                if (nb) {  // one column block at a time
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const int col = n0 + 32 * nb + (lane & 31);
-                const float bias = g.bias ? g.bias[col] : 0.f;
-                float rv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ar = (r & 3) + 8 * (r >> 2);
-                    uint32_t vo = vres;
-                    if (RAGGED && (int)lrow + ar >= rows_here) vo |= BUF_OOB;
-                    rv[r] = buf_load_f32(rr, vo, (ar * g.ldres + 32 * nb) * 4);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ar = (r & 3) + 8 * (r >> 2);
-                    const uint32_t grow = (uint32_t)m0 + lrow + (uint32_t)ar;
-                    const bool keep = drop_hash(g.drop.key, grow, col) >= dthr;
-                    float v = keep ? (acc[nb][r] + bias) * dinv : 0.f;
-                    if (g.row_scale) v *= g.row_scale[min((int)grow, g.M - 1) / g.T];
-                    uint32_t vo = vout;
-                    if (RAGGED && (int)lrow + ar >= rows_here) vo |= BUF_OOB;
-                    buf_store_f32(cr, vo, (ar * g.ldc + 32 * nb) * 4, rv[r] + v);
-                }
-            }
-        };
-        if (rows_here == BM) body(std::false_type{});  // workgroup-uniform
-        else body(std::true_type{});
+        epi_bias_res<NBLK, BM>(g, acc, m0, n0, wave, lane);
     } else {
         gemm_epilogue<NBLK, EPI>(g, acc, resv, m0, n0, wave, lane);
     }
@@ -830,6 +837,185 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
         if (tn + nsplit < ntn) swrite(buf ^ 1);
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The whole MLP branch forward in one launch (vit.py:132-154 behind LN2, :356-358): x_out = x + row_scale * dropout(FC2(dropout(GELU(FC1(LN(x)))))).
+// ln_gemm_kernel's FC1 form (4 waves, 128 rows, 64-column weight tiles, the LayerNorm'd rows resident as A fragments) with FC2 folded into its
+// column-tile loop: the fp16 activation tile a wave stages in LDS for its 16-B row stores (the plane the backward's dW2 GEMM reads) IS the A operand
+// of FC2's K-chunk [64 tn, 64 tn + 64) - the wave reads it back as fragments (row = lane, 8 consecutive k) and accumulates x W2^T over the column
+// tiles in 5 more accumulators, against the W2 chunk [DP][64] staged beside the W1 tile. After the last tile the accumulators are FC2's (same
+// layout and same K order as gemm_nt's) and leave through its proj / FC2 epilogue (epi_bias_res). The separate FC2 launch, its read of the
+// activation plane (190 MB per 112-image launch) and its fill / drain disappear; everything the backward reads is written as before.
+// LDS: ONE buffer per weight tile (21.5 + 23 KB; the next tiles wait in registers, two barriers per column tile) + the staging (18.4 KB): 64 KB,
+// two workgroups per CU as ln_gemm_kernel has (double buffers: 109 KB, one workgroup per CU).
+template <int DP>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(LnFwdArgs l, GemmNTArgs g, GemmNTArgs g2) {
+    constexpr int NW = 4, NBLK = 2, NB2 = DP / 32;
+    constexpr int KS = DP / 16, BN = 32 * NBLK, LS = DP + 8, NTH = 64 * NW, KC = DP / 8, BM = 32 * NW;
+    constexpr int CS = BN + 8, L2S = BN + 8, KC2 = BN / 8;
+    constexpr int B_CHUNKS = BN * KC, B_ITERS = (B_CHUNKS + NTH - 1) / NTH;
+    constexpr int W_CHUNKS = DP * KC2, W_ITERS = (W_CHUNKS + NTH - 1) / NTH;
+    __shared__ __attribute__((aligned(16))) bf16_t sB[BN * LS];
+    __shared__ __attribute__((aligned(16))) bf16_t sW2[DP * L2S];
+    __shared__ __attribute__((aligned(16))) bf16_t stg[NW][32 * CS];
+    __shared__ __attribute__((aligned(16))) float sgb[2][DP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r31 = lane & 31, h2 = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int ntn = g.N / BN;
+
+    u32x4 rb[B_ITERS], rw[W_ITERS];
+    auto gload = [&](int tn) {
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + NTH * i, brow = c / KC, kc = c % KC;
+            if (c < B_CHUNKS) rb[i] = *(const u32x4*)(g.B + (size_t)(tn * BN + brow) * g.ldb + 8 * kc);
+        }
+#pragma unroll
+        for (int i = 0; i < W_ITERS; ++i) {
+            const int c = tid + NTH * i, n = c / KC2, kc = c % KC2;
+            if (c < W_CHUNKS) rw[i] = *(const u32x4*)(g2.B + (size_t)n * g2.ldb + tn * BN + 8 * kc);
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + NTH * i, brow = c / KC, kc = c % KC;
+            if (c < B_CHUNKS) *(u32x4*)(&sB[brow * LS + 8 * kc]) = rb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W_ITERS; ++i) {
+            const int c = tid + NTH * i, n = c / KC2, kc = c % KC2;
+            if (c < W_CHUNKS) *(u32x4*)(&sW2[n * L2S + 8 * kc]) = rw[i];
+        }
+    };
+    gload(0);  // in flight during the LayerNorm
+    if (tid < DP) {
+        sgb[0][tid] = tid < l.D ? l.gamma[tid] : 0.f;
+        sgb[1][tid] = tid < l.D ? l.beta[tid] : 0.f;
+    }
+
+    // ---- LayerNorm of this lane's half row (columns 16 ks + 8 h2 + e): ln_gemm_kernel's prologue (no injection in front of LN2)
+    bf16x8 afrag[KS];
+    {
+        const int row = m0 + 32 * wave + r31;
+        const bool rok = row < l.rows;
+        const int rr = rok ? row : l.rows - 1;
+        float xv[KS][8];
+        const float* xp = l.x + (size_t)rr * DP + 8 * h2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 a = *(const f32x4*)(xp + 16 * ks), b = *(const f32x4*)(xp + 16 * ks + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[ks][e] = a[e];
+                xv[ks][4 + e] = b[e];
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (ks >= KS - 2 && 16 * ks + 8 * h2 + e >= l.D) xv[ks][e] = 0.f;  // pad columns (D > DP - 32) stay out of the statistics
+                sum += xv[ks][e];
+            }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum / l.D;
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (ks >= KS - 2 && 16 * ks + 8 * h2 + e >= l.D) ? 0.f : xv[ks][e] - mean;
+                q += d * d;
+            }
+        q += __shfl_xor(q, 32);
+        const float rstd = rsqrtf(q / l.D + l.eps);
+        const bool wz = rok && !l.lean;  // the LayerNorm plane and its statistics: read by the backward only
+        if (wz && h2 == 0) {
+            l.mean[row] = mean;
+            l.rstd[row] = rstd;
+        }
+        __syncthreads();  // gamma / beta staged
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c0 = 16 * ks + 8 * h2;
+            const f32x4 g0 = *(const f32x4*)&sgb[0][c0], g1 = *(const f32x4*)&sgb[0][c0 + 4];
+            const f32x4 b0 = *(const f32x4*)&sgb[1][c0], b1 = *(const f32x4*)&sgb[1][c0 + 4];
+            bf16x8 zh;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int cc = c0 + e;
+                const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
+                float z = (xv[ks][e] - mean) * rstd * ga + be;
+                if (ks >= KS - 2 && cc >= l.D) z = (cc == l.ones_col) ? 1.f : 0.f;
+                zh[e] = (bf16_t)z;
+                afrag[ks][e] = aux_plane(z, zh[e], 1);
+            }
+            if (wz) *(bf16x8*)(l.z + (size_t)row * DP + c0) = zh;
+        }
+    }
+
+    bf16_t* st = stg[wave];
+    auto staged_store = [&](f32x16 (&acc)[NBLK], bf16_t* dst, int ld, int n0, auto conv) {
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[acc_row(r, lane) * CS + 32 * nb + r31] = conv(acc[nb][r]);
+        constexpr int CPR = BN / 8;
+#pragma unroll
+        for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
+            const int c = c0 + lane, crow = c / CPR, ch = c % CPR;
+            const int grow = m0 + 32 * wave + crow;
+            if (grow < g.M) *(u32x4*)(dst + (size_t)grow * ld + n0 + 8 * ch) = *(const u32x4*)(st + crow * CS + 8 * ch);
+        }
+    };
+    f32x16 acc2[NB2];
+#pragma unroll
+    for (int d = 0; d < NB2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[d][r] = 0.f;
+    swrite();
+    __syncthreads();
+    const int boff = r31 * LS + 8 * h2, woff = r31 * L2S + 8 * h2, aoff = r31 * CS + 8 * h2;
+    for (int tn = 0; tn < ntn; ++tn) {
+        const int n0 = tn * BN;
+        {
+            f32x16 acc[NBLK];
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mfma32h(afrag[ks], *(const bf16x8*)(&sB[32 * nb * LS + boff + 16 * ks]), acc[nb]);
+            f32x16 resv[NBLK];
+            gemm_epilogue<NBLK, EPI_BIAS_GELU, true>(g, acc, resv, m0, n0, wave, lane);  // gelu' written (fragment order), activation left in acc
+            if (g.C2) staged_store(acc, g.C2, g.ldc2, n0, [](float v) { return (bf16_t)v; });
+            staged_store(acc, g.C2_lo, g.ldc2, n0, [](float v) { return aux_plane(v, (bf16_t)v, 1); });  // last: the staging now holds the fp16 tile
+        }
+        // the next tiles' loads go out HERE, behind the element-wise stage (its registers are free again) and in front of FC2's MFMAs, which
+        // cover most of their L2 latency: held across the GELU stage the 40 staging registers spilled
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (tn + 1 < ntn) gload(tn + 1);
+        // ---- FC2 over this K-chunk: A = the staged tile (this wave's own region: its LDS operations execute in order), B = the W2 chunk
+#pragma unroll
+        for (int ks2 = 0; ks2 < BN / 16; ++ks2) {
+            const bf16x8 a2 = *(const bf16x8*)(st + aoff + 16 * ks2);
+#pragma unroll
+            for (int d = 0; d < NB2; ++d) acc2[d] = mfma32h(a2, *(const bf16x8*)(&sW2[32 * d * L2S + woff + 16 * ks2]), acc2[d]);
+        }
+        __syncthreads();  // every wave is done with this tile's sB / sW2
+        if (tn + 1 < ntn) {
+            swrite();
+            __syncthreads();
+        }
+    }
+    epi_bias_res<NB2, BM>(g2, acc2, m0, 0, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1473,6 +1659,17 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
         default: return V1T_ERR_UNSUPPORTED;
     }
 #undef LNG_CASE
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+
+// LN2 -> FC1 (+ GELU, dropout) -> FC2 (+ bias, dropout, residual) as one launch (mlp_fwd_kernel). l / g as for launch_ln_gemm(EPI_BIAS_GELU), g2 as for
+// launch_gemm_nt(EPI_BIAS_RES) with A = g's fp16 activation plane. V1T_ERR_UNSUPPORTED: use those two.
+int launch_mlp_fwd(const LnFwdArgs& l, const GemmNTArgs& g, const GemmNTArgs& g2, hipStream_t s) {
+    if (l.DP != 160 || g.K != l.DP || g.M != l.rows || !g.f16 || !g2.f16 || g.A_lo || g.B_lo || g2.A_lo || g2.B_lo || l.inject) return V1T_ERR_UNSUPPORTED;
+    if (g.N % 64 != 0 || g2.K != g.N || g2.N != l.DP || g2.M != g.M || !g.C2_lo || g2.A != g.C2_lo || g2.lda != g.ldc2 || (g.ldb % 8) || (g2.ldb % 8)) return V1T_ERR_UNSUPPORTED;
+    if (!g2.res || g2.res != l.x || g2.ldres != l.DP || !g2.C || g2.rd.o || g.rd.o) return V1T_ERR_UNSUPPORTED;
+    if (g.M <= 0) return V1T_OK;
+    hipLaunchKernelGGL((mlp_fwd_kernel<160>), dim3((g.M + 127) / 128), dim3(256), 0, s, l, g, g2);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 
