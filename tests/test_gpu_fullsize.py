@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from oracle import weights as W
-from tests.helpers import check_rel, assert_close, build_native_model, rel_to_max
+from tests.helpers import check_rel_bulk, check_rel, assert_close, build_native_model, rel_to_max
 
 pytestmark = pytest.mark.gpu
 Y_RTOL, Y_ATOL = 1e-3, 1e-6
@@ -112,8 +112,10 @@ def test_c2_batched_backward_equals_per_mouse_loop_full_size(dev):
     assert abs(float(torch.stack(losses).sum()) - ref_loss) <= 1e-4 * abs(ref_loss)
     for k in ref:
         assert bool(torch.isfinite(got[k]).all()), k
-        # same bf16 operands, other tile shapes / summation orders; bf16-rounded intermediates (dS', dY) may round differently
-        check_rel(f"c2x112 forward_mice vs per-mouse loop: arena {k}", got[k], ref[k], 2e-4)
+        # same bf16 operands, other tile shapes / summation orders / kernels (the 112-image pass runs the fused MLP forward, the 16-image passes
+        # LN2 + FC1 and FC2 as two launches); bf16-rounded intermediates (dS', dY) may round differently and move one row of a gradient: all but
+        # 0.1 % of an arena's elements within 1e-4 of its max, the rest within 1e-3 (tests/helpers.py::check_rel_bulk)
+        check_rel_bulk(f"c2x112 forward_mice vs per-mouse loop: arena {k}", got[k], ref[k], 1e-4, 1e-3)
     # per-tensor check of the core (a max over the arena is dominated by the largest tensor)
     for s in model.core._arena.slots:
         if not s.is_param:
@@ -143,7 +145,7 @@ def test_c2_batched_backward_equals_per_mouse_loop_full_size(dev):
     assert set(rec) == set(ref)
     for k in ref:
         assert bool(torch.isfinite(rec[k]).all()), k
-        check_rel(f"c2x112 native step vs per-mouse loop: arena {k}", rec[k], ref[k], 2e-4)
+        check_rel_bulk(f"c2x112 native step vs per-mouse loop: arena {k}", rec[k], ref[k], 1e-4, 1e-3)  # (as above: other kernels at 112 than at 16 images)
     for s in model.core._arena.slots:
         if not s.is_param:
             continue
@@ -275,7 +277,12 @@ def test_c5_rollout_batch_256(dev):
     for idx in ([0, 1], [255, 7]):
         small = rollout_rows(core, b["image"][idx], b["behavior"][idx], b["pupil_center"][idx], "A")
         for j, i in enumerate(idx):
-            check_rel(f"c5@256 row chain, image {i} vs the same image in a batch of 2", rows[i], small[j], 2e-5)
+            # the same image through other launch shapes: at batch 256 the MLP branch runs as ONE launch (mlp_fwd_kernel, above 256 row tiles), at
+            # batch 2 as ln_gemm + gemm_nt - the same operands and K order, but the compiler contracts the GELU arithmetic of the two
+            # instantiations differently: half of the tokens differ in their last bits (<= 1e-4 absolute, tools/mlp_probe.py) and four blocks of
+            # softmax carry that into the rows. 3e-4 of a row's max is 7x under the bound against the oracle (2e-3, test_gpu_parity.py) and far under
+            # what an indexing error across the batch would show (another image's row: O(1))
+            check_rel(f"c5@256 row chain, image {i} vs the same image in a batch of 2", rows[i], small[j], 3e-4)
     full = rollout_rows(core, b["image"], b["behavior"], b["pupil_center"], "A", full_chain=True)
     assert full.shape == rows.shape
     for i in (0, 1, 100, 255):

@@ -698,3 +698,51 @@ def test_fused_poisson_criterion_and_elu1_backward_vs_torch(ctx):
     # no-grad call (validation): no gradient buffer, same value
     with torch.no_grad():
         assert abs(float(crit(y_true=y_true, y_pred=y_pred.detach(), mouse_id="A")) - float(ref)) <= 2e-6 * abs(float(ref))
+
+
+@pytest.mark.parametrize("images,train", [(3, True), (2, False)])
+def test_fused_mlp_forward_equals_two_launches(images, train):
+    """The MLP branch forward as ONE launch (gemm.hip mlp_fwd_kernel: LN2 -> FC1 -> GELU -> dropout -> FC2 -> dropout -> + residual; default
+    above 256 row tiles, forced here with V1T_MLP_FUSE=2) against ln_gemm + gemm_nt (V1T_MLP_FUSE=0; the switch is read once per process: two
+    subprocesses) at the default width (D = 155 -> 160, MLP 488 -> 512), ragged last row tile, dropout masks on (counter-based: identical in
+    both runs): core output, and - through the planes the forward saves for the backward (LayerNorm output + statistics, gelu', the fp16
+    activation) - the loss gradient of every core parameter. Same operands, same K order of FC2's accumulation."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from oracle import v1t_oracle as O
+from oracle import weights as W
+from tests.helpers import build_native_model
+images, train = int(sys.argv[2]), bool(int(sys.argv[3]))
+dev = torch.device("cuda:0")
+cfg = O.Config(num_blocks=2, emb_dim=155, mlp_dim=488, num_heads=4, patch_stride=2, mouse_ids=("A",), num_neurons={"A": 40},
+               p_dropout=0.2 if train else 0.0, t_dropout=0.1 if train else 0.0)
+sd = W.make_state_dict(cfg, 7)
+model, _ = build_native_model(cfg, sd, dev)
+model.train(train)
+b = {k: v.to(dev) for k, v in W.make_batch(cfg, "A", images, 7).items()}
+model.core.prepare()
+model.core._arena.attach_grads()
+model.core._arena.grad.zero_()
+torch.manual_seed(0)
+u = model(inputs=b["image"], mouse_id="A", behaviors=b["behavior"], pupil_centers=b["pupil_center"], activate=False)[0]
+(u * torch.linspace(-1, 1, u.numel(), device=dev).view_as(u)).sum().backward()
+torch.cuda.synchronize()
+torch.save({"u": u.detach().cpu(), "g": model.core._arena.grad.cpu()}, sys.argv[1])
+'''
+    outs = []
+    for fuse in ("0", "2"):
+        path = f"/tmp/v1t_mlpfuse_{fuse}.pt"
+        env = dict(os.environ, V1T_MLP_FUSE=fuse)
+        r = subprocess.run([sys.executable, "-c", code, path, str(images), str(int(train))], env=env, capture_output=True, text=True,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(path))
+    a, b = outs
+    assert bool(torch.isfinite(b["u"]).all()) and bool(torch.isfinite(b["g"]).all())
+    check_rel("test_fused_mlp_forward_equals_two_launches:u", b["u"], a["u"], 2e-5)
+    check_rel("test_fused_mlp_forward_equals_two_launches:g", b["g"], a["g"], 2e-5)

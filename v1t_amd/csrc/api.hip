@@ -792,7 +792,8 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
         g2.bias = b.s_fc2b >= 0 ? (const float*)(sh + b.s_fc2b) : nullptr; g2.res = xm; g2.ldres = DP;
         g2.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 3);
         g2.row_scale = path_scale ? path_scale + (size_t)(2 * k + 1) * B : nullptr; g2.T = h->T;
-        // the whole MLP branch as one launch where the shape allows (gemm.h, launch_mlp_fwd: fp16 operands, DP = 160); V1T_MLP_FUSE=0 (dev, A/B): never
+        // the whole MLP branch as one launch where the shape allows (gemm.h, launch_mlp_fwd: fp16 operands, DP = 160, more than 256 row tiles);
+        // V1T_MLP_FUSE=0 (dev, A/B): never, 2: at every size
         int rc_mlp = V1T_ERR_UNSUPPORTED;
         if (g_mlp_fuse && g_ln_fuse) rc_mlp = launch_mlp_fwd(l2, g, g2, s);
         if (rc_mlp == V1T_ERR_UNSUPPORTED) {

@@ -86,7 +86,8 @@ int launch_gemm_tn_group(const GemmTNArgs* a, int n, hipStream_t s);  // the GEM
 // not read, l.z (bf16 plane), l.mean, l.rstd and l.xout are written, l.z_lo is not. V1T_ERR_UNSUPPORTED: use ln_fwd + gemm_nt.
 struct LnFwdArgs;
 int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t s);
-// LN -> FC1 (EPI_BIAS_GELU) -> FC2 (EPI_BIAS_RES) in one launch; g2.A must be g's fp16 activation plane. V1T_ERR_UNSUPPORTED: launch the two.
+// LN -> FC1 (EPI_BIAS_GELU) -> FC2 (EPI_BIAS_RES) in one launch; g2.A must be g's fp16 activation plane. V1T_ERR_UNSUPPORTED (other shapes, launches of
+// at most 256 row tiles): launch the two.
 int launch_mlp_fwd(const LnFwdArgs& l, const GemmNTArgs& g, const GemmNTArgs& g2, hipStream_t s);
 // dz = A . B^T (bf16 operands, N = l.DP <= 160) consumed in registers by the LayerNorm backward `l` describes (l.dz is not read; same
 // outputs as launch_gemm_nt(EPI_F32) + launch_ln_bwd). V1T_ERR_UNSUPPORTED: use those two.

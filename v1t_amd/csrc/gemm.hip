@@ -847,17 +847,18 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
 // tiles in 5 more accumulators, against the W2 chunk [DP][64] staged beside the W1 tile. After the last tile the accumulators are FC2's (same
 // layout and same K order as gemm_nt's) and leave through its proj / FC2 epilogue (epi_bias_res). The separate FC2 launch, its read of the
 // activation plane (190 MB per 112-image launch) and its fill / drain disappear; everything the backward reads is written as before.
-// LDS: ONE buffer per weight tile (21.5 + 23 KB; the next tiles wait in registers, two barriers per column tile) + the staging (18.4 KB): 64 KB,
-// two workgroups per CU as ln_gemm_kernel has (double buffers: 109 KB, one workgroup per CU).
-template <int DP>
+// NBLK = 1 (32-column tiles): double-buffered weight tiles 2 x (10.7 + 12.8) KB + the staging 10 KB = 57 KB, two workgroups per CU as
+// ln_gemm_kernel has, 24 staging registers, 256 VGPRs. (NBLK = 2: 107 KB, one workgroup per CU: slower at every launch size measured.)
+// Per 112-image step against the two launches: 20.88 / 20.94 against 21.02 / 21.02 ms; a 28-image share 6.06 against 6.14; C5 19.68 against 20.04.
+template <int DP, int NBLK>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(LnFwdArgs l, GemmNTArgs g, GemmNTArgs g2) {
-    constexpr int NW = 4, NBLK = 2, NB2 = DP / 32;
+    constexpr int NW = 4, NB2 = DP / 32;
     constexpr int KS = DP / 16, BN = 32 * NBLK, LS = DP + 8, NTH = 64 * NW, KC = DP / 8, BM = 32 * NW;
     constexpr int CS = BN + 8, L2S = BN + 8, KC2 = BN / 8;
     constexpr int B_CHUNKS = BN * KC, B_ITERS = (B_CHUNKS + NTH - 1) / NTH;
     constexpr int W_CHUNKS = DP * KC2, W_ITERS = (W_CHUNKS + NTH - 1) / NTH;
-    __shared__ __attribute__((aligned(16))) bf16_t sB[BN * LS];
-    __shared__ __attribute__((aligned(16))) bf16_t sW2[DP * L2S];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LS];
+    __shared__ __attribute__((aligned(16))) bf16_t sW2[2][DP * L2S];
     __shared__ __attribute__((aligned(16))) bf16_t stg[NW][32 * CS];
     __shared__ __attribute__((aligned(16))) float sgb[2][DP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -878,16 +879,16 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(LnFwdArgs l, GemmNTArgs
             if (c < W_CHUNKS) rw[i] = *(const u32x4*)(g2.B + (size_t)n * g2.ldb + tn * BN + 8 * kc);
         }
     };
-    auto swrite = [&]() {
+    auto swrite = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
             const int c = tid + NTH * i, brow = c / KC, kc = c % KC;
-            if (c < B_CHUNKS) *(u32x4*)(&sB[brow * LS + 8 * kc]) = rb[i];
+            if (c < B_CHUNKS) *(u32x4*)(&sB[buf][brow * LS + 8 * kc]) = rb[i];
         }
 #pragma unroll
         for (int i = 0; i < W_ITERS; ++i) {
             const int c = tid + NTH * i, n = c / KC2, kc = c % KC2;
-            if (c < W_CHUNKS) *(u32x4*)(&sW2[n * L2S + 8 * kc]) = rw[i];
+            if (c < W_CHUNKS) *(u32x4*)(&sW2[buf][n * L2S + 8 * kc]) = rw[i];
         }
     };
     gload(0);  // in flight during the LayerNorm
@@ -977,11 +978,12 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(LnFwdArgs l, GemmNTArgs
     for (int d = 0; d < NB2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[d][r] = 0.f;
-    swrite();
+    swrite(0);
     __syncthreads();
     const int boff = r31 * LS + 8 * h2, woff = r31 * L2S + 8 * h2, aoff = r31 * CS + 8 * h2;
     for (int tn = 0; tn < ntn; ++tn) {
-        const int n0 = tn * BN;
+        const int n0 = tn * BN, buf = tn & 1;
+        if (tn + 1 < ntn) gload(tn + 1);
         {
             f32x16 acc[NBLK];
 #pragma unroll
@@ -991,29 +993,21 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(LnFwdArgs l, GemmNTArgs
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mfma32h(afrag[ks], *(const bf16x8*)(&sB[32 * nb * LS + boff + 16 * ks]), acc[nb]);
+                for (int nb = 0; nb < NBLK; ++nb) acc[nb] = mfma32h(afrag[ks], *(const bf16x8*)(&sB[buf][32 * nb * LS + boff + 16 * ks]), acc[nb]);
             f32x16 resv[NBLK];
             gemm_epilogue<NBLK, EPI_BIAS_GELU, true>(g, acc, resv, m0, n0, wave, lane);  // gelu' written (fragment order), activation left in acc
             if (g.C2) staged_store(acc, g.C2, g.ldc2, n0, [](float v) { return (bf16_t)v; });
             staged_store(acc, g.C2_lo, g.ldc2, n0, [](float v) { return aux_plane(v, (bf16_t)v, 1); });  // last: the staging now holds the fp16 tile
         }
-        // the next tiles' loads go out HERE, behind the element-wise stage (its registers are free again) and in front of FC2's MFMAs, which
-        // cover most of their L2 latency: held across the GELU stage the 40 staging registers spilled
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (tn + 1 < ntn) gload(tn + 1);
         // ---- FC2 over this K-chunk: A = the staged tile (this wave's own region: its LDS operations execute in order), B = the W2 chunk
 #pragma unroll
         for (int ks2 = 0; ks2 < BN / 16; ++ks2) {
             const bf16x8 a2 = *(const bf16x8*)(st + aoff + 16 * ks2);
 #pragma unroll
-            for (int d = 0; d < NB2; ++d) acc2[d] = mfma32h(a2, *(const bf16x8*)(&sW2[32 * d * L2S + woff + 16 * ks2]), acc2[d]);
+            for (int d = 0; d < NB2; ++d) acc2[d] = mfma32h(a2, *(const bf16x8*)(&sW2[buf][32 * d * L2S + woff + 16 * ks2]), acc2[d]);
         }
-        __syncthreads();  // every wave is done with this tile's sB / sW2
-        if (tn + 1 < ntn) {
-            swrite();
-            __syncthreads();
-        }
+        if (tn + 1 < ntn) swrite(buf ^ 1);
+        __syncthreads();
     }
     epi_bias_res<NB2, BM>(g2, acc2, m0, 0, wave, lane);
 }
@@ -1666,10 +1660,17 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
 // launch_gemm_nt(EPI_BIAS_RES) with A = g's fp16 activation plane. V1T_ERR_UNSUPPORTED: use those two.
 int launch_mlp_fwd(const LnFwdArgs& l, const GemmNTArgs& g, const GemmNTArgs& g2, hipStream_t s) {
     if (l.DP != 160 || g.K != l.DP || g.M != l.rows || !g.f16 || !g2.f16 || g.A_lo || g.B_lo || g2.A_lo || g2.B_lo || l.inject) return V1T_ERR_UNSUPPORTED;
-    if (g.N % 64 != 0 || g2.K != g.N || g2.N != l.DP || g2.M != g.M || !g.C2_lo || g2.A != g.C2_lo || g2.lda != g.ldc2 || (g.ldb % 8) || (g2.ldb % 8)) return V1T_ERR_UNSUPPORTED;
+    if (g.N % 128 != 0 || g2.K != g.N || g2.N != l.DP || g2.M != g.M || !g.C2_lo || g2.A != g.C2_lo || g2.lda != g.ldc2 || (g.ldb % 8) || (g2.ldb % 8)) return V1T_ERR_UNSUPPORTED;
     if (!g2.res || g2.res != l.x || g2.ldres != l.DP || !g2.C || g2.rd.o || g.rd.o) return V1T_ERR_UNSUPPORTED;
     if (g.M <= 0) return V1T_OK;
-    hipLaunchKernelGGL((mlp_fwd_kernel<160>), dim3((g.M + 127) / 128), dim3(256), 0, s, l, g, g2);
+    // More than one workgroup per CU only: a launch of <= 256 row tiles (a 14-image share of an 8-GPU step, a 16-image launch of the per-mouse loop)
+    // is faster as two kernels - ln_gemm deals its column tiles over two workgroups per row tile there and FC2 streams through the LDS-DMA ring
+    // (sim 8: 3.55 fused against 3.47 ms; per-mouse loop 28.3 against 27.7; 28 images and up the fused launch wins: profiles/r05_small_launch_experiments.txt #24).
+    // V1T_MLP_FUSE=2 (dev, A/B): fused at every size.
+    static const bool always = std::getenv("V1T_MLP_FUSE") && atoi(std::getenv("V1T_MLP_FUSE")) == 2;
+    const int tiles = (g.M + 127) / 128;
+    if (tiles <= 256 && !always) return V1T_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((mlp_fwd_kernel<160, 1>), dim3(tiles), dim3(256), 0, s, l, g, g2);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 
