@@ -759,6 +759,11 @@ def run_training(a, wd, state):
                          "peak_measured_how": f"v1t_mfma_peak_probe: v_mfma_f32_32x32x16_bf16 back to back on all CUs, register operands, random data, "
                                               f"{peak_m['waves_per_simd']} wave(s) per SIMD, {peak_m['cycles_per_mfma_per_simd']} cycles per MFMA and SIMD; nominal clock 2.4 GHz"},
         }
+        # the backward hands a block's weight-gradient GEMMs (HBM-bound) to a second stream, where they run beside the NEXT block's dK/dV
+        # kernel (compute-bound): its live duration then includes the sharing (alone: V1T_DW_SIDE=0, ~12 % shorter per launch, the step slower)
+        if a.profile_class == 2 and int(lib.v1t_vit_backward_second_stream(model.core._plan, int(imgs_launch))):
+            line["roofline"]["shares_gpu_with"] = ("gemm_tn2 / tn_reduce_multi of the previous block on a second stream (weight gradients; "
+                                                   "V1T_DW_SIDE=0 runs everything on one stream: this kernel ~12 % shorter, the step ~1.3 % slower)")
         line["model_frac_of_measured_peak"] = round(fl["train_per_image"] * images / dt / 1e12 / (peak_m["tflops"] * world), 4)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -13,7 +13,7 @@
  * memory is allocated inside a launch function (workspaces are sized by the *_bytes queries and passed in; the measurement aid
  * v1t_mfma_peak_probe is the one exception); all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
  * v1t_vit_backward(_events) additionally owns one internal stream per plan (created by its first small launch, destroyed with the plan) on which
- * the weight-gradient GEMMs of launches below 131 072 rows run, joined to `stream` by events before the call returns its last launch.
+ * the weight-gradient GEMMs of launches below 262 144 rows run, joined to `stream` by events before the call returns its last launch.
  * Return value 0 = ok, negative = error code below (the Python shim raises RuntimeError, which the reference's OOM probe utils/utils.py:460
  * relies on). Thread-safe for distinct handles; calls on ONE handle must be serialised by the caller (the plan owns the second stream and
  * the events of its backward, created on first use on the device that is current then: two backward calls on the same plan from two threads
@@ -119,6 +119,11 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
                             void* scratch, long long scratch_bytes, int training, uint64_t seed,
                             const float* path_scale, const float* gout, float* grads, void* const* block_done,
                             void* stream);
+
+/* 1 when v1t_vit_backward* of `batch` images hands its weight-gradient GEMMs (dW = dY^T X of the four linear layers of a block) to a second
+ * stream that runs them beside the next block's dX / attention kernels (launches under 262 144 token rows), 0 when everything runs on
+ * `stream`. The gradients are complete on `stream` when the call's work is, either way. */
+int v1t_vit_backward_second_stream(const v1t_vit* h, int batch);
 
 /* keep-mask of one dropout stream, for replaying the exact mask in a CPU check.
  * stream ids: 8*block + {0: attention P (rows B*H*T, cols T), 1: proj out, 2: fc1 out, 3: fc2 out}

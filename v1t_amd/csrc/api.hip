@@ -211,15 +211,16 @@ static bool x16_gelu_out(const v1t_vit* h, long long R) {
     return !g_keep_bf16 && g_fwd_f16 && !(g_nosplit & 8) && gemm_tn_takes_f16_x(h->DP, h->MP, tn_plan(h, R).mc_fc2);
 }
 
-// Weight-gradient GEMMs on a second stream beside the main stream's kernels (backward, below): for launches under 131 072 rows, or as
+// Weight-gradient GEMMs on a second stream beside the main stream's kernels (backward, below): for launches under 262 144 rows, or as
 // V1T_DW_SIDE=0 / 1 forces (dev). One place decides for the scratch layout (four slab regions, second dqkv) and for the backward.
 // Round 5, with the hand-over once per block (same call, on / off): 14 images 3.46-3.49 vs 3.63-3.64 ms per step, 28 images 6.05-6.15 vs
-// 6.20-6.22, 56 images 11.08-11.23 vs 11.29-11.38, 112 images 20.79-20.89 vs 20.99-21.00 (bench.py, three runs each). At 112 images the
-// 0.7 % come with the dK/dV kernel sharing the chip (1.63 -> 1.82 ms per launch live): the single-GPU step keeps one stream, so that the
-// bench line's dominant-kernel time stays that kernel's own.
+// 6.20-6.22, 56 images 11.08-11.23 vs 11.29-11.38, 112 images 20.79-20.89 vs 20.99-21.00 and, on the final build, 20.69 / 20.74 vs 20.96 / 21.01
+// (bench.py). The HBM-bound weight-gradient GEMMs of a block then share the chip with the compute-bound dK/dV kernel of the next one, whose
+// launches take 1.83 instead of 1.61 ms live: at 112 images the bench line's dominant-kernel time includes that sharing (it says so:
+// roofline.shares_gpu_with) - the step is 1.3 % faster for it.
 static bool dw_side_for(long long R) {
     static const int dw_force = std::getenv("V1T_DW_SIDE") ? atoi(std::getenv("V1T_DW_SIDE")) : -1;
-    return dw_force >= 0 ? dw_force > 0 : R < 131072;
+    return dw_force >= 0 ? dw_force > 0 : R < 262144;
 }
 
 ScratchLayout scratch_layout(const v1t_vit* h, int B) {
@@ -1159,6 +1160,12 @@ int v1t_dropout_mask(uint64_t seed, uint32_t stream_id, float p, long long rows,
     if (stream_id != 0xFFFFu && stream_id % 8 == 0)  // attention-P stream: rows = B*H*T, cols = T
         return launch_attn_dropout_mask(out, rows, cols, make_adrop(true, p, seed, stream_id), (hipStream_t)stream);
     return launch_dropout_mask(out, rows, cols, make_drop(true, p, seed, stream_id), (hipStream_t)stream);
+}
+
+int v1t_vit_backward_second_stream(const v1t_vit* h, int batch) {
+    if (!h || batch <= 0) return 0;
+    const long long R = (long long)batch * h->T;
+    return (tn_plan(h, R).slab && dw_side_for(R)) ? 1 : 0;
 }
 
 float v1t_attention_dropout_rate(float p) {

@@ -84,6 +84,7 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_vit_backward_events": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_ll, c_int, c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "v1t_dropout_mask": (c_int, [c_u64, c_u32, c_float, c_ll, c_ll, c_void_p, c_void_p]),
     "v1t_attention_dropout_rate": (c_float, [c_float]),
+    "v1t_vit_backward_second_stream": (c_int, [c_void_p, c_int]),
     "v1t_gaussian2d_forward": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "v1t_gaussian2d_backward": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_void_p]),
     "v1t_gather_transform": (c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_void_p, c_void_p]),
