@@ -700,13 +700,16 @@ def test_fused_poisson_criterion_and_elu1_backward_vs_torch(ctx):
         assert abs(float(crit(y_true=y_true, y_pred=y_pred.detach(), mouse_id="A")) - float(ref)) <= 2e-6 * abs(float(ref))
 
 
+@pytest.mark.parametrize("switch", ["V1T_MLP_FUSE", "V1T_MLP_BWD_FUSE"])
 @pytest.mark.parametrize("images,train", [(3, True), (2, False)])
-def test_fused_mlp_forward_equals_two_launches(images, train):
+def test_fused_mlp_forward_equals_two_launches(images, train, switch):
     """The MLP branch forward as ONE launch (gemm.hip mlp_fwd_kernel: LN2 -> FC1 -> GELU -> dropout -> FC2 -> dropout -> + residual; default
     above 256 row tiles, forced here with V1T_MLP_FUSE=2) against ln_gemm + gemm_nt (V1T_MLP_FUSE=0; the switch is read once per process: two
     subprocesses) at the default width (D = 155 -> 160, MLP 488 -> 512), ragged last row tile, dropout masks on (counter-based: identical in
     both runs): core output, and - through the planes the forward saves for the backward (LayerNorm output + statistics, gelu', the fp16
-    activation) - the loss gradient of every core parameter. Same operands, same K order of FC2's accumulation."""
+    activation) - the loss gradient of every core parameter. Same operands, same K order of FC2's accumulation.
+    V1T_MLP_BWD_FUSE: the same for the backward's mirror (mlp_bwd_kernel: dGELU GEMM + dz GEMM + LN2 backward in one launch against
+    gemm_nt<EPI_DGELU> + gemm_lnbwd_kernel): every core gradient."""
     import os
     import subprocess
     import sys
@@ -736,8 +739,9 @@ torch.save({"u": u.detach().cpu(), "g": model.core._arena.grad.cpu()}, sys.argv[
 '''
     outs = []
     for fuse in ("0", "2"):
-        path = f"/tmp/v1t_mlpfuse_{fuse}.pt"
-        env = dict(os.environ, V1T_MLP_FUSE=fuse)
+        path = f"/tmp/v1t_mlpfuse_{switch}_{fuse}.pt"
+        env = dict(os.environ)
+        env[switch] = fuse
         r = subprocess.run([sys.executable, "-c", code, path, str(images), str(int(train))], env=env, capture_output=True, text=True,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stderr[-2000:]

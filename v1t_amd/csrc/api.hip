@@ -962,18 +962,9 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         g.aux = hpre; g.ldaux = MP;
         g.colsum = (b.fc1b >= 0 && DP == D) ? grads + b.fc1b : nullptr; g.n_valid = M;  // else: ones column in dW1
         g.drop = make_drop(train, h->c.t_dropout, seed, 8 * k + 2);
-        CHECK(launch_gemm_nt(g, EPI_DGELU, s));
-        // dW1 += d_hpre^T z2
-        t = GemmTNArgs{};
-        t.Y = dhpre; t.ldy = MP; t.X = z2; t.ldx = DP; t.M = R; t.NY = MP; t.NX = DP; t.dW = grads + b.fc1; t.ldw = D;
-        t.yseg_pad = MP; t.yseg_valid = M; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
-        if (DP > D && b.fc1b >= 0) { t.dbias = grads + b.fc1b; t.ones_col = DP - 1; }  // z2[:, DP-1] == 1 (LN kernel)
-        t.m_chunk = tp.mc_fc1;
-        CHECK(launch_dw(t, 1));  // reads dhpre, z2
-        // dz2 = d_hpre . W1
-        g = GemmNTArgs{};
-        g.A = dhpre; g.lda = MP; g.B = (const bf16_t*)(sh + b.s_fc1_t); g.ldb = MP; g.M = R; g.N = DP; g.K = MP; g.C = dz; g.ldc = DP;
-        // LN2 backward: G = gin + dx; dy = dropout_bwd(G) for the projection output; dbo += colsum
+        // dz2 = d_hpre . W1, then the LN2 backward: G = gin + dx; dy = dropout_bwd(G) for the projection output; dbo += colsum
+        GemmNTArgs gz{};
+        gz.A = dhpre; gz.lda = MP; gz.B = (const bf16_t*)(sh + b.s_fc1_t); gz.ldb = MP; gz.M = R; gz.N = DP; gz.K = MP; gz.C = dz; gz.ldc = DP;
         LnBwdArgs lb{};
         lb.dz = dz; lb.x = xm; lb.mean = (const float*)(wb + w.mean2); lb.rstd = (const float*)(wb + w.rstd2); lb.gamma = arena + b.ln2w;
         lb.gin = gin; lb.gout = G; lb.dgamma = grads + b.ln2w; lb.dbeta = grads + b.ln2b; lb.dinject = nullptr;
@@ -981,7 +972,19 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         lb.drop_next = make_drop(train, h->c.t_dropout, seed, 8 * k + 1);
         lb.scale_next = path_scale ? path_scale + (size_t)(2 * k + 0) * B : nullptr;
         lb.B = B; lb.T = h->T; lb.D = D; lb.DP = DP;
-        CHECK(dx_then_ln_bwd(g, lb, s));
+        // the dGELU GEMM, the dz GEMM and the LN2 backward as one launch where the shape allows (gemm.h, launch_mlp_bwd: DP = 160, more than 256
+        // row tiles, no stochastic depth) - off unless V1T_MLP_BWD_FUSE=1 / 2 (dev: measured neutral)
+        const int rc_mb = g_lnbwd_unfused ? V1T_ERR_UNSUPPORTED : launch_mlp_bwd(g, gz, lb, s);
+        if (rc_mb == V1T_ERR_UNSUPPORTED) CHECK(launch_gemm_nt(g, EPI_DGELU, s));
+        else CHECK(rc_mb);
+        // dW1 += d_hpre^T z2
+        t = GemmTNArgs{};
+        t.Y = dhpre; t.ldy = MP; t.X = z2; t.ldx = DP; t.M = R; t.NY = MP; t.NX = DP; t.dW = grads + b.fc1; t.ldw = D;
+        t.yseg_pad = MP; t.yseg_valid = M; t.xseg_pad = DP; t.xseg_valid = D; t.alpha = 1.f;
+        if (DP > D && b.fc1b >= 0) { t.dbias = grads + b.fc1b; t.ones_col = DP - 1; }  // z2[:, DP-1] == 1 (LN kernel)
+        t.m_chunk = tp.mc_fc1;
+        CHECK(launch_dw(t, 1));  // reads dhpre, z2
+        if (rc_mb == V1T_ERR_UNSUPPORTED) CHECK(dx_then_ln_bwd(gz, lb, s));
         gin = G;
 
         // ---- attention branch: dWo += dy^T o

@@ -93,3 +93,5 @@ int launch_mlp_fwd(const LnFwdArgs& l, const GemmNTArgs& g, const GemmNTArgs& g2
 // outputs as launch_gemm_nt(EPI_F32) + launch_ln_bwd). V1T_ERR_UNSUPPORTED: use those two.
 struct LnBwdArgs;
 int launch_gemm_ln_bwd(const GemmNTArgs& g, const LnBwdArgs& l, hipStream_t s);
+// dGELU GEMM + dz GEMM + LayerNorm backward of the MLP branch in one launch (gz.A = gd.C). V1T_ERR_UNSUPPORTED: launch_gemm_nt(gd, EPI_DGELU) + launch_gemm_ln_bwd(gz, l).
+int launch_mlp_bwd(const GemmNTArgs& gd, const GemmNTArgs& gz, const LnBwdArgs& l, hipStream_t s);

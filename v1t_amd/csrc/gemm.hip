@@ -1353,6 +1353,153 @@ DEVFN float half32_sum(float v) {  // sum over the 32 lanes of a half-wave, retu
     const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // rows 0 <-> 1, 2 <-> 3
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// ---- LayerNorm backward on a workgroup's accumulators dz (BM rows x 32 NBLK columns: column = 32 nb + (lane & 31), row = 32 wave + acc_row(r, lane)):
+// the tail of gemm_lnbwd_kernel (tiles aligned to an image: row0 = the image's first row, t0 = the tile's first row inside it, Tlim = T, b = image)
+// and of mlp_bwd_kernel (global 128-row tiles: row0 = 0, t0 = the tile's first row, Tlim = all rows, no per-image terms). `smem`: >= BM x CS bf16 of
+// LDS that every wave is done with.
+template <int NBLK, bool NEXT, int BM, int CS>
+DEVFN void lnbwd_epilogue(const LnBwdArgs& l, f32x16 (&acc)[NBLK], size_t row0, int t0, int Tlim, int b, bf16_t* smem, int tid, int wave, int lane) {
+    constexpr int BN = 32 * NBLK, NW = BM / 32;
+    // ---- LayerNorm backward on the accumulators: column = 32 nb + (lane & 31), row = 32 wave + acc_row(r, lane)
+    const float snext = l.scale_next ? l.scale_next[b] : 1.f;
+    const float invD = 1.0f / (float)l.D;
+    float gam[NBLK], adg[NBLK], adb[NBLK], ainj[NBLK], abn[NBLK];
+    bool cok[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+        const int col = 32 * nb + (lane & 31);
+        cok[nb] = col < l.D;
+        gam[nb] = cok[nb] ? l.gamma[col] : 0.f;
+        adg[nb] = adb[nb] = ainj[nb] = abn[nb] = 0.f;
+    }
+    if (t0 + BM > Tlim) {  // ragged last tile of the image (workgroup-uniform): its clamped rows contribute nothing
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool rok = t0 + 32 * wave + acc_row(r, lane) < Tlim;
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) acc[nb][r] = rok ? acc[nb][r] : 0.f;
+        }
+    }
+    bf16_t* st = smem + wave * 32 * CS;
+    constexpr int RPG = 4;  // accumulator rows per group: 8 NBLK loads in flight per group
+    // dropout of the next branch without a branch: threshold 0 keeps everything (hash >= 0), factor 1
+    const uint32_t dthr = (NEXT && l.drop_next.thresh) ? l.drop_next.thresh : 0u;
+    const float dinv = (NEXT && l.drop_next.thresh) ? l.drop_next.inv_keep : 1.0f;
+    // the image's rows as buffers: rows past the image read 0 (x, gin, mean, rstd = 0: G = 0 there) and their stores are dropped
+    const uint32_t img_bytes = (uint32_t)Tlim * (uint32_t)l.DP * 4u;
+    const __amdgpu_buffer_rsrc_t x_r = buf_rsrc(l.x + row0 * l.DP, img_bytes), gin_r = buf_rsrc(l.gin + row0 * l.DP, img_bytes);
+    const __amdgpu_buffer_rsrc_t gout_r = buf_rsrc(l.gout + row0 * l.DP, img_bytes);
+    const __amdgpu_buffer_rsrc_t mean_r = buf_rsrc(l.mean + row0, (uint32_t)Tlim * 4u), rstd_r = buf_rsrc(l.rstd + row0, (uint32_t)Tlim * 4u);
+#pragma unroll
+    for (int rg = 0; rg < 16 / RPG; ++rg) {
+        // one row group at a time: without the fence the scheduler hoists every group's 40 loads to the top
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        float mean[RPG], rstd[RPG], xh[NBLK][RPG], gi[NBLK][RPG];
+        uint32_t trow[RPG], eoff[RPG];  // row inside the image, byte offset of (row, lane & 31) from the image's first row
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            trow[i] = (uint32_t)(t0 + 32 * wave + acc_row(RPG * rg + i, lane));
+            eoff[i] = (trow[i] * (uint32_t)l.DP + (uint32_t)(lane & 31)) * 4u;
+            if (trow[i] >= (uint32_t)Tlim) eoff[i] |= BUF_OOB;
+            mean[i] = buf_load_f32(mean_r, trow[i] * 4u, 0);
+            rstd[i] = buf_load_f32(rstd_r, trow[i] * 4u, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int i = 0; i < RPG; ++i) {
+                xh[nb][i] = buf_load_f32(x_r, eoff[i], 128 * nb);
+                gi[nb][i] = buf_load_f32(gin_r, eoff[i], 128 * nb);
+            }
+        float s1[RPG], s2[RPG];
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            s1[i] = s2[i] = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb) {
+                const float xc = (xh[nb][i] - mean[i]) * rstd[i];
+                xh[nb][i] = cok[nb] ? xc : 0.f;
+                const float dy = acc[nb][RPG * rg + i] * gam[nb];  // pad columns: gamma = 0
+                s1[i] += dy;
+                s2[i] = fmaf(dy, xh[nb][i], s2[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            s1[i] = half32_sum(s1[i]) * invD;
+            s2[i] = half32_sum(s2[i]) * invD;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) {
+            const int col = 32 * nb + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < RPG; ++i) {
+                const float dz = acc[nb][RPG * rg + i];
+                const float gfull = fmaf(rstd[i], fmaf(-xh[nb][i], s2[i], dz * gam[nb] - s1[i]), gi[nb][i]);
+                const float go = cok[nb] ? gfull : 0.f;  // rows past the image: gi = rstd = 0
+                adg[nb] = fmaf(dz, xh[nb][i], adg[nb]);
+                adb[nb] += dz;
+                ainj[nb] += go;
+                buf_store_f32(gout_r, eoff[i], 128 * nb, go);
+                if constexpr (NEXT) {
+                    const bool keep = drop_hash(l.drop_next.key, (uint32_t)row0 + trow[i], col) >= dthr;
+                    const bf16_t vb = (bf16_t)(keep ? go * snext * dinv : 0.f);
+                    abn[nb] += (float)vb;
+                    st[acc_row(RPG * rg + i, lane) * CS + col] = vb;
+                }
+            }
+        }
+        // the column sums must be formed HERE: left alone the compiler sinks all 4 x 16 x NBLK additions behind the loop and keeps
+        // (spills) every G and dy value until then
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) asm volatile("" : "+v"(adg[nb]), "+v"(adb[nb]), "+v"(ainj[nb]), "+v"(abn[nb]));
+    }
+    if constexpr (NEXT) {  // wave-private staging -> 16-B chunks of consecutive row segments
+        constexpr int CPR = BN / 8;
+#pragma unroll
+        for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < 32 * CPR) {
+                const int row = c / CPR, ch = c % CPR;
+                const int t = t0 + 32 * wave + row;
+                if (t < Tlim) *(u32x4*)(l.dy_next + (row0 + t) * l.DP + 8 * ch) = *(const u32x4*)(st + row * CS + 8 * ch);
+            }
+        }
+    }
+    // column partials: the two half-waves hold different rows of the same columns; each wave parks its 4 x BN sums in its own staging
+    // region (its read-back above is complete: LDS operations of a wave execute in order)
+    float* sred_w = (float*)(smem + wave * 32 * CS);
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+        float q[4] = {adg[nb], adb[nb], ainj[nb], abn[nb]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned u = __float_as_uint(q[k]);
+            const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            q[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            if (lane < 32) sred_w[k * BN + 32 * nb + lane] = q[k];
+        }
+    }
+    __syncthreads();
+    const int c = tid;
+    if (c < l.D) {
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float* sw = (const float*)(smem + w * 32 * CS);
+            r0 += sw[c];
+            r1 += sw[BN + c];
+            r2 += sw[2 * BN + c];
+            r3 += sw[3 * BN + c];
+        }
+        atomicAdd(&l.dgamma[c], r0);
+        atomicAdd(&l.dbeta[c], r1);
+        if (l.dinject) atomicAdd(&l.dinject[(size_t)b * l.DP + c], r2);
+        if (NEXT && l.dbias_next) atomicAdd(&l.dbias_next[c], r3);
+    }
+}
+
 template <int NBLK, bool NEXT, int RING = 0>
 __global__ __launch_bounds__(256, RING ? 1 : 2) void gemm_lnbwd_kernel(GemmNTArgs g, LnBwdArgs l) {
     constexpr int NW = 4, BK = 32, BM = 32 * NW, NT = 64 * NW;
@@ -1458,144 +1605,118 @@ __global__ __launch_bounds__(256, RING ? 1 : 2) void gemm_lnbwd_kernel(GemmNTArg
     __syncthreads();  // every wave is done with the operand tiles: the bf16 staging below reuses them
   }
 
-    // ---- LayerNorm backward on the accumulators: column = 32 nb + (lane & 31), row = 32 wave + acc_row(r, lane)
-    const float snext = l.scale_next ? l.scale_next[b] : 1.f;
-    const float invD = 1.0f / (float)l.D;
-    float gam[NBLK], adg[NBLK], adb[NBLK], ainj[NBLK], abn[NBLK];
-    bool cok[NBLK];
+    lnbwd_epilogue<NBLK, NEXT, BM, CS>(l, acc, row0, t0, l.T, b, smem, tid, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// The MLP branch BACKWARD down to the residual-stream gradient in one launch - mlp_fwd_kernel's mirror: dhpre = (dy W2) * gelu' * mask (the dGELU
+// GEMM, K = DP: the dy rows resident as A fragments, the hidden units walked in 32-column tiles) with dz = dhpre W1 folded into the tile loop - the
+// bf16 dhpre tile a wave stages in LDS for its row stores (the plane the dW1 GEMM reads) is the A operand of the K-chunk [32 tn, 32 tn + 32) of
+// the second GEMM, accumulated in NB2 blocks against the W1^T chunk staged beside the W2^T tile - and the LayerNorm backward of LN2 on those
+// accumulators at the end (lnbwd_epilogue: gemm_lnbwd_kernel's tail, here over global 128-row tiles - LN2 has no per-image term). Against
+// gemm_nt<EPI_DGELU> + gemm_lnbwd_kernel: one launch, dhpre written (for dW1) but not read back (190 MB per 112-image launch).
+template <int DP>
+__global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(GemmNTArgs g, GemmNTArgs g2, LnBwdArgs l) {
+    constexpr int NW = 4, NB2 = DP / 32, KS = DP / 16, BN = 32, LS = DP + 8, NTH = 64 * NW, KC = DP / 8, BM = 32 * NW;
+    constexpr int CS = BN + 8, L2S = BN + 8, KC2 = BN / 8, ECS = DP + 8;
+    constexpr int B_CHUNKS = BN * KC, B_ITERS = (B_CHUNKS + NTH - 1) / NTH;
+    constexpr int W_CHUNKS = DP * KC2, W_ITERS = (W_CHUNKS + NTH - 1) / NTH;
+    constexpr int SB = BN * LS, SW = DP * L2S, SS = 32 * CS;
+    constexpr int SMEM = (2 * SB + 2 * SW + NW * SS) > BM * ECS ? (2 * SB + 2 * SW + NW * SS) : BM * ECS;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
+    bf16_t* sB = smem;                 // [2][BN x LS]: W2^T tile (hidden unit rows, K = DP)
+    bf16_t* sW = smem + 2 * SB;        // [2][DP x L2S]: W1^T chunk (input-feature rows, K-chunk of 32 hidden units)
+    bf16_t* stg = smem + 2 * SB + 2 * SW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r31 = lane & 31, h2 = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int ntn = g.N / BN;
+
+    u32x4 rb[B_ITERS], rw[W_ITERS];
+    auto gload = [&](int tn) {
 #pragma unroll
-    for (int nb = 0; nb < NBLK; ++nb) {
-        const int col = 32 * nb + (lane & 31);
-        cok[nb] = col < l.D;
-        gam[nb] = cok[nb] ? l.gamma[col] : 0.f;
-        adg[nb] = adb[nb] = ainj[nb] = abn[nb] = 0.f;
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + NTH * i, brow = c / KC, kc = c % KC;
+            if (c < B_CHUNKS) rb[i] = *(const u32x4*)(g.B + (size_t)(tn * BN + brow) * g.ldb + 8 * kc);
+        }
+#pragma unroll
+        for (int i = 0; i < W_ITERS; ++i) {
+            const int c = tid + NTH * i, n = c / KC2, kc = c % KC2;
+            if (c < W_CHUNKS) rw[i] = *(const u32x4*)(g2.B + (size_t)n * g2.ldb + tn * BN + 8 * kc);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + NTH * i, brow = c / KC, kc = c % KC;
+            if (c < B_CHUNKS) *(u32x4*)(&sB[buf * SB + brow * LS + 8 * kc]) = rb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W_ITERS; ++i) {
+            const int c = tid + NTH * i, n = c / KC2, kc = c % KC2;
+            if (c < W_CHUNKS) *(u32x4*)(&sW[buf * SW + n * L2S + 8 * kc]) = rw[i];
+        }
+    };
+    gload(0);
+    // the dy rows of this wave as A fragments of the whole K extent (lane = row, half rows on the two 32-lane halves; rows past M: the last row,
+    // masked where they leave the workgroup)
+    bf16x8 afrag[KS];
+    {
+        const int row = min(m0 + 32 * wave + r31, g.M - 1);
+        const bf16_t* ap = g.A + (size_t)row * g.lda + 8 * h2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) afrag[ks] = *(const bf16x8*)(ap + 16 * ks);
     }
-    if (t0 + BM > l.T) {  // ragged last tile of the image (workgroup-uniform): its clamped rows contribute nothing
+    bf16_t* st = stg + wave * SS;
+    f32x16 acc2[NB2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool rok = t0 + 32 * wave + acc_row(r, lane) < l.T;
+    for (int d = 0; d < NB2; ++d)
 #pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) acc[nb][r] = rok ? acc[nb][r] : 0.f;
-        }
-    }
-    bf16_t* st = smem + wave * 32 * CS;
-    constexpr int RPG = 4;  // accumulator rows per group: 8 NBLK loads in flight per group
-    // dropout of the next branch without a branch: threshold 0 keeps everything (hash >= 0), factor 1
-    const uint32_t dthr = (NEXT && l.drop_next.thresh) ? l.drop_next.thresh : 0u;
-    const float dinv = (NEXT && l.drop_next.thresh) ? l.drop_next.inv_keep : 1.0f;
-    // the image's rows as buffers: rows past the image read 0 (x, gin, mean, rstd = 0: G = 0 there) and their stores are dropped
-    const uint32_t img_bytes = (uint32_t)l.T * (uint32_t)l.DP * 4u;
-    const __amdgpu_buffer_rsrc_t x_r = buf_rsrc(l.x + row0 * l.DP, img_bytes), gin_r = buf_rsrc(l.gin + row0 * l.DP, img_bytes);
-    const __amdgpu_buffer_rsrc_t gout_r = buf_rsrc(l.gout + row0 * l.DP, img_bytes);
-    const __amdgpu_buffer_rsrc_t mean_r = buf_rsrc(l.mean + row0, (uint32_t)l.T * 4u), rstd_r = buf_rsrc(l.rstd + row0, (uint32_t)l.T * 4u);
+        for (int r = 0; r < 16; ++r) acc2[d][r] = 0.f;
+    swrite(0);
+    __syncthreads();
+    const int boff = r31 * LS + 8 * h2, woff = r31 * L2S + 8 * h2, aoff = r31 * CS + 8 * h2;
+    for (int tn = 0; tn < ntn; ++tn) {
+        const int n0 = tn * BN, buf = tn & 1;
+        if (tn + 1 < ntn) gload(tn + 1);
+        {
+            f32x16 acc[1], resv[1];
+            {  // saved gelu' fragments of this (row tile, column block): 2 x 16 B per lane
+                const bf16_t* fp = g.aux + frag_index(g, m0, n0, 0, wave, lane);
+                const f32x4 lo = *(const f32x4*)fp, hi = *(const f32x4*)(fp + 8);
 #pragma unroll
-    for (int rg = 0; rg < 16 / RPG; ++rg) {
-        // one row group at a time: without the fence the scheduler hoists every group's 40 loads to the top
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        float mean[RPG], rstd[RPG], xh[NBLK][RPG], gi[NBLK][RPG];
-        uint32_t trow[RPG], eoff[RPG];  // row inside the image, byte offset of (row, lane & 31) from the image's first row
-#pragma unroll
-        for (int i = 0; i < RPG; ++i) {
-            trow[i] = (uint32_t)(t0 + 32 * wave + acc_row(RPG * rg + i, lane));
-            eoff[i] = (trow[i] * (uint32_t)l.DP + (uint32_t)(lane & 31)) * 4u;
-            if (trow[i] >= (uint32_t)l.T) eoff[i] |= BUF_OOB;
-            mean[i] = buf_load_f32(mean_r, trow[i] * 4u, 0);
-            rstd[i] = buf_load_f32(rstd_r, trow[i] * 4u, 0);
-        }
-#pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb)
-#pragma unroll
-            for (int i = 0; i < RPG; ++i) {
-                xh[nb][i] = buf_load_f32(x_r, eoff[i], 128 * nb);
-                gi[nb][i] = buf_load_f32(gin_r, eoff[i], 128 * nb);
-            }
-        float s1[RPG], s2[RPG];
-#pragma unroll
-        for (int i = 0; i < RPG; ++i) {
-            s1[i] = s2[i] = 0.f;
-#pragma unroll
-            for (int nb = 0; nb < NBLK; ++nb) {
-                const float xc = (xh[nb][i] - mean[i]) * rstd[i];
-                xh[nb][i] = cok[nb] ? xc : 0.f;
-                const float dy = acc[nb][RPG * rg + i] * gam[nb];  // pad columns: gamma = 0
-                s1[i] += dy;
-                s2[i] = fmaf(dy, xh[nb][i], s2[i]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < RPG; ++i) {
-            s1[i] = half32_sum(s1[i]) * invD;
-            s2[i] = half32_sum(s2[i]) * invD;
-        }
-#pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb) {
-            const int col = 32 * nb + (lane & 31);
-#pragma unroll
-            for (int i = 0; i < RPG; ++i) {
-                const float dz = acc[nb][RPG * rg + i];
-                const float gfull = fmaf(rstd[i], fmaf(-xh[nb][i], s2[i], dz * gam[nb] - s1[i]), gi[nb][i]);
-                const float go = cok[nb] ? gfull : 0.f;  // rows past the image: gi = rstd = 0
-                adg[nb] = fmaf(dz, xh[nb][i], adg[nb]);
-                adb[nb] += dz;
-                ainj[nb] += go;
-                buf_store_f32(gout_r, eoff[i], 128 * nb, go);
-                if constexpr (NEXT) {
-                    const bool keep = drop_hash(l.drop_next.key, (uint32_t)row0 + trow[i], col) >= dthr;
-                    const bf16_t vb = (bf16_t)(keep ? go * snext * dinv : 0.f);
-                    abn[nb] += (float)vb;
-                    st[acc_row(RPG * rg + i, lane) * CS + col] = vb;
+                for (int j = 0; j < 4; ++j) {
+                    resv[0][j] = lo[j];
+                    resv[0][4 + j] = hi[j];
                 }
             }
-        }
-        // the column sums must be formed HERE: left alone the compiler sinks all 4 x 16 x NBLK additions behind the loop and keeps
-        // (spills) every G and dy value until then
 #pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb) asm volatile("" : "+v"(adg[nb]), "+v"(adb[nb]), "+v"(ainj[nb]), "+v"(abn[nb]));
-    }
-    if constexpr (NEXT) {  // wave-private staging -> 16-B chunks of consecutive row segments
-        constexpr int CPR = BN / 8;
+            for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
 #pragma unroll
-        for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
-            const int c = c0 + lane;
-            if (c < 32 * CPR) {
-                const int row = c / CPR, ch = c % CPR;
-                const int t = t0 + 32 * wave + row;
-                if (t < l.T) *(u32x4*)(l.dy_next + (row0 + t) * l.DP + 8 * ch) = *(const u32x4*)(st + row * CS + 8 * ch);
+            for (int ks = 0; ks < KS; ++ks) acc[0] = mfma32(afrag[ks], *(const bf16x8*)(&sB[buf * SB + boff + 16 * ks]), acc[0]);
+            gemm_epilogue<1, EPI_DGELU, true>(g, acc, resv, m0, n0, wave, lane);  // d(pre-activation), rounded to bf16, left in acc; bias column sums
+            // staged [32 rows][32] per wave -> 16-B row chunks of the dhpre plane (the dW1 GEMM reads it); the staging is FC1-backward's A operand
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[acc_row(r, lane) * CS + r31] = (bf16_t)acc[0][r];
+            constexpr int CPR = BN / 8;
+#pragma unroll
+            for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
+                const int c = c0 + lane, crow = c / CPR, ch = c % CPR;
+                const int grow = m0 + 32 * wave + crow;
+                if (grow < g.M) *(u32x4*)((bf16_t*)g.C + (size_t)grow * g.ldc + n0 + 8 * ch) = *(const u32x4*)(st + crow * CS + 8 * ch);
             }
         }
-    }
-    // column partials: the two half-waves hold different rows of the same columns; each wave parks its 4 x BN sums in its own staging
-    // region (its read-back above is complete: LDS operations of a wave execute in order)
-    float* sred_w = (float*)(smem + wave * 32 * CS);
 #pragma unroll
-    for (int nb = 0; nb < NBLK; ++nb) {
-        float q[4] = {adg[nb], adb[nb], ainj[nb], abn[nb]};
+        for (int ks2 = 0; ks2 < BN / 16; ++ks2) {
+            const bf16x8 a2 = *(const bf16x8*)(st + aoff + 16 * ks2);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned u = __float_as_uint(q[k]);
-            const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            q[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            if (lane < 32) sred_w[k * BN + 32 * nb + lane] = q[k];
+            for (int d = 0; d < NB2; ++d) acc2[d] = mfma32(a2, *(const bf16x8*)(&sW[buf * SW + 32 * d * L2S + woff + 16 * ks2]), acc2[d]);
         }
+        if (tn + 1 < ntn) swrite(buf ^ 1);
+        __syncthreads();
     }
-    __syncthreads();
-    const int c = tid;
-    if (c < l.D) {
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float* sw = (const float*)(smem + w * 32 * CS);
-            r0 += sw[c];
-            r1 += sw[BN + c];
-            r2 += sw[2 * BN + c];
-            r3 += sw[3 * BN + c];
-        }
-        atomicAdd(&l.dgamma[c], r0);
-        atomicAdd(&l.dbeta[c], r1);
-        if (l.dinject) atomicAdd(&l.dinject[(size_t)b * l.DP + c], r2);
-        if (NEXT && l.dbias_next) atomicAdd(&l.dbias_next[c], r3);
-    }
+    // (the last barrier of the loop: every wave is done with the tiles and its staging - the epilogue's staging overlays them)
+    lnbwd_epilogue<NB2, true, BM, ECS>(l, acc2, 0, m0, g.M, 0, smem, tid, wave, lane);
 }
 
 }  // namespace
@@ -1671,6 +1792,24 @@ int launch_mlp_fwd(const LnFwdArgs& l, const GemmNTArgs& g, const GemmNTArgs& g2
     const int tiles = (g.M + 127) / 128;
     if (tiles <= 256 && !always) return V1T_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((mlp_fwd_kernel<160, 1>), dim3(tiles), dim3(256), 0, s, l, g, g2);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+
+// dGELU GEMM (gd: launch_gemm_nt(EPI_DGELU) arguments) + dz GEMM (gz: A = gd's output plane) + LayerNorm backward (l: as launch_gemm_ln_bwd, with
+// dy_next, without per-image terms) as one launch (mlp_bwd_kernel). V1T_ERR_UNSUPPORTED: use launch_gemm_nt + launch_gemm_ln_bwd.
+int launch_mlp_bwd(const GemmNTArgs& gd, const GemmNTArgs& gz, const LnBwdArgs& l, hipStream_t s) {
+    if (l.DP != 160 || gd.K != l.DP || gz.N != l.DP || gz.K != gd.N || gd.N % 32 != 0 || gd.M != gz.M || gd.M != l.B * l.T) return V1T_ERR_UNSUPPORTED;
+    if (gd.A_lo || gd.B_lo || gz.A_lo || gz.B_lo || gd.f16 || gz.f16 || gd.rd.o || gz.rd.o || !gd.aux || !gd.C || gz.A != (const bf16_t*)gd.C || gz.lda != gd.ldc) return V1T_ERR_UNSUPPORTED;
+    if ((gd.lda % 8) || (gd.ldb % 8) || (gz.ldb % 8) || (gd.ldc % 8) || l.dinject || l.scale_next || !l.dy_next || !l.gin || !l.gout || !l.dgamma || !l.dbeta || l.D > l.DP) return V1T_ERR_UNSUPPORTED;
+    if (gd.M <= 0) return V1T_OK;
+    // OFF by default: measured neutral (112 images: 20.70 / 20.88 / 20.80 fused against 20.79 / 20.80 / 20.63 ms per step; 28- and 14-image shares
+    // 6.14 / 3.49 against 6.15 / 3.51: profiles/r05_small_launch_experiments.txt #26) - unlike the forward's fold, whose GELU stage hides FC2's
+    // MFMAs, both halves here are bound by the same HBM traffic, and the weight-gradient GEMMs of the second stream fill whatever a shorter
+    // chain leaves. V1T_MLP_BWD_FUSE=1: above 256 row tiles, 2: at every size (the equality test runs it).
+    static const int mode = std::getenv("V1T_MLP_BWD_FUSE") ? atoi(std::getenv("V1T_MLP_BWD_FUSE")) : 0;
+    const int tiles = (gd.M + 127) / 128;
+    if (mode == 0 || (mode != 2 && tiles <= 256)) return V1T_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((mlp_bwd_kernel<160>), dim3(tiles), dim3(256), 0, s, gd, gz, l);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 
