@@ -13,6 +13,17 @@
 
 namespace {
 
+// Stores of planes that only the BACKWARD reads (LayerNorm outputs, gelu', the fp16 activation plane of the fused MLP forward): non-temporal, so
+// that 0.4-0.5 GB per block written once do not evict the weight tiles and the residual rows the forward's next kernels read from L2
+// (-DV1T_NO_NT_SAVED: plain stores, A/B builds).
+template <typename V>
+DEVFN void store_saved(V* p, const V& v) {
+#ifdef V1T_NO_NT_SAVED
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
 constexpr int FRAG_BM = 128;  // row tile of the kernels that read / write fragment-order buffers (NW = 4)
 
 DEVFN size_t frag_index(const GemmNTArgs& g, int m0, int n0, int nb, int wave, int lane) {
@@ -108,8 +119,8 @@ DEVFN void gemm_epilogue(const GemmNTArgs& g, f32x16 (&acc)[NBLK], const f32x16 
         if constexpr (EPI == EPI_BIAS_GELU) {
             if (!g.lean) {  // kernel-uniform: inference forwards skip the gelu' plane (433 MB per block at batch 256)
                 bf16_t* fp = (bf16_t*)g.C + frag_index(g, m0, n0, nb, wave, lane);
-                *(bf16x8*)fp = gp0;
-                *(bf16x8*)(fp + 8) = gp1;
+                store_saved((bf16x8*)fp, gp0);
+                store_saved((bf16x8*)(fp + 8), gp1);
             }
         }
     }
@@ -774,7 +785,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ln_gemm_kernel(LnFwdArgs l, GemmNT
             zh[e] = (bf16_t)z;
             afrag[u][ks][e] = aux_plane(z, zh[e], 1);
         }
-        if (wz) *(bf16x8*)(l.z + (size_t)row * DP + c0) = zh;
+        if (wz) store_saved((bf16x8*)(l.z + (size_t)row * DP + c0), zh);
     }
     }  // row sets
 
@@ -955,7 +966,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(LnFwdArgs l, GemmNTArgs
                 zh[e] = (bf16_t)z;
                 afrag[ks][e] = aux_plane(z, zh[e], 1);
             }
-            if (wz) *(bf16x8*)(l.z + (size_t)row * DP + c0) = zh;
+            if (wz) store_saved((bf16x8*)(l.z + (size_t)row * DP + c0), zh);
         }
     }
 
@@ -970,7 +981,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(LnFwdArgs l, GemmNTArgs
         for (int c0 = 0; c0 < 32 * CPR; c0 += 64) {
             const int c = c0 + lane, crow = c / CPR, ch = c % CPR;
             const int grow = m0 + 32 * wave + crow;
-            if (grow < g.M) *(u32x4*)(dst + (size_t)grow * ld + n0 + 8 * ch) = *(const u32x4*)(st + crow * CS + 8 * ch);
+            if (grow < g.M) store_saved((u32x4*)(dst + (size_t)grow * ld + n0 + 8 * ch), *(const u32x4*)(st + crow * CS + 8 * ch));  // read by the backward only
         }
     };
     f32x16 acc2[NB2];
