@@ -1,3 +1,6 @@
+"""Dev probe (GPU box): core tokens and rollout rows of the default V1T in eval mode with the MLP branch forward as one launch (V1T_MLP_FUSE=2)
+against LN2 + FC1 and FC2 as two (V1T_MLP_FUSE=0), same seeded weights, batches of 2 / 24 / 40 images: how many elements differ and by how much
+(same operands and K order; the compiler contracts the GELU arithmetic of the two instantiations differently: last-bit differences)."""
 import os, sys, subprocess, torch
 code = r'''
 import os, sys, torch
