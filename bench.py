@@ -373,6 +373,8 @@ class Watchdog:
             while True:
                 b = r.recv(1)
                 if b and b[0] == signal.SIGTERM:
+                    if self._stop:  # the run is complete (its line is printed): terminated during teardown = success
+                        os._exit(0)
                     try:
                         if self.on_expire is not None:
                             self.on_expire(f"terminated by the launcher in phase '{self.phase}' (another rank failed or a deadline passed)")
@@ -483,9 +485,11 @@ def main():
     if a.dry_run:
         raise SystemExit(dry_run(a))
 
-    state = {"line": None}  # what rank 0 knows of the line so far: printed with the failure if the run cannot finish
+    state = {"line": None, "done": False}  # what rank 0 knows of the line so far: printed with the failure if the run cannot finish
 
     def fail_line(msg: str) -> None:
+        if state.get("done"):  # the success line is out: ONE JSON line per run, whatever happens during teardown
+            return
         if int(os.environ.get("RANK", "0")) == 0:
             base = state["line"] or {"metric": "training images/sec at batch 16x7 mice (V1T core vit + gaussian2d readout)", "unit": "images/s", "n_gpus": a.gpus,
                                      "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "config": {}}
@@ -505,6 +509,10 @@ def main():
         import traceback
 
         traceback.print_exc()
+        if state.get("done"):  # the measurement completed and its line is printed: a teardown error does not turn it into a failure
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         fail_line(f"{type(e).__name__}: {e}")
         sys.stdout.flush()
         sys.stderr.flush()
@@ -522,7 +530,7 @@ def run_training(a, wd, state):
 
     if os.environ.get("V1T_BENCH_RAISE"):  # test hook (tests/test_bench_launch.py): an error inside the run -> the failure line, rc != 0
         raise RuntimeError(os.environ["V1T_BENCH_RAISE"])
-    rank, local, world = init_from_env()
+    rank, local, world = init_from_env(timeout_s=float(os.environ.get("V1T_DIST_TIMEOUT_S", "300")))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))  # ranks on THIS node (a multi-node launch has world > the node's GPUs)
@@ -542,6 +550,8 @@ def run_training(a, wd, state):
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
+        state["done"] = True
+        wd.stop()
         return
 
     if a.config == "c2":
@@ -768,8 +778,15 @@ def run_training(a, wd, state):
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
+    # The measurement is complete (rank 0: printed). From here on nothing may print a second line or turn the run into a failure: disarm the
+    # watchdog / failure paths first, then leave WITHOUT the process group's destructor - it can hang or raise when a sibling is already gone
+    # (ADVICE r05), and a completed 8-GPU measurement must not be recorded as failed because of its teardown.
+    state["done"] = True
+    wd.stop()
     if world > 1:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

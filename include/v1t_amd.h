@@ -120,6 +120,18 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
                             const float* path_scale, const float* gout, float* grads, void* const* block_done,
                             void* stream);
 
+/* Same, and - when dimages is not NULL - also writes (=, not +=) the gradient with respect to the core input, dimages (B, C, H, W) fp32:
+ * the reference's core is plain autograd, so d response / d image comes with `.backward()` there (Unfold + Linear vit.py:66-72, Conv2d
+ * :73-82, the patch LayerNorms :83-100, cls / pos / dropout :122-129; conv tokenizer cct.py:30-104) and gradient-based analyses of a
+ * trained model (MEIs, saliency) rely on it. d x0 . W in fp32 against the fp32 master weight, [input gradient of the LayerNorm over the
+ * patch], col2im. scratch must then hold v1t_vit_scratch_bytes_input(h, batch) bytes. */
+long long v1t_vit_scratch_bytes_input(const v1t_vit* h, int batch);
+int v1t_vit_backward_input(const v1t_vit* h, const float* arena, const void* shadow, const float* images,
+                           const float* behaviors, int mouse_idx, int batch, const void* workspace,
+                           void* scratch, long long scratch_bytes, int training, uint64_t seed,
+                           const float* path_scale, const float* gout, float* grads, void* const* block_done,
+                           float* dimages, void* stream);
+
 /* 1 when v1t_vit_backward* of `batch` images hands its weight-gradient GEMMs (dW = dY^T X of the four linear layers of a block) to a second
  * stream that runs them beside the next block's dX / attention kernels (launches under 262 144 token rows), 0 when everything runs on
  * `stream`. The gradients are complete on `stream` when the call's work is, either way. */
@@ -213,6 +225,8 @@ int v1t_crop_nearest(const float* in, int B, int C, int IH, int IW, const float*
 /* ImageCropper resize (image_cropper.py:96-99,134-135): torchvision Resize(antialias=False) = bilinear, half-pixel
  * centres, on `planes` = B*C images of IH x IW -> OH x OW (144x256 -> 36x64 for Sensorium). */
 int v1t_resize_bilinear(const float* in, int planes, int IH, int IW, float* out, int OH, int OW, void* stream);
+/* its adjoint (autograd of F.interpolate in the reference): din (planes, IH, IW) = sum over the output pixels of weight * dout (written, not +=) */
+int v1t_resize_bilinear_backward(const float* dout, int planes, int IH, int IW, float* din, int OH, int OW, void* stream);
 
 /* ELU1 (models/utils.py:109-118) + PoissonLoss (losses.py:153-166, scale_ds :114-119).
  * yhat/du/loss may be NULL; y may be NULL (inference: only yhat). loss is += (zero it first). */

@@ -189,10 +189,10 @@ def ref_core_taps(model, batch, mouse_id):
 # --------------------------------------------------------------------------------------
 # fixtures
 # --------------------------------------------------------------------------------------
-def gen_train_fixture(name: str, cfg: O.Config, batch_size: int, seed: int, out: dict, train: bool = False, log=print):
+def gen_train_fixture(name: str, cfg: O.Config, batch_size: int, seed: int, out: dict, train: bool = False, log=print, sd_fn=None):
     """G1/G2/G4: outputs, loss, reg and gradient samples for one mouse-batch."""
     mouse = cfg.mouse_ids[0]
-    sd = W.make_state_dict(cfg, seed)
+    sd = (sd_fn or W.make_state_dict)(cfg, seed)
     batch = W.make_batch(cfg, mouse, batch_size, seed)
     model = build_reference_model(cfg, sd, seed)
     ds_size = 4500.0
@@ -641,6 +641,56 @@ def gen_data(out: dict, log=print):
             log(f"  g10/{ds_name}: ok ({len(dsx)} test trials, image {dsx.image_shape})")
 
 
+def input_gradient(name: str, cfg: O.Config, sd, batch_size: int, seed: int, out: dict, ds_size: float = 4500.0, log=print):
+    """d (loss + reg) / d image from the REAL reference's autograd (the core is plain torch there: Unfold + Linear vit.py:66-72, Conv2d
+    :73-82, patch LayerNorms :83-100; conv tokenizer cct.py:30-104; the cropper at crop 1 is the identity gather), eval mode, whole tensor
+    stored; the oracle's own autograd is pinned against it (fp32 and fp64). SURVEY 8(c) G1 "grads of all params + core input"."""
+    from v1t.losses import PoissonLoss
+
+    mouse = cfg.mouse_ids[0]
+    batch = W.make_batch(cfg, mouse, batch_size, seed)
+    model = build_reference_model(cfg, sd, seed)
+    model.train(False)
+    crit = PoissonLoss(SimpleNamespace(ds_scale=1), ds={m: SimpleNamespace(dataset=range(int(ds_size))) for m in cfg.mouse_ids})
+    img = batch["image"].clone().requires_grad_(True)
+    y, _, _ = model(inputs=img, mouse_id=mouse, behaviors=batch["behavior"], pupil_centers=batch["pupil_center"])
+    loss = crit(y_true=batch["response"], y_pred=y, mouse_id=mouse, batch_size=batch_size)
+    (loss + model.regularizer(mouse)).backward()
+    dx = img.grad.detach().clone()
+    for dt, rt in ((torch.float32, 1e-3), (torch.float64, 1e-4)):
+        b = {k: v.to(dt) for k, v in batch.items()}
+        b["image"] = b["image"].clone().requires_grad_(True)
+        ol, orr, _ = O.total_loss(cfg, O.to_dtype(sd, dt), b, mouse, ds_size)
+        (ol + orr).backward()
+        e = check(f"{name}.dx[{dt}]", dx, b["image"].grad, rt, rt * float(dx.abs().max()))
+    out[f"{name}/input_grad"] = dx.numpy()
+    log(f"  {name}: d / d image |max| {float(dx.abs().max()):.3e}, oracle[fp64] vs reference {e:.2e}")
+
+
+def gen_sharp_and_input_grad(out: dict, log=print):
+    """G14: (i) the default V1T in the regime of TRAINED weights (`weights.make_sharp_state_dict`: score std 3-9, LayerNorm gains 0.3-3 with
+    sign flips, residual outlier channels of +-80, clamped / out-of-range sample positions) - predictions, loss, every gradient, eval and
+    train-mode sampling with injected eps; (ii) gradients with respect to the core input for C1, the default V1T (flat and sharp), the
+    patch modes, a stride, two channels and the CCT tokenizer."""
+    cfg = W.config_c2({"A": 8000})
+    gen_train_fixture("g14", cfg, 2, 1234, out, log=log, sd_fn=W.make_sharp_state_dict)
+    c = W.config_c2({"A": 8000})
+    c.p_dropout = 0.0
+    c.t_dropout = 0.0
+    gen_train_fixture("g14t", c, 2, 1234, out, train=True, log=log, sd_fn=W.make_sharp_state_dict)
+    input_gradient("g14", cfg, W.make_sharp_state_dict(cfg, 1234), 2, 1234, out, log=log)
+    input_gradient("g1", W.config_c1(), W.make_state_dict(W.config_c1(), 1234), 2, 1234, out, log=log)
+    input_gradient("g2", cfg, W.make_state_dict(cfg, 1234), 2, 1234, out, log=log)
+    base = dict(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 200, "B": 123})
+    for vn, kw in {"patch1": dict(patch_mode=1), "patch2": dict(patch_mode=2), "patch3": dict(patch_mode=3), "stride2": dict(patch_stride=2),
+                   "franke": dict(input_shape=(2, 36, 64))}.items():
+        c = O.Config(**{**base, **kw})
+        input_gradient(f"dx_{vn}", c, W.make_state_dict(c, 77), 2, 77, out, log=log)
+    c13 = W.config_cct({"A": 200})
+    c13.num_blocks, c13.behavior_mode, c13.pos_emb, c13.emb_dim, c13.mlp_dim, c13.num_heads = 2, 0, "none", 64, 128, 2
+    input_gradient("dx_cct", c13, W.make_state_dict(c13, 77), 2, 77, out, log=log)
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
@@ -650,6 +700,13 @@ def main():
         path = os.path.join(ROOT, "tests", "golden", fname)
         np.savez_compressed(path, **d)
         print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB, {len(d)} arrays")
+
+    d = {}
+    print("G14 trained-regime (sharp attention, outlier channels, clamped positions) default V1T + gradients w.r.t. the core input")
+    gen_sharp_and_input_grad(d)
+    save("g14_sharp_dx.npz", d)
+    if "--only-g14" in sys.argv:
+        return
 
     d = {}
     print("G12 boundary: optimizer groups / readout initialisation of the reference's constructors")

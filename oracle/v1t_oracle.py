@@ -125,6 +125,16 @@ def linear(x: Tensor, w: Tensor, b: t.Optional[Tensor]) -> Tensor:
     return y if b is None else y + b
 
 
+# None = the reference's arithmetic. A number = ALSO emulate the one documented saturation of the product under test (the
+# attention output and the GELU output are stored as fp16 planes, written saturated at +-65504): used by ONE test that drives activations
+# past fp16's range and checks that the product degrades as documented (finite, clamped) instead of overflowing.
+F16_PLANE_MAX: t.Optional[float] = None
+
+
+def _plane(x: Tensor) -> Tensor:
+    return x if F16_PLANE_MAX is None else x.clamp(-F16_PLANE_MAX, F16_PLANE_MAX)
+
+
 def apply_mask(x: Tensor, mask: t.Optional[Tensor], p: float) -> Tensor:
     """nn.Dropout in train mode with an explicit keep-mask (1 = keep): x * mask / (1 - p)."""
     if mask is None:
@@ -229,7 +239,7 @@ def attention(
         record.append(attn.detach().clone())  # Recorder hook: P before dropout (attention_rollout.py:28-36)
     # "attn_p": effective rate of a replayed mask (the HIP kernels run the attention-P dropout at round(65536 p) / 65536)
     attn = apply_mask(attn, masks.get(f"attn{k}"), masks.get("attn_p", cfg.t_dropout))
-    o = (attn @ v).permute(0, 2, 1, 3).reshape(b, n, h * d)
+    o = _plane((attn @ v).permute(0, 2, 1, 3).reshape(b, n, h * d))
     o = linear(o, sd[p + "projection.0.weight"], sd.get(p + "projection.0.bias"))
     return apply_mask(o, masks.get(f"proj{k}"), cfg.t_dropout)
 
@@ -240,7 +250,7 @@ def mlp(cfg: Config, sd: SD, k: int, x: Tensor, masks: t.Optional[t.Dict[str, Te
     masks = masks or {}
     z = layer_norm(x, sd[p + "0.weight"], sd[p + "0.bias"])
     hdn = gelu_erf(linear(z, sd[p + "1.weight"], sd.get(p + "1.bias")))
-    hdn = apply_mask(hdn, masks.get(f"fc1{k}"), cfg.t_dropout)
+    hdn = _plane(apply_mask(hdn, masks.get(f"fc1{k}"), cfg.t_dropout))
     y = linear(hdn, sd[p + "4.weight"], sd.get(p + "4.bias"))
     return apply_mask(y, masks.get(f"fc2{k}"), cfg.t_dropout)
 

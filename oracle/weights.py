@@ -208,6 +208,44 @@ def _finish_state_dict(cfg, seed, sd, put):
     return {k: torch.from_numpy(np.array(v, copy=True, order="C")) for k, v in sd.items()}
 
 
+def make_sharp_state_dict(cfg: Config, seed: int = 1234, qk_gain: float = 2.6, outlier: float = 80.0) -> t.Dict[str, torch.Tensor]:
+    """`make_state_dict` moved into the regime a TRAINED V1T lives in (every other golden has score std ~ 0.6, i.e.
+    nearly flat softmax rows and O(1) activations): the q / k rows of every to_qkv times `qk_gain` (scores ~ gain^2: std 4-6, peaked rows),
+    LayerNorm gains spread over [0.3, 3], a handful of residual-stream outlier channels of magnitude `outlier` (through the patch bias and
+    one FC2 bias: the "massive activations" of trained transformers, which also shrink every LayerNorm's rstd), readout sigma and core
+    shifts large enough that sigma * eps + mu is clamped and mu + shift leaves [-1, 1] (zero-padded taps). ViT cores only."""
+    assert cfg.core == "vit"
+    sd = {k: v.clone() for k, v in make_state_dict(cfg, seed).items()}
+    D, H = cfg.emb_dim, cfg.num_heads
+    for k in range(cfg.num_blocks):
+        b = f"core.transformer.blocks.{k}."
+        sd[b + "mha.to_qkv.weight"][: 2 * H * D] *= qk_gain
+        for ln, tag in ((b + "mha.layer_norm.weight", "ln1g"), (b + "mlp.model.0.weight", "ln2g")):
+            g = np.exp(_uniform(seed, ln + tag, (D,), np.log(0.3), np.log(3.0)))
+            sign = np.where(_rng(seed, ln + tag + "s").uniform(size=D) < 0.1, -1.0, 1.0)
+            sd[ln] = torch.from_numpy((g * sign).astype(np.float32))
+    # outlier channels: constant over tokens (patch bias) and appearing mid-stream (FC2 bias of block 0); class token shares them via cls
+    ch = _rng(seed, "outlier.ch").choice(D, size=4, replace=False)
+    amp = np.array([outlier, -0.75 * outlier, 0.6 * outlier, -outlier], np.float32)
+    pb = [k for k in sd if k.startswith("core.patch_embedding.projection.") and k.endswith(".bias") and sd[k].shape == (D,)]
+    pbk = sorted(pb)[0] if cfg.patch_mode != 3 else "core.patch_embedding.projection.3.bias"
+    sd[pbk][ch[:2]] += torch.from_numpy(amp[:2])
+    sd["core.patch_embedding.cls_token"][0, 0, ch[:2]] += torch.from_numpy(amp[:2])
+    if not cfg.disable_bias:
+        sd["core.transformer.blocks.0.mlp.model.4.bias"][ch[2:]] += torch.from_numpy(amp[2:])
+    for mid in cfg.mouse_ids:
+        n = cfg.num_neurons[mid]
+        r = f"readouts.{mid}."
+        sd[r + "sigma"] = torch.from_numpy(_uniform(seed, r + "sigma.sharp", (1, n, 2, 2), -0.6, 0.6))
+        if cfg.shift_mode in (2, 3, 4):
+            s = f"core_shifter.{mid}.mlp."
+            sd[s + "4.weight"] = torch.from_numpy(_uniform(seed, s + "4w", (2, 5), -0.45, 0.45) * 2.0)
+            sd[s + "4.bias"] = torch.from_numpy(_uniform(seed, s + "4b", (2,), -0.45, 0.45))
+        if not cfg.disable_grid_predictor:
+            sd[r + "mu_transform.2.weight"] = torch.from_numpy(_uniform(seed, r + "m2w", (2, 30), -1, 1) * 1.5)  # mu = tanh(.) pushed towards +-1
+    return sd
+
+
 def make_batch(cfg: Config, mouse_id: str, batch: int, seed: int = 1234, full_res: bool = False) -> t.Dict[str, torch.Tensor]:
     """Synthetic Sensorium-shaped batch: image ~N(0,1) at the CORE input shape
     (or (C,144,256) pre-cropper when full_res), behavior ~|N(0,1)|, pupil ~N(0,1), response ~Exp(1)."""

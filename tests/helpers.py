@@ -52,6 +52,27 @@ def check_rel(name: str, got, ref, tol: float) -> float:
     return e
 
 
+G_L2_TOL = 4e-2    # relative L2 error of a gradient tensor, ||g - ref|| / ||ref||
+G_COS_TOL = 1e-3   # 1 - cosine(g, ref)
+
+
+def check_grad(name: str, got, ref, tol_max: float, tol_l2: float = G_L2_TOL, tol_cos: float = G_COS_TOL) -> float:
+    """A gradient tensor against its reference under THREE bounds (a per-tensor max bound alone lets an error that
+    is confined to the small entries, or a sign error on ~1 % of the elements, pass): max error relative to the tensor's max (`check_rel`),
+    relative L2 error, and 1 - cosine. Margins of all three are recorded for the end-of-run table."""
+    e = check_rel(name, got, ref, tol_max)
+    g, r = _np(got).reshape(-1), _np(ref).reshape(-1)
+    nr = float(np.linalg.norm(r))
+    if nr > 0.0:
+        l2 = float(np.linalg.norm(g - r)) / nr
+        cos = 1.0 - float(np.dot(g, r)) / (float(np.linalg.norm(g)) * nr + 1e-300)
+        record_margin(name + " [rel L2]", l2, tol_l2)
+        record_margin(name + " [1 - cos]", max(cos, 0.0), tol_cos)
+        assert l2 < tol_l2, f"{name}: relative L2 error {l2:.3e}, bound {tol_l2:.1e}"
+        assert cos < tol_cos, f"{name}: 1 - cosine {cos:.3e}, bound {tol_cos:.1e}"
+    return e
+
+
 def build_native_model(cfg, sd, device, dropout=None):
     """v1t_amd.Model configured like the oracle Config `cfg`, weights loaded from state-dict `sd`."""
     import v1t_amd

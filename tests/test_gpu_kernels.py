@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import check_rel, rel_to_max
+from tests.helpers import check_grad, check_rel, rel_to_max
 
 pytestmark = pytest.mark.gpu
 
@@ -558,6 +558,56 @@ def test_attention_forward_extreme_scores(ctx):
     check_rel("test_attention_forward_extreme_scores:38", o.float().cpu(), ref.cpu(), 1.5e-2)
     # scores of ~1e3 in log2 units
     assert float(((lse - ref_lse2).abs() / (1.0 + 4e-3 * ref_lse2.abs())).max()) < 1.0
+
+
+@pytest.mark.parametrize("p", [0.0, 0.2544])
+def test_attention_backward_extreme_scores(ctx, p):
+    """The default backward pair - `attn_bwd_dkv2` (S' = c q.k - lse folded into the accumulator, dS' materialised as bf16) and `attn_bwd_dq2`
+    - at the production shape (head dim 160, T = 1654) in the regime of trained weights: score std ~ 6 (peaked rows: the largest
+    probability of a row ~ 0.3-1), single queries / keys scaled further so that some rows are one-hot and some scores reach ~ +-100, against
+    fp32 torch autograd over the same bf16 inputs; forward log-sum-exp and output too (the extreme-score check was
+    forward-only at T = 200)."""
+    lib, L, dev = ctx
+    B, H, T, DP = 1, 2, 1654, 160
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B * T, 3, H, DP, generator=g) * 0.7
+    x[:, 0] *= 3.5          # q, k: scores ~ N(0, (0.7 * 3.5)^4 * 160 / 160) -> std ~ 6
+    x[:, 1] *= 3.5
+    x[5, 0] *= 4.0          # a query with scores up to ~ +-100: a one-hot row
+    x[900, 1, 0] *= 4.0     # a key (head 0) most queries either lock on to or never see
+    x[1653, 0, 1] *= 6.0    # the last query of the ragged tail tile, head 1
+    x[:, 2] *= 1.5
+    qkv = x.reshape(B * T, 3 * H * DP).to(dev).bfloat16().requires_grad_(True)
+    scale = torch.tensor([DP ** -0.5], device=dev)
+    o = torch.empty(B * T, H * DP, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, T, device=dev)
+    seed, sid = 99, 8
+    L.check(lib.v1t_attention_forward(qkv.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid, o.data_ptr(), lse.data_ptr(), L.stream()))
+    mask = None
+    if p > 0:
+        mask = torch.empty(B * H * T, T, device=dev, dtype=torch.uint8)
+        L.check(lib.v1t_dropout_mask(seed, sid, p, B * H * T, T, mask.data_ptr(), L.stream()))
+    p_eff = float(lib.v1t_attention_dropout_rate(p))
+    ref = _attn_ref(qkv, B, H, T, DP, scale.expand(H), mask, p_eff)
+    q_, k_ = (qkv.detach().float().view(B, T, 3, H, DP)[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+    s_ = (q_ @ k_.transpose(-1, -2)) * float(scale)
+    assert 4.0 < float(s_.std()) < 9.0 and float(torch.softmax(s_, -1).max(-1).values.median()) > 0.2  # the regime the test claims
+    assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
+    check_rel(f"extreme scores p={p}: forward", o.float().cpu(), ref.detach().cpu(), 1.2e-2)
+    ref_lse2 = torch.logsumexp(s_, -1) * 1.4426950408889634
+    assert float(((lse - ref_lse2).abs() / (1.0 + 4e-3 * ref_lse2.abs())).max()) < 1.0
+    dO = (torch.randn(B * T, H * DP, generator=g) * 0.5).to(dev).bfloat16()
+    (gq,) = torch.autograd.grad(ref, (qkv,), dO.float())
+    delta = torch.empty(B, H, T, device=dev)
+    nb = int(lib.v1t_attention_backward_ws_bytes(B, H, T))
+    ws = torch.full((nb,), 0xFF, dtype=torch.uint8, device=dev)
+    d2 = torch.zeros_like(qkv)
+    L.check(lib.v1t_attention_backward_ws(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid,
+                                          delta.data_ptr(), d2.data_ptr(), None, ws.data_ptr(), nb, L.stream()))
+    assert bool(torch.isfinite(d2.float()).all())
+    gq, e = gq.view(B * T, 3, H * DP), d2.float().view(B * T, 3, H * DP)
+    for i, nm in enumerate("qkv"):
+        check_grad(f"extreme scores p={p}: d{nm} (dkv2 + dq2)", e[:, i].cpu(), gq[:, i].cpu(), 1.2e-2)
 
 
 def test_multi_unit_entry_points_beyond_one_table(ctx):

@@ -16,7 +16,7 @@ import torch
 
 from oracle import v1t_oracle as O
 from oracle import weights as W
-from tests.helpers import build_native_model, check_rel, record_margin
+from tests.helpers import build_native_model, check_grad, check_rel, record_margin
 
 pytestmark = pytest.mark.gpu
 G_TOL = 1.2e-2  # the gradient bound of tests/test_gpu_parity.py
@@ -74,12 +74,23 @@ def test_c2_native_step_gradients_vs_oracle_direct(dev):
         if float(ref.abs().max()) == 0.0:
             assert float(p.grad.abs().max()) == 0.0, k
         else:
-            check_rel(f"c2 direct: native-step grad {k} vs oracle", p.grad.detach().cpu().reshape(ref.shape), ref, G_TOL)
+            check_grad(f"c2 direct: native-step grad {k} vs oracle", p.grad.detach().cpu().reshape(ref.shape), ref, G_TOL)
         n += 1
     assert n >= 60, n  # 4 blocks x 12 + patch embedding + BehaviorMLPs + readout + shifter
 
 
-def test_c2_native_step_dropout_on_vs_oracle_replayed_masks(dev):
+REPLAY_CASES = {
+    "c2": (lambda: W.config_c2({"A": 8000}), W.make_state_dict),
+    # the same step in the regime of trained weights: peaked attention rows, LayerNorm gains 0.3-3, residual outlier channels of +-80,
+    # clamped / out-of-range sample positions (oracle/weights.py::make_sharp_state_dict)
+    "c2-sharp": (lambda: W.config_c2({"A": 8000}), W.make_sharp_state_dict),
+    # BASELINE configs[3] at the bench shape: Franke-shaped 2-channel input, behavior_mode 3, 1121 neurons, batch 16
+    "c4": (W.config_c4, W.make_state_dict),
+}
+
+
+@pytest.mark.parametrize("case", sorted(REPLAY_CASES))
+def test_c2_native_step_dropout_on_vs_oracle_replayed_masks(dev, case):
     """The step bench.py times, as bench.py runs it: BASELINE configs[1] (4 blocks, D = 155, 4 heads, MLP 488, T = 1654, 8000 neurons),
     one mouse at the metric's batch 16, ALL dropouts ON (p = 0.0229 / 0.2544) and readout sampling on, through `Trainer.train_step` ->
     `_NativeStep` (the fixed C-ABI sequence). The counter-based keep masks of the step's seed are read back through `v1t_dropout_mask`
@@ -92,9 +103,10 @@ def test_c2_native_step_dropout_on_vs_oracle_replayed_masks(dev):
     from v1t_amd.trainer import Trainer
 
     B = 16
-    cfg = W.config_c2({"A": 8000})
+    cfg_fn, sd_fn = REPLAY_CASES[case]
+    cfg = cfg_fn()
     assert cfg.p_dropout > 0 and cfg.t_dropout > 0
-    sd = W.make_state_dict(cfg, 1234)
+    sd = sd_fn(cfg, 1234)
     batch = W.make_batch(cfg, "A", B, 2468)
     eps = W.make_eps(cfg, "A", B, 2468)
     model, args = build_native_model(cfg, sd, dev)
@@ -121,7 +133,7 @@ def test_c2_native_step_dropout_on_vs_oracle_replayed_masks(dev):
     finally:
         torch.set_num_threads(nthr)
     lo = float(ol)
-    record_margin("c2 dropout-on: native-step loss vs oracle", abs(float(out["loss"]) - lo), 1e-4 * abs(lo))
+    record_margin(f"{case} dropout-on: native-step loss vs oracle", abs(float(out["loss"]) - lo), 1e-4 * abs(lo))
     assert abs(float(out["loss"]) - lo) <= 1e-4 * abs(lo)
     n = 0
     for k, p in model.named_parameters():
@@ -132,7 +144,7 @@ def test_c2_native_step_dropout_on_vs_oracle_replayed_masks(dev):
         if float(ref.abs().max()) == 0.0:
             assert float(p.grad.abs().max()) == 0.0, k
         else:
-            check_rel(f"c2 dropout-on: native-step grad {k} vs oracle", p.grad.detach().cpu().reshape(ref.shape), ref, G_TOL)
+            check_grad(f"{case} dropout-on: native-step grad {k} vs oracle", p.grad.detach().cpu().reshape(ref.shape), ref, G_TOL)
         n += 1
     assert n >= 60, n
 

@@ -37,13 +37,14 @@ SEEDS = {"g13b": 77, "g13c": 78}
 
 
 @pytest.mark.parametrize("name,cfg_fn,train", [("g1", W.config_c1, False), ("g4", W.config_c1, True), ("g2b", W.config_c4, False),
-                                               ("g13", W.config_cct, False), ("g13b", _cct_b, False), ("g13c", _cct_c, False)])
+                                               ("g13", W.config_cct, False), ("g13b", _cct_b, False), ("g13c", _cct_c, False),
+                                               ("g14t", lambda: W.config_c2({"A": 8000}), True)])
 def test_forward_backward_vs_golden(golden, name, cfg_fn, train):
     cfg = cfg_fn()
     if train:
         cfg.p_dropout = cfg.t_dropout = 0.0
     seed = SEEDS.get(name, 1234)
-    sd = W.make_state_dict(cfg, seed)
+    sd = (W.make_sharp_state_dict if name.startswith("g14") else W.make_state_dict)(cfg, seed)  # g14*: the trained-weights regime
     batch = W.make_batch(cfg, "A", 2, seed)
     eps = torch.from_numpy(golden[f"{name}/eps"]) if train else None
     loss, reg, y, sdd = _grads(cfg, sd, batch, "A", eps)
@@ -60,6 +61,23 @@ def test_forward_backward_vs_golden(golden, name, cfg_fn, train):
             assert_close(f"{name}.grad.{key}", sample(g), ref, 1e-3, 1e-3 * float(np.abs(ref).max()) + 1e-7)
             n += 1
     assert n >= (16 if name.startswith("g13") else 20)
+
+
+@pytest.mark.parametrize("name,cfg_fn,seed", [("g1", W.config_c1, 1234), ("dx_patch2", lambda: O.Config(patch_mode=2, **_VAR_BASE), 77),
+                                              ("dx_stride2", lambda: O.Config(patch_stride=2, **_VAR_BASE), 77), ("dx_cct", _cct_b, 77)])
+def test_input_gradient_vs_golden(golden, name, cfg_fn, seed):
+    """d (loss + reg) / d image of the oracle's autograd against the real reference's (golden G14; SURVEY 8(c) G1 "+ core input")."""
+    cfg = cfg_fn()
+    sd = W.make_state_dict(cfg, seed)
+    batch = W.make_batch(cfg, "A", 2, seed)
+    batch["image"] = batch["image"].clone().requires_grad_(True)
+    loss, reg, _ = O.total_loss(cfg, sd, batch, "A", 4500.0)
+    (loss + reg).backward()
+    ref = golden[f"{name}/input_grad"]
+    assert_close(f"{name}.dx", batch["image"].grad.numpy(), ref, 1e-3, 1e-3 * float(np.abs(ref).max()))
+
+
+_VAR_BASE = dict(num_blocks=1, emb_dim=64, mlp_dim=128, num_heads=4, mouse_ids=("A", "B"), num_neurons={"A": 200, "B": 123})
 
 
 def test_taps_vs_golden(golden):

@@ -115,6 +115,7 @@ class _VitFn(torch.autograd.Function):
         )
         ctx.core, ctx.ws, ctx.images, ctx.behaviors = core, ws, images, behaviors
         ctx.mouse_idx, ctx.seed, ctx.training, ctx.B = mouse_idx, seed, training, B
+        ctx.want_dx = bool(images.requires_grad)
         ctx.path_scale = ps
         core._last_ws = (ws, B, bool(need_bwd))
         return out
@@ -125,21 +126,23 @@ class _VitFn(torch.autograd.Function):
         lib = L.load()
         gout = gout.contiguous()
         core._arena.attach_grads()
-        sb = lib.v1t_vit_scratch_bytes(core._plan, ctx.B)
+        want_dx = ctx.want_dx and ctx.needs_input_grad[1]
+        sb = (lib.v1t_vit_scratch_bytes_input if want_dx else lib.v1t_vit_scratch_bytes)(core._plan, ctx.B)
         scratch = torch.empty(sb, dtype=torch.uint8, device=gout.device)
+        dx = torch.empty_like(ctx.images) if want_dx else None  # d / d(core input): vit.py:66-72, 122-129 under the reference's autograd
         evs = core._block_events  # data-parallel trainer: one event per block, recorded when its gradients are complete
         ev_arr = None
         if evs is not None:
             ev_arr = (C.c_void_p * len(evs))(*[e.cuda_event for e in evs])
         L.check(
-            lib.v1t_vit_backward_events(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), ctx.images.data_ptr(),
-                                        L.ptr(ctx.behaviors), ctx.mouse_idx, ctx.B, ctx.ws.data_ptr(), scratch.data_ptr(), sb,
-                                        int(ctx.training), ctx.seed, L.ptr(ctx.path_scale), gout.data_ptr(), core._arena.grad.data_ptr(),
-                                        ev_arr, L.stream()),
+            lib.v1t_vit_backward_input(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), ctx.images.data_ptr(),
+                                       L.ptr(ctx.behaviors), ctx.mouse_idx, ctx.B, ctx.ws.data_ptr(), scratch.data_ptr(), sb,
+                                       int(ctx.training), ctx.seed, L.ptr(ctx.path_scale), gout.data_ptr(), core._arena.grad.data_ptr(),
+                                       ev_arr, L.ptr(dx), L.stream()),
             "vit_backward",
         )
         ctx.ws = None
-        return None, None, None, None, None, None
+        return None, dx, None, None, None, None
 
 
 class _SplitFn(torch.autograd.Function):
@@ -514,10 +517,8 @@ class ViTCore(Core):
         """Token-major residual stream (B, T, DP) fp32 (CLS at t=0, columns >= emb_dim are zero).
         keep_workspace: keep every block's activations (qkv, lse2, ...) even under no_grad (attention rollout)."""
         L.require_cuda(inputs, "ViTCore.forward")
-        if inputs.requires_grad:
-            raise NotImplementedError("gradient w.r.t. the core input has no gfx950 kernel (no reference configuration needs it: the cropper samples nearest)")
         self.prepare()
-        inputs = inputs.to(torch.float32).contiguous()
+        inputs = inputs.to(torch.float32).contiguous()  # differentiable: an input that requires grad gets its gradient from v1t_vit_backward_input
         if tuple(inputs.shape[1:]) != tuple(self.input_shape):
             raise RuntimeError(f"ViTCore: expected input (B, {self.input_shape}), got {tuple(inputs.shape)}")
         beh = None
@@ -529,7 +530,7 @@ class ViTCore(Core):
         self._anchor.requires_grad_(next(self.parameters()).requires_grad and not self.frozen)  # freeze() flips every parameter
         # workspace mode of v1t_vit_forward: 1 = everything the backward reads; 2 = inference that keeps every block's q / k / log-sum-exp
         # (rollout, attention probabilities); 0 = inference. Modes 0 and 2 skip the planes only the backward reads (include/v1t_amd.h)
-        need_bwd = 1 if (torch.is_grad_enabled() and self._anchor.requires_grad) else (2 if keep_workspace else 0)
+        need_bwd = 1 if (torch.is_grad_enabled() and (self._anchor.requires_grad or inputs.requires_grad)) else (2 if keep_workspace else 0)
         return _VitFn.apply(self, inputs, beh, midx, self._anchor, need_bwd)
 
     # ------------------------------------------------------------------ the reference's own Recorder (utils/attention_rollout.py:15-77)

@@ -831,10 +831,23 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
                             int mouse_idx, int B, const void* workspace, void* scratch, long long scratch_bytes, int training,
                             uint64_t seed, const float* path_scale, const float* gout, float* grads, void* const* block_done,
                             void* stream) {
+    return v1t_vit_backward_input(h, arena, shadow, images, behaviors, mouse_idx, B, workspace, scratch, scratch_bytes, training, seed, path_scale,
+                                  gout, grads, block_done, nullptr, stream);
+}
+// fp32 [rows of the unfolded-patch matrix][PD] behind the backward's own scratch: dU of the input gradient
+static long long input_grad_bytes(const v1t_vit* h, int B) { return align_up((long long)B * h->RCI * h->PD * 4, 256); }
+long long v1t_vit_scratch_bytes_input(const v1t_vit* h, int batch) {
+    if (!h || batch <= 0) return 0;
+    return scratch_layout(h, batch).total + input_grad_bytes(h, batch);
+}
+int v1t_vit_backward_input(const v1t_vit* h, const float* arena, const void* shadow, const float* images, const float* behaviors,
+                           int mouse_idx, int B, const void* workspace, void* scratch, long long scratch_bytes, int training,
+                           uint64_t seed, const float* path_scale, const float* gout, float* grads, void* const* block_done,
+                           float* dimages, void* stream) {
     if (!h || !arena || !shadow || !images || !workspace || !scratch || !gout || !grads || B <= 0) return V1T_ERR_ARG;
     const WsLayout w = ws_layout(h, B, true);
     const ScratchLayout sl = scratch_layout(h, B);
-    if (scratch_bytes < sl.total) return V1T_ERR_WORKSPACE;
+    if (scratch_bytes < sl.total + (dimages ? input_grad_bytes(h, B) : 0)) return V1T_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const char* ws = (const char*)workspace;
     char* sc = (char*)scratch;
@@ -1085,6 +1098,9 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
     }
     join_dw(0);
     if (join_err) return join_err;
+    // block 1's gradients are complete here (its dWqkv rode in group 0, its dW2 / dW1 / dWo in group 1, joined at the start of block 0): its
+    // exchange can start beside the patch-embedding backward; only block 0 has to wait for the tail group
+    if (dw_side && block_done && h->NB > 1 && block_done[1] && hipEventRecord((hipEvent_t)block_done[1], s) != hipSuccess) return V1T_ERR_LAUNCH;
     // ---- patch embedding backward (gin = grad wrt x0)
     PatchArgs pa{};
     pa.img = images; pa.B = B; pa.C = h->C; pa.IH = h->IH; pa.IW = h->IW; pa.P = h->P; pa.stride = h->S; pa.NH = h->NH; pa.NW = h->NW;
@@ -1150,11 +1166,29 @@ int v1t_vit_backward_events(const v1t_vit* h, const float* arena, const void* sh
         CHECK(launch_patch_embed_bwd(pa, s));
     }
     if (!tail_side) CHECK(bmlp_backward(s));
+    if (dimages) {
+        // gradient with respect to the core input (vit.py:66-72, 122-129 under autograd; cct.py:30-104): dU = d x0 . W in fp32 against the fp32
+        // master weight, [the LayerNorm over the patch], col2im. An analysis path (MEIs, saliency): training never asks for it.
+        float* dU = (float*)(sc + sl.total);
+        const float* Wp = arena + h->o_pw;  // [D][PD] (mode 1 / CCT: the conv weight [D][C][P][P], the same layout)
+        if (h->cct) {
+            const long long RU = (long long)B * h->RCI;
+            CHECK(launch_patch_du(nullptr, (const bf16_t*)(sc + sl.pgd), DP, pa.drop, 0, 0, Wp, D, h->PD, RU, dU, s));
+            CHECK(launch_patch_col2im(dU, h->PD, B, h->C, h->IH, h->IW, h->P, h->S, h->c.conv_pad, h->CH, h->CW, h->RCI, 0, 0, dimages, s));
+        } else if (h->c.patch_mode >= 2) {
+            const char* wsb = (const char*)workspace;
+            CHECK(launch_patch_ln_bwd_rows((const float*)(sc + sl.pdu), h->PD, (const float*)(wsb + w.u32), h->PDX, (const float*)(wsb + w.pmean1),
+                                           (const float*)(wsb + w.prstd1), arena + h->o_pln_w, R, h->PD, dU, s));
+            CHECK(launch_patch_col2im(dU, h->PD, B, h->C, h->IH, h->IW, h->P, h->S, 0, h->NH, h->NW, h->T, 1, h->c.patch_mode == 2, dimages, s));
+        } else {
+            CHECK(launch_patch_du((const float*)gin, nullptr, DP, pa.drop, h->T, 1, Wp, D, h->PD, R, dU, s));
+            CHECK(launch_patch_col2im(dU, h->PD, B, h->C, h->IH, h->IW, h->P, h->S, 0, h->NH, h->NW, h->T, 1, 0, dimages, s));
+        }
+    }
     join_dw(1);  // everything of the second stream is behind `s` from here on
     if (join_err) return join_err;
-    if (dw_side && block_done)  // blocks 1 and 0: their groups are joined only now
-        for (int k = std::min(h->NB - 1, 1); k >= 0; --k)
-            if (block_done[k] && hipEventRecord((hipEvent_t)block_done[k], s) != hipSuccess) return V1T_ERR_LAUNCH;
+    if (dw_side && block_done && block_done[0] && hipEventRecord((hipEvent_t)block_done[0], s) != hipSuccess)  // block 0: its dWqkv is in the tail group
+        return V1T_ERR_LAUNCH;
     return V1T_OK;
 }
 
@@ -1218,6 +1252,10 @@ int v1t_crop_nearest(const float* in, int B, int C, int IH, int IW, const float*
 int v1t_resize_bilinear(const float* in, int planes, int IH, int IW, float* out, int OH, int OW, void* stream) {
     if (!in || !out || planes < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return V1T_ERR_ARG;
     return launch_resize_bilinear(in, out, planes, IH, IW, OH, OW, (hipStream_t)stream);
+}
+int v1t_resize_bilinear_backward(const float* dout, int planes, int IH, int IW, float* din, int OH, int OW, void* stream) {
+    if (!dout || !din || planes < 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return V1T_ERR_ARG;
+    return launch_resize_bilinear_bwd(dout, din, planes, IH, IW, OH, OW, (hipStream_t)stream);
 }
 int v1t_readout_grid_forward(int B, int N, int gd, const float* src, const float* W0, const float* b0, const float* W2, const float* b2,
                              const float* mu_free, const float* sigma, const float* eps, const float* shift, float* grid, void* stream) {

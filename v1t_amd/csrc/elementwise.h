@@ -79,6 +79,17 @@ int launch_patch_ln2_finish(const PatchLn2Args& a, hipStream_t s);
 int launch_ln_param_grad(const float* dz, int lddz, const float* x, int ldx, const float* mean, const float* rstd, int rows, int D,
                          float* dgamma, float* dbeta, hipStream_t s);
 
+// Gradient with respect to the core input (analysis path; the reference gets it from autograd through vit.py:66-72, 122-129):
+// dU = g . W in fp32 (g: fp32 rows through `drop`, class-token rows zero when cls; or bf16 rows gb), the input gradient of the
+// LayerNorm over the patch (modes 2 / 3), and col2im back onto the image (stride, zero padding, SPT's shifted channels).
+int launch_patch_du(const float* gf, const bf16_t* gb, int ldg, DropCfg drop, int T, int cls, const float* W, int D, int PD, long long rows, float* du,
+                    hipStream_t s);
+int launch_patch_ln_bwd_rows(const float* dz, int lddz, const float* u, int ldu, const float* mean, const float* rstd, const float* gamma, long long rows,
+                             int PD, float* out, hipStream_t s);
+int launch_patch_col2im(const float* du, int PD, int B, int C, int IH, int IW, int P, int stride, int pad, int GH, int GW, int rows_per_image, int row0,
+                        int spt, float* dx, hipStream_t s);
+int launch_resize_bilinear_bwd(const float* dout, float* din, int planes, int IH, int IW, int OH, int OW, hipStream_t s);
+
 struct LnFwdArgs {
     const float* x;      // [rows][DP]
     const float* inject; // [B][DP] or nullptr: x += inject[b] (written to xout)

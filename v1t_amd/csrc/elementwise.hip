@@ -133,6 +133,98 @@ __global__ __launch_bounds__(256) void patch_unfold_kernel(PatchArgs a, bf16_t* 
     if (u_lo) *(bf16x8*)(u_lo + row * ldu + 8 * jc) = lo;
 }
 
+// ---- gradient with respect to the core input (elementwise.h, launch_patch_input_grad): the reference's core is plain autograd, so
+// d response / d image comes for free there (vit.py:66-72, 122-129); gradient-based analyses of a trained model (MEIs, saliency) need it.
+// Not on the training path (the cropper samples nearest), so plain fp32 VALU from the fp32 residual-stream gradient.
+// dU[r][j] = sum_d g[r][d] W[d][j], W the fp32 master [D][PD]; g = dropout_bwd(gf) (fp32 rows, class-token rows skipped) or gb (bf16 rows)
+__global__ __launch_bounds__(256) void patch_du_kernel(const float* __restrict__ gf, const bf16_t* __restrict__ gb, int ldg, DropCfg drop, int T, int cls,
+                                                       const float* __restrict__ W, int D, int PD, long long rows, float* __restrict__ du) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * PD) return;
+    const long long row = i / PD;
+    const int j = (int)(i % PD);
+    float acc = 0.f;
+    if (!(cls && row % T == 0)) {
+        for (int d = 0; d < D; ++d) {
+            float g;
+            if (gf) {
+                g = gf[row * ldg + d];
+                if (drop.thresh) g = drop_keep(drop.key, (uint32_t)row, (uint32_t)d, drop.thresh) ? g * drop.inv_keep : 0.f;
+            } else {
+                g = (float)gb[row * ldg + d];
+            }
+            acc = fmaf(g, W[(size_t)d * PD + j], acc);
+        }
+    }
+    du[i] = acc;
+}
+// input gradient of the LayerNorm over the patch (patch modes 2 / 3, vit.py:88, 97): one wave per row,
+// out = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dz * gamma, xhat = (u - mean) * rstd
+__global__ __launch_bounds__(256) void patch_ln_bwd_rows_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ u, int ldu,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, long long rows, int PD, float* __restrict__ out) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = lane; j < PD; j += 64) {
+        const float g = dz[row * lddz + j] * gamma[j], xh = (u[row * ldu + j] - mu) * rs;
+        s1 += g; s2 += g * xh;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    const float m1 = s1 / (float)PD, m2 = s2 / (float)PD;
+    for (int j = lane; j < PD; j += 64) {
+        const float g = dz[row * lddz + j] * gamma[j], xh = (u[row * ldu + j] - mu) * rs;
+        out[row * PD + j] = rs * (g - m1 - xh * m2);
+    }
+}
+// col2im: dx[b][c][y][x] = sum over the (patch, kh, kw) that read the pixel of dU[row(patch)][(c*P + kh)*P + kw]; zero padding `pad` (CCT conv
+// tokenizer), stride, and - spt - the four diagonal half-patch shifts of channel 0 that Shifted Patch Tokenization appends as channels C..C+3
+__global__ __launch_bounds__(256) void patch_col2im_kernel(const float* __restrict__ du, int PD, int B, int C, int IH, int IW, int P, int stride, int pad,
+                                                           int GH, int GW, int rows_per_image, int row0, int spt, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * C * IH * IW) return;
+    const int x = (int)(i % IW), y = (int)((i / IW) % IH), c = (int)((i / ((long long)IW * IH)) % C), b = (int)(i / ((long long)IW * IH * C));
+    const float* base = du + ((size_t)b * rows_per_image + row0) * PD;
+    float acc = 0.f;
+    auto gather = [&](int chan, int ys, int xs) {  // ys / xs = y0 + kh / x0 + kw of the patch element that read this pixel
+        for (int kh = 0; kh < P; ++kh) {
+            const int yy = ys + pad - kh;
+            if (yy < 0 || yy % stride != 0 || yy / stride >= GH) continue;
+            for (int kw = 0; kw < P; ++kw) {
+                const int xx = xs + pad - kw;
+                if (xx < 0 || xx % stride != 0 || xx / stride >= GW) continue;
+                acc += base[((size_t)(yy / stride) * GW + xx / stride) * PD + (chan * P + kh) * P + kw];
+            }
+        }
+    };
+    gather(c, y, x);
+    if (spt && c == 0) {
+        const int sh = P / 2;
+        for (int q = 0; q < 4; ++q) gather(C + q, y - ((q >> 1) ? sh : -sh), x - ((q & 1) ? sh : -sh));
+    }
+    dx[i] = acc;
+}
+// adjoint of resize_bilinear_kernel: din[pl][tap] += weight * dout[pl][y][x] (din zeroed by the caller)
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int planes, int IH, int IW, int OH, int OW) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)planes * OH * OW) return;
+    const int x = (int)(i % OW), y = (int)((i / OW) % OH);
+    const long long pl = i / ((long long)OW * OH);
+    const float sy = fmaxf(((float)y + 0.5f) * ((float)IH / (float)OH) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)x + 0.5f) * ((float)IW / (float)OW) - 0.5f, 0.f);
+    const int y0 = min((int)sy, IH - 1), x0 = min((int)sx, IW - 1);
+    const int y1 = min(y0 + 1, IH - 1), x1 = min(x0 + 1, IW - 1);
+    const float fy = sy - (float)y0, fx = sx - (float)x0;
+    float* p = din + pl * IH * IW;
+    const float g = dout[i];
+    atomicAdd(p + (size_t)y0 * IW + x0, g * (1.f - fx) * (1.f - fy));
+    atomicAdd(p + (size_t)y0 * IW + x1, g * fx * (1.f - fy));
+    atomicAdd(p + (size_t)y1 * IW + x0, g * (1.f - fx) * fy);
+    atomicAdd(p + (size_t)y1 * IW + x1, g * fx * fy);
+}
+
 // ---- CCT conv tokenizer (elementwise.h, ConvTokArgs)
 __global__ __launch_bounds__(256) void conv_unfold_kernel(ConvTokArgs a, bf16_t* u_hi, bf16_t* u_lo, int lo_f16, int ldu) {
     const int PD = a.C * a.P * a.P, PP = a.P * a.P, cpr = ldu / 8;
@@ -1221,6 +1313,35 @@ int launch_resize_bilinear(const float* in, float* out, int planes, int IH, int 
     const long long n = (long long)planes * OH * OW;
     if (n <= 0) return V1T_OK;
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, planes, IH, IW, OH, OW);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_resize_bilinear_bwd(const float* dout, float* din, int planes, int IH, int IW, int OH, int OW, hipStream_t s) {
+    const long long n = (long long)planes * OH * OW;
+    if (n <= 0) return V1T_OK;
+    const int rc = launch_fill_zero(din, (long long)planes * IH * IW * 4, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dout, din, planes, IH, IW, OH, OW);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_patch_du(const float* gf, const bf16_t* gb, int ldg, DropCfg drop, int T, int cls, const float* W, int D, int PD, long long rows, float* du,
+                    hipStream_t s) {
+    const long long n = rows * PD;
+    if (n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(patch_du_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gf, gb, ldg, drop, T, cls, W, D, PD, rows, du);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_patch_ln_bwd_rows(const float* dz, int lddz, const float* u, int ldu, const float* mean, const float* rstd, const float* gamma, long long rows,
+                             int PD, float* out, hipStream_t s) {
+    if (rows <= 0) return V1T_OK;
+    hipLaunchKernelGGL(patch_ln_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dz, lddz, u, ldu, mean, rstd, gamma, rows, PD, out);
+    return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+}
+int launch_patch_col2im(const float* du, int PD, int B, int C, int IH, int IW, int P, int stride, int pad, int GH, int GW, int rows_per_image, int row0,
+                        int spt, float* dx, hipStream_t s) {
+    const long long n = (long long)B * C * IH * IW;
+    if (n <= 0) return V1T_OK;
+    hipLaunchKernelGGL(patch_col2im_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, du, PD, B, C, IH, IW, P, stride, pad, GH, GW, rows_per_image,
+                       row0, spt, dx);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
 }
 int launch_inputs_multi(const float* const* img, const float* const* beh, const float* const* pup, const int* n_images, int n, int C, int IH, int IW,

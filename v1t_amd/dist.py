@@ -203,9 +203,9 @@ def describe_rank(sharding: "MouseSharding", device: t.Any) -> str:
 def init_from_env(backend: t.Optional[str] = None, timeout_s: t.Optional[float] = None) -> t.Tuple[int, int, int]:
     """(rank, local_rank, world) from torchrun's environment; initialises the process group when world > 1.
 
-    `timeout_s` (default: V1T_DIST_TIMEOUT_S or 300 s) bounds the rendezvous and every collective: the library default (10 min for
-    RCCL, 30 min for gloo) would let one hung rank burn a whole benchmark budget before anything fails; 300 s still covers ranks whose
-    first `import torch` on a fresh box differs by minutes."""
+    `timeout_s` bounds the rendezvous and every collective. Default: V1T_DIST_TIMEOUT_S when set, else torch's own (10 min for RCCL, 30 min
+    for gloo) - a training run may legitimately let ranks drift apart for minutes (rank-0-only validation or checkpointing, a first-step
+    build). `bench.py` passes 300 s: one hung rank must not burn a benchmark budget before anything fails."""
     import datetime
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -218,7 +218,8 @@ def init_from_env(backend: t.Optional[str] = None, timeout_s: t.Optional[float] 
             backend = os.environ.get("V1T_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-        if timeout_s is None:
-            timeout_s = float(os.environ.get("V1T_DIST_TIMEOUT_S", "300"))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+        if timeout_s is None and os.environ.get("V1T_DIST_TIMEOUT_S"):
+            timeout_s = float(os.environ["V1T_DIST_TIMEOUT_S"])
+        kw = {} if timeout_s is None else {"timeout": datetime.timedelta(seconds=timeout_s)}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world

@@ -84,6 +84,8 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_vit_backward_events": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_ll, c_int, c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "v1t_dropout_mask": (c_int, [c_u64, c_u32, c_float, c_ll, c_ll, c_void_p, c_void_p]),
     "v1t_attention_dropout_rate": (c_float, [c_float]),
+    "v1t_vit_scratch_bytes_input": (c_ll, [c_void_p, c_int]),
+    "v1t_vit_backward_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_ll, c_int, c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "v1t_vit_backward_second_stream": (c_int, [c_void_p, c_int]),
     "v1t_gaussian2d_forward": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "v1t_gaussian2d_backward": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -94,6 +96,7 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_metrics_group_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "v1t_crop_nearest": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "v1t_resize_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "v1t_resize_bilinear_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "v1t_gaussian2d_backward_ws_bytes": (c_ll, [c_int, c_int, c_int, c_int]),
     "v1t_gaussian2d_backward_ws": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     "v1t_gaussian2d_backward_parts": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),

@@ -145,6 +145,9 @@ def _crop_nearest(inputs: torch.Tensor, grid: torch.Tensor, shifts: t.Optional[t
     gather kernel. Nearest sampling has no gradient w.r.t. the grid (the reference's shifter receives exact zeros
     through it), so the result is a constant of the graph: the ImageShifter learns from its L1 term only."""
     L.require_cuda(inputs, "ImageCropper")
+    if inputs.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("ImageCropper: the gradient with respect to the raw image through the nearest-neighbour crop has no gfx950 kernel "
+                                  "(center_crop < 1 or shift_mode 1 / 3 / 4); differentiate with respect to the core input instead")
     src = inputs.detach().to(torch.float32).contiguous()
     b, c, ih, iw = src.shape
     oh, ow = grid.shape[1], grid.shape[2]
@@ -153,6 +156,27 @@ def _crop_nearest(inputs: torch.Tensor, grid: torch.Tensor, shifts: t.Optional[t
     L.check(L.load().v1t_crop_nearest(src.data_ptr(), b, c, ih, iw, grid.data_ptr(), None if sh is None else sh.data_ptr(), out.data_ptr(), oh, ow,
                                       L.stream()), "crop_nearest")
     return out
+
+
+class _ResizeFn(torch.autograd.Function):
+    """torchvision Resize(antialias=False) of the cropper (image_cropper.py:96-99, 134-135) as one kernel each way; the backward is the
+    adjoint the reference gets from autograd of F.interpolate (d response / d raw image: MEIs, saliency)."""
+
+    @staticmethod
+    def forward(ctx, src: torch.Tensor, oh: int, ow: int):
+        b, c, ih, iw = src.shape
+        out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=src.device)
+        L.check(L.load().v1t_resize_bilinear(src.data_ptr(), b * c, ih, iw, out.data_ptr(), oh, ow, L.stream()), "resize_bilinear")
+        ctx.shape = (b, c, ih, iw, oh, ow)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, c, ih, iw, oh, ow = ctx.shape
+        g = g.to(torch.float32).contiguous()
+        din = torch.empty((b, c, ih, iw), dtype=torch.float32, device=g.device)
+        L.check(L.load().v1t_resize_bilinear_backward(g.data_ptr(), b * c, ih, iw, din.data_ptr(), oh, ow, L.stream()), "resize_bilinear_backward")
+        return din, None, None
 
 
 class ImageCropper(nn.Module):
@@ -204,10 +228,7 @@ class ImageCropper(nn.Module):
         if self.resize is not None:
             src = outputs.to(torch.float32).contiguous()
             L.require_cuda(src, "ImageCropper")
-            b, c, ih, iw = src.shape
-            outputs = torch.empty((b, c, *self.resize), dtype=torch.float32, device=src.device)
-            L.check(L.load().v1t_resize_bilinear(src.data_ptr(), b * c, ih, iw, outputs.data_ptr(), self.resize[0], self.resize[1], L.stream()),
-                    "resize_bilinear")
+            outputs = _ResizeFn.apply(src, int(self.resize[0]), int(self.resize[1]))
         if self.behavior_mode == 1:
             h, w = outputs.size(2), outputs.size(3)
             outputs = torch.concat((outputs, behaviors[:, :, None, None].expand(-1, -1, h, w)), dim=1)

@@ -84,7 +84,6 @@ class FusedAdamW:
             ca = core._arena
             self._adopt_grads(ca)
             self.step_arena(ca, [(0, ca.param_floats, 0.0, self.group_lr("core"))], zero_grad=True)
-            ca._clean = True
             core.mark_updated()
         items = []
         for m in model.readouts.keys():
@@ -97,21 +96,20 @@ class FusedAdamW:
             a.attach_grads()
             self._adopt_grads(a)
             items.append((a, [(o, n, 0.0, self.group_lr(g)) for o, n, _, g in mouse_step_ranges(model, m)]))
-            a._clean = True
         self.step_arenas(items, zero_grad=True)
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         """torch.optim.Optimizer.zero_grad over the arenas. Every parameter's .grad stays (or becomes) the view of its gradient arena - the
-        backward kernels accumulate straight into it - and an arena is zero-filled only when `step` has not just zeroed it in its kernel.
+        backward kernels accumulate straight into it - and every arena is zero-filled, ALSO when `step` has just zeroed it in its kernel:
+        a backward that ran between `step()` and this call (an auxiliary loss, a discarded backward after a skipped GradScaler step) must
+        not leak into the next step (torch.optim semantics; ADVICE r05 - eight fills of 5-10 MB, ~0.2 % of a step).
         `set_to_none` is accepted for signature compatibility; a mouse that is not visited is skipped by `step` through the readout's mark,
         which is what `None` gradients achieve in torch.optim."""
         model = self.model
         arenas = [model.core._arena] + [mouse_arena(model, m) for m in model.readouts.keys()]
         for a in arenas:
             a.ensure()
-            if not getattr(a, "_clean", False):
-                a.grad.zero_()
-            a._clean = False
+            a.grad.zero_()
             first = next((s for s in a.slots if s.is_param and s.tensor.requires_grad), None)
             if first is not None and (first.tensor.grad is None or first.tensor.grad.data_ptr() != a.grad.data_ptr() + 4 * first.offset):
                 a.attach_grads(force=True)
