@@ -478,6 +478,12 @@ def main():
                     "rank 0 prints how many ranks the group's all-reduce saw")
     a = ap.parse_args()
 
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0 and "V1T_LIB" not in os.environ:
+        # the library must be the tree's (content hash, v1t_amd/build.py); a no-op when it is, a rebuild (hipcc, before anything touches the
+        # GPU) when the snapshot carried a stale one. Other local ranks find it current or fail loudly in lib.load().
+        from v1t_amd.build import build as _build
+
+        _build(force=False, verbose=False)
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         # started without torchrun: become the launcher BEFORE anything touches the GPU (a process that has initialised HIP is
         # never re-executed; the ranks are fresh children)

@@ -147,6 +147,14 @@ def load() -> C.CDLL:
             f"v1t_amd: HIP library {LIB_PATH} not found — build it with `python -m v1t_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    if "V1T_LIB" not in os.environ and not os.environ.get("V1T_ALLOW_STALE_LIB"):
+        # the git-ignored .so travels with the repo snapshot: refuse one that was built from other sources than the tree holds (content
+        # hash over every .hip / .h and the flags, v1t_amd/build.py) instead of silently testing / timing old kernels
+        from . import build as _b
+
+        if not _b.is_current(LIB_PATH):
+            raise RuntimeError(f"v1t_amd: {LIB_PATH} was built from other sources than the tree holds (built {_b.buildinfo(LIB_PATH).get('sources_sha16')}, "
+                               f"tree {_b.sources_sha16()}): run `python -m v1t_amd.build`. There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
