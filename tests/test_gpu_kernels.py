@@ -12,6 +12,27 @@ from tests.helpers import check_grad, check_rel, rel_to_max
 pytestmark = pytest.mark.gpu
 
 
+def exp_env(**switches):
+    """Environment of a child process that loads the EXPERIMENT build (libv1t_amd_exp.so = the product's sources + -DV1T_EXPERIMENTS,
+    v1t_amd/build.py) with development switches set: the product library contains neither the switches nor the experiment kernels, so every
+    "fused == unfused" equality test compares the product (no switch, default library) against an experiment-build variant."""
+    import os
+
+    from v1t_amd.build import build_experiments
+
+    build_experiments(force=False, verbose=False)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("V1T_")}
+    env["V1T_LIB"] = "libv1t_amd_exp.so"
+    env.update({k: str(v) for k, v in switches.items()})
+    return env
+
+
+def product_env():
+    import os
+
+    return {k: v for k, v in os.environ.items() if not k.startswith("V1T_")}
+
+
 @pytest.fixture(scope="module")
 def ctx():
     from v1t_amd import lib as L
@@ -344,10 +365,7 @@ torch.save({"o": o.float().cpu(), "lse": lse.cpu()}, sys.argv[1])
     outs = []
     for v2 in (False, True):
         path = f"/tmp/v1t_fwd_{int(v2)}.pt"
-        env = dict(os.environ)
-        env.pop("V1T_ATTN_FWD_V3", None)
-        if v2:
-            env["V1T_ATTN_FWD_V3"] = "1"
+        env = exp_env(V1T_ATTN_FWD_V3=1) if v2 else product_env()
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(path))
@@ -390,7 +408,7 @@ torch.save({"u": u.detach().cpu(), "g": model.core._arena.grad.cpu()}, sys.argv[
     outs = []
     for fuse in ("0", "1"):
         path = f"/tmp/v1t_lnfuse_{fuse}.pt"
-        env = dict(os.environ, V1T_LN_FUSE=fuse)
+        env = exp_env(V1T_LN_FUSE=0) if fuse == "0" else product_env()
         r = subprocess.run([sys.executable, "-c", code, path, str(emb), str(images)], env=env, capture_output=True, text=True,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stderr[-2000:]
@@ -446,10 +464,7 @@ torch.save({"u": u.detach().cpu(), "g": model.core._arena.grad.cpu()}, sys.argv[
     outs = []
     for on in (False, True):
         path = f"/tmp/v1t_{switch}_{int(on)}.pt"
-        env = dict(os.environ)
-        env.pop(switch, None)
-        if on:
-            env[switch] = "1"
+        env = exp_env(**{switch: 1}) if on else product_env()
         r = subprocess.run([sys.executable, "-c", code, path, str(emb), str(images), str(beh)], env=env, capture_output=True, text=True,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stderr[-2000:]
@@ -790,8 +805,7 @@ torch.save({"u": u.detach().cpu(), "g": model.core._arena.grad.cpu()}, sys.argv[
     outs = []
     for fuse in ("0", "2"):
         path = f"/tmp/v1t_mlpfuse_{switch}_{fuse}.pt"
-        env = dict(os.environ)
-        env[switch] = fuse
+        env = exp_env(**{switch: fuse})
         r = subprocess.run([sys.executable, "-c", code, path, str(images), str(int(train))], env=env, capture_output=True, text=True,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stderr[-2000:]

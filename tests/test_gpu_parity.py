@@ -175,11 +175,16 @@ def test_input_gradient_vs_reference_golden(golden, dev, name):
 
     dx, grads = run(True)
     _, grads0 = run(False)
+    _, grads1 = run(False)
     ref = golden[f"{name}/input_grad"]
     assert dx is not None and tuple(dx.shape) == ref.shape and bool(torch.isfinite(dx).all())
     check_grad(f"input gradient [{name}]", dx.cpu().numpy(), ref, G_TOL)
-    for k in grads0:  # the same launches in the same order: only float-atomic order may differ
-        check_rel_bulk(f"input gradient [{name}]: parameter gradient {k} unchanged", grads[k], grads0[k], 1e-4, 1e-3)
+    for k in grads0:
+        # the same launches in the same order: only float-atomic order may differ (the readout's dz gather; a bf16 rounding flip downstream of
+        # it moves a row of a weight gradient). The run-to-run noise of two IDENTICAL backward passes is the yardstick: 1e-4 in the flat regime,
+        # up to ~6e-4 with the outlier channels of the trained-weights regime (g14)
+        noise = rel_to_max(grads1[k], grads0[k])
+        check_rel_bulk(f"input gradient [{name}]: parameter gradient {k} unchanged", grads[k], grads0[k], max(1e-4, 4 * noise), max(1e-3, 8 * noise))
 
 
 def test_amp_autocast_and_gradscaler_over_native_modules(dev):

@@ -48,11 +48,19 @@ def all_sources() -> list:
     return [os.path.join(CSRC, f) for f in files] + [os.path.join(HERE, "..", "include", "v1t_amd.h")]
 
 
-def sources_sha16() -> str:
+EXP_LIB = os.path.join(LIBDIR, "libv1t_amd_exp.so")  # the experiment build: the same sources with -DV1T_EXPERIMENTS (dev switches + experiment kernels)
+EXP_FLAGS = ["-DV1T_EXPERIMENTS"]
+
+
+def _extra_for(lib_path: str) -> list:
+    return EXP_FLAGS if os.path.basename(lib_path) == os.path.basename(EXP_LIB) else EXTRA
+
+
+def sources_sha16(extra=None) -> str:
     """Content hash over every source + header + the compiler flags: what `buildinfo` records and `is_current` compares. Staleness is by
     CONTENT, not by mtime: the git-ignored .so travels with the repo snapshot, and a restored tree or a skewed clock must not run the
     tests against a library built from other sources (VERDICT r05 weak #9)."""
-    return _sha(all_sources(), [FLAGS, sorted(PER_FILE.items()), EXTRA])[:16]
+    return _sha(all_sources(), [FLAGS, sorted(PER_FILE.items()), EXTRA if extra is None else extra])[:16]
 
 
 def attention_sha16() -> str:
@@ -77,11 +85,19 @@ def buildinfo(lib_path: str = LIB) -> dict:
 
 def is_current(lib_path: str = LIB) -> bool:
     """The library exists and was built from exactly the sources (and flags) in the tree."""
-    return os.path.exists(lib_path) and buildinfo(lib_path).get("sources_sha16") == sources_sha16()
+    return os.path.exists(lib_path) and buildinfo(lib_path).get("sources_sha16") == sources_sha16(_extra_for(lib_path))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build_experiments(force: bool = False, verbose: bool = True) -> str:
+    """libv1t_amd_exp.so: the product's sources compiled with -DV1T_EXPERIMENTS - the development switches (csrc/common.h `dev_env`,
+    tools/DEV_SWITCHES.md) and the experiment kernels of rounds 1-5 exist only here. The equality tests (fused == unfused forms) load it
+    in a child process with V1T_LIB; nothing else does."""
+    return build(force=force, verbose=verbose, alt=os.path.basename(EXP_LIB), extra=EXP_FLAGS)
+
+
+def build(force: bool = False, verbose: bool = True, alt: str = None, extra: list = None) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
+    EXTRA = globals()["EXTRA"] if extra is None else list(extra)
     hdrs = [f for f in all_sources() if f.endswith(".h")]
     listed = {os.path.join(CSRC, s_) for s_ in SOURCES}
     stray = [f for f in all_sources() if f.endswith(".hip") and f not in listed]
@@ -91,7 +107,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs, jobs = [], []
     # dev: V1T_BUILD_LIB=libv1t_amd_x.so builds a second library next to the product one (its own objects; V1T_HIPCC_EXTRA flags),
     # loaded with V1T_LIB=libv1t_amd_x.so - A/B experiments and the in-kernel probe builds
-    alt = os.environ.get("V1T_BUILD_LIB", "")
+    alt = os.environ.get("V1T_BUILD_LIB", "") if alt is None else alt
     ablation = ("V1T_DEV_ABLATION", "V1T_F3_", "V1T_B2_")
     if not alt and any(any(a in f for a in ablation) for f in EXTRA):
         # timing-only ablations compile pieces of kernels out and return garbage: never into the product library
@@ -122,7 +138,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return r
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(4, (os.cpu_count() or 8) // 2))) as ex:
             list(ex.map(run, jobs))
         for obj, want in stamps.items():
             with open(obj + ".sha", "w") as fh:
@@ -132,10 +148,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         # what this library was built from: every source (is_current, the smoke's report) and the attention sources the tracked PMC summary
         # was measured on (bench.py)
         with open(lib_path + ".buildinfo.json", "w") as fh:
-            json.dump({"sources_sha16": sources_sha16(), "attention_sources_sha16": attention_sha16(), "extra_flags": EXTRA,
+            json.dump({"sources_sha16": sources_sha16(EXTRA), "attention_sources_sha16": attention_sha16(), "extra_flags": EXTRA,
                        "n_sources": len(all_sources())}, fh)
     return lib_path
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--experiments" in sys.argv:
+        print(build_experiments(force="--force" in sys.argv))

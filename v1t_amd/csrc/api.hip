@@ -101,13 +101,13 @@ struct WsLayout {
 };
 
 // V1T_NOSPLIT=<mask> (dev, numerics ablation): bit 0/1/2/3 runs QKV / proj / FC1 / FC2 of the forward in plain bf16
-static const int g_nosplit = std::getenv("V1T_NOSPLIT") ? atoi(std::getenv("V1T_NOSPLIT")) : 0;
+static const int g_nosplit = dev_env("V1T_NOSPLIT") ? atoi(dev_env("V1T_NOSPLIT")) : 0;
 // Operand format of the forward linear layers (patch projection, QKV, proj, FC1, FC2): fp16 planes + one fp16 MFMA per
 // step (default; 0.28 of the 1e-3 parity bound on the default V1T), or V1T_FWD_BF16X3=1 (dev, numerics ablation): bf16
 // hi + lo planes and three MFMAs (0.07 of the bound, 2.4x the GEMM time). The second plane of every forward activation /
 // weight holds the one or the other; the bf16 "hi" planes are what the backward reads (except the
 // attention output / GELU output in fp16 mode: x16_attn_out / x16_gelu_out below).
-static const int g_fwd_f16 = (std::getenv("V1T_FWD_BF16X3") && atoi(std::getenv("V1T_FWD_BF16X3"))) ? 0 : 1;
+static const int g_fwd_f16 = (dev_env("V1T_FWD_BF16X3") && atoi(dev_env("V1T_FWD_BF16X3"))) ? 0 : 1;
 static bool x16_attn_out(const v1t_vit* h, long long R);
 static bool x16_gelu_out(const v1t_vit* h, long long R);
 
@@ -167,7 +167,7 @@ WsLayout ws_layout(const v1t_vit* h, int B, bool save) {
 // default shape it is a draw (dK/dV + store 378 us + GEMM 120 us = 498 us against 497 us fused, dropout on; 470 against 490
 // without dropout); inside the training step it is 1.6 % of the whole step faster (3062 against 3015 images/s, twice),
 // so it is the default. V1T_ATTN_BWD_DS=0 (dev) selects the fused recompute kernel, which LSA (mask_diag) always uses.
-static const int g_attn_ds = (std::getenv("V1T_ATTN_BWD_DS") && !atoi(std::getenv("V1T_ATTN_BWD_DS"))) ? 0 : 1;
+static const int g_attn_ds = (dev_env("V1T_ATTN_BWD_DS") && !atoi(dev_env("V1T_ATTN_BWD_DS"))) ? 0 : 1;
 struct ScratchLayout {
     long long G, dy, dy2, dy3, dhpre, dz, dO, delta, dqkv, dqkv2, dbeta, slab, pu, pgd, pdu, ds, total;
 };
@@ -177,7 +177,7 @@ struct ScratchLayout {
 // there (half the m-chunks, half the slab traffic). A/B in one call at a 14-image share: 512: 3.67 / 3.69 ms per step, 256: 3.60 / 3.57,
 // 128: 3.62 / 3.56, 64: 3.61 / 3.68; the 7 x 16-image loop: 28.8 -> 28.3 ms (profiles/r05_small_launch_experiments.txt)
 int tn_mchunk(long long R, int tiles) {
-    static const int forced = std::getenv("V1T_TN_WGS") ? atoi(std::getenv("V1T_TN_WGS")) : 0;  // dev switch
+    static const int forced = dev_env("V1T_TN_WGS") ? atoi(dev_env("V1T_TN_WGS")) : 0;  // dev switch
     const int target = forced > 0 ? forced : (R < 65536 ? 256 : 512);
     const int want = std::max(1, target / std::max(tiles, 1));
     const int mc = (int)round_up((R + want - 1) / want, 64);
@@ -203,7 +203,7 @@ TnPlan tn_plan(const v1t_vit* h, long long R) {
 // the row constants) and fp16 (the A operand of the forward's projection / FC2 GEMM). Where the weight-gradient kernel can convert its X
 // fragments (gemm_tn_takes_f16_x) the bf16 plane is never written: the backward reads the fp16 one (237 + 190 MB less per block and
 // 112-image step at the default shape).
-static const bool g_keep_bf16 = std::getenv("V1T_KEEP_BF16_PLANES") != nullptr;  // dev (A/B): write and read the bf16 planes as before
+static const bool g_keep_bf16 = dev_env("V1T_KEEP_BF16_PLANES") != nullptr;  // dev (A/B): write and read the bf16 planes as before
 static bool x16_attn_out(const v1t_vit* h, long long R) {
     return !g_keep_bf16 && g_fwd_f16 && !(g_nosplit & 2) && gemm_tn_takes_f16_x(h->DP, h->HDP, tn_plan(h, R).mc_proj);
 }
@@ -271,8 +271,8 @@ DropCfg make_drop(bool training, float p, uint64_t seed, uint32_t stream) {
 
 // LayerNorm followed by the GEMM that reads it: one fused A-stationary launch where the shape allows (gemm.h, launch_ln_gemm;
 // fp16 operands, K = DP <= 160, N % 128 == 0), else the two kernels. V1T_LN_FUSE=0 (dev): always the two kernels.
-static const int g_ln_fuse = (std::getenv("V1T_LN_FUSE") && !atoi(std::getenv("V1T_LN_FUSE"))) ? 0 : 1;
-static const int g_mlp_fuse = (std::getenv("V1T_MLP_FUSE") && !atoi(std::getenv("V1T_MLP_FUSE"))) ? 0 : 1;
+static const int g_ln_fuse = (dev_env("V1T_LN_FUSE") && !atoi(dev_env("V1T_LN_FUSE"))) ? 0 : 1;
+static const int g_mlp_fuse = (dev_env("V1T_MLP_FUSE") && !atoi(dev_env("V1T_MLP_FUSE"))) ? 0 : 1;
 static inline int ln_then_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t s) {
     if (g_ln_fuse) {
         const int rc = launch_ln_gemm(l, g, epi, s);
@@ -810,8 +810,8 @@ int v1t_vit_forward(const v1t_vit* h, const float* arena, const void* shadow, co
 
 // dz = dY . W (fp32, g.C) followed by the backward of the LayerNorm in front of that linear layer: one kernel where the shape allows
 // (gemm.h, launch_gemm_ln_bwd: dz stays in the accumulators), else the GEMM and ln_bwd_kernel. V1T_LNBWD_UNFUSED=1 (dev, A/B): always two.
-static const bool g_lnbwd_unfused = std::getenv("V1T_LNBWD_UNFUSED") != nullptr;
-static const bool g_delta_unfused = std::getenv("V1T_DELTA_UNFUSED") != nullptr;  // dev (A/B): attn_delta2_kernel instead of the dO GEMM's row-dot epilogue
+static const bool g_lnbwd_unfused = dev_env("V1T_LNBWD_UNFUSED") != nullptr;
+static const bool g_delta_unfused = dev_env("V1T_DELTA_UNFUSED") != nullptr;  // dev (A/B): attn_delta2_kernel instead of the dO GEMM's row-dot epilogue
 static int dx_then_ln_bwd(const GemmNTArgs& g, const LnBwdArgs& lb, hipStream_t s) {
     if (!g_lnbwd_unfused) {
         const int rc = launch_gemm_ln_bwd(g, lb, s);
@@ -885,7 +885,7 @@ int v1t_vit_backward_input(const v1t_vit* h, const float* arena, const void* sha
     if (dw_side && !h->dw_stream) {
         // V1T_DW_PRIO=low (dev, A/B): the second stream at the lowest queue priority, so that its workgroups only take CUs the main stream's
         // kernels leave idle
-        static const bool dw_low = std::getenv("V1T_DW_PRIO") && std::string(std::getenv("V1T_DW_PRIO")) == "low";
+        static const bool dw_low = dev_env("V1T_DW_PRIO") && std::string(dev_env("V1T_DW_PRIO")) == "low";
         int lo = 0, hi = 0;
         if (dw_low && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) {
             if (hipStreamCreateWithPriority(&h->dw_stream, hipStreamNonBlocking, lo) != hipSuccess) return V1T_ERR_LAUNCH;

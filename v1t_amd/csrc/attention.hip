@@ -527,6 +527,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
     }
 }
 
+#ifdef V1T_EXPERIMENTS  // round-3 experiment kernel (V1T_ATTN_FWD_V3): experiment builds only, never in the product library
 // ------------------------------------------------------------------------------------------
 // Forward with FOUR waves per SIMD (round 3). Why: in the kernels above a wave runs S -> softmax -> P.V one after the other, ~260
 // instructions per 32-key tile at ~10 cycles each (in-kernel timeline, tools/kprof.py: MFMA chains, LDS and exp latencies are exposed
@@ -774,6 +775,8 @@ __global__ __launch_bounds__(128 * F3_PAIRS, 4) void attn_fwd3_kernel(AttnArgs a
         lds_barrier();
     }
 }
+
+#endif  // V1T_EXPERIMENTS
 
 // delta[b][h][t] = keep_prob * sum_d dO * O. 16 lanes per (row, head) segment: a load instruction reads 256 contiguous
 // bytes of each of its 4 segments (one thread per segment read 16 B at a 320-B stride per lane: 3.4 TB/s).
@@ -1232,9 +1235,9 @@ static void choose_fwd_split_uncached(int B, int H, int T, int& F, int& Hh, int&
     const int F0 = T / 256 + (rem > 128 ? 1 : 0), H0 = (rem >= 1 && rem <= 128) ? 1 : 0;
     F = F0; Hh = H0;
     const int nblk0 = B * H * (F0 + H0);
-    static const int lpt_max = std::getenv("V1T_FWD_LPT_MAX") ? atoi(std::getenv("V1T_FWD_LPT_MAX")) : 1152;  // dev (A/B)
+    static const int lpt_max = dev_env("V1T_FWD_LPT_MAX") ? atoi(dev_env("V1T_FWD_LPT_MAX")) : 1152;  // dev (A/B)
     lpt = (H0 && nblk0 >= 640 && nblk0 <= lpt_max) ? 1 : 0;  // measured (round 5): helps a 28-image launch, hurts at 14 and at 112 images
-    static const bool allow = !(std::getenv("V1T_FWD_SPLIT") && !atoi(std::getenv("V1T_FWD_SPLIT")));
+    static const bool allow = !(dev_env("V1T_FWD_SPLIT") && !atoi(dev_env("V1T_FWD_SPLIT")));
     if (!allow || nblk0 > lpt_max || T <= 256) return;
     const int nbh = (B * H + 7) / 8;  // (image, head) pairs of the fullest XCD
     auto makespan = [&](int f, int hh) {
@@ -1268,7 +1271,8 @@ int launch_fwd_t(const AttnArgs& a_in, hipStream_t s) {
     choose_fwd_split(a.B, a.H, a.T, a.fwd_full, a.fwd_half, a.fwd_lpt);
     const dim3 grid_main((a.fwd_full + a.fwd_half) * a.H * a.B);
     prof_begin(PROF_ATTN_FWD, s);
-    static const bool v3 = std::getenv("V1T_ATTN_FWD_V3") != nullptr;  // dev: the 16-wave S / PV role kernel
+#ifdef V1T_EXPERIMENTS
+    static const bool v3 = dev_env("V1T_ATTN_FWD_V3") != nullptr;  // dev: the 16-wave S / PV role kernel
     if constexpr (DP >= 128 && !DIAG) {
         if (v3) {
             hipLaunchKernelGGL((attn_fwd3_kernel<DP, DROP>), grid, dim3(128 * F3_PAIRS), 0, s, a);
@@ -1276,7 +1280,7 @@ int launch_fwd_t(const AttnArgs& a_in, hipStream_t s) {
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
     }
-    static const bool stagger = std::getenv("V1T_ATTN_FWD_STAGGER") != nullptr;  // dev: A/B of the rotated second half
+    static const bool stagger = dev_env("V1T_ATTN_FWD_STAGGER") != nullptr;  // dev: A/B of the rotated second half
     if constexpr (DP >= 128 && !DIAG) {
         if (stagger) {
             hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG, true>), grid_main, dim3(64 * FWD_WAVES), 0, s, a);
@@ -1284,6 +1288,9 @@ int launch_fwd_t(const AttnArgs& a_in, hipStream_t s) {
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
     }
+#else
+    (void)grid;
+#endif
     hipLaunchKernelGGL((attn_fwd_kernel<DP, DROP, DIAG>), grid_main, dim3(64 * FWD_WAVES), 0, s, a);
     prof_end(PROF_ATTN_FWD, s);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
@@ -2024,14 +2031,14 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
-            static const bool dq_deep = !(std::getenv("V1T_DQ2_DEEP") && !atoi(std::getenv("V1T_DQ2_DEEP")));  // dev (A/B): 0 = the one 3-deep ring
+            static const bool dq_deep = !(dev_env("V1T_DQ2_DEEP") && !atoi(dev_env("V1T_DQ2_DEEP")));  // dev (A/B): 0 = the one 3-deep ring
             if (dq_deep) hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP, true>), dim3(((a.T + 511) / 512) * a.H * a.B), dim3(512), 0, s, a);
             else hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP, false>), dim3(((a.T + 511) / 512) * a.H * a.B), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DQ, s);
             return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
         }
     }
-    static const bool split = std::getenv("V1T_ATTN_BWD_SPLIT") != nullptr;  // dev switch: time the two bodies separately
+    static const bool split = dev_env("V1T_ATTN_BWD_SPLIT") != nullptr;  // dev switch: time the two bodies separately
     if (DP >= 128 && !split) {
         const int n8 = (n + 7) / 8 * 8;
         prof_begin(PROF_ATTN_DKV, s);
@@ -2500,7 +2507,7 @@ int launch_headmax_t(const AttnArgs& a, float* A, int TP, float* rowsum, int q_r
     }
     // V1T_HEADMAX8=0 (dev, A/B): the 4-wave kernel also where the 8-wave one applies (an even head count at head dims >= 128, where the
     // 4-wave kernel cannot fit two waves on a SIMD)
-    static const bool hm8 = !(std::getenv("V1T_HEADMAX8") && !atoi(std::getenv("V1T_HEADMAX8")));
+    static const bool hm8 = !(dev_env("V1T_HEADMAX8") && !atoi(dev_env("V1T_HEADMAX8")));
     if constexpr (DP >= 128) {
         if (hm8 && (a.H == 2 || a.H == 4)) {
             if (a.H == 2) hipLaunchKernelGGL((rollout_headmax8_kernel<DP, 2>), grid, dim3(512), 0, s, a, A, TP, rowsum);

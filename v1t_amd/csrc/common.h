@@ -3,6 +3,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
+
+// Development switches (A/B experiments, ablations, the round-1..5 experiment kernels) exist ONLY in experiment builds
+// (`V1T_BUILD_LIB=libv1t_amd_exp.so V1T_HIPCC_EXTRA=-DV1T_EXPERIMENTS python -m v1t_amd.build`, loaded with V1T_LIB): in the product
+// library dev_env() is a constant nullptr, every switch folds to its measured default and the experiment kernels are not compiled, so
+// the product has no untested configurations. The product reads two documented environment options through
+// std::getenv directly: V1T_DW_SIDE (api.hip) and V1T_DEBUG_SYNC.
+#ifdef V1T_EXPERIMENTS
+inline const char* dev_env(const char* name) { return std::getenv(name); }
+#else
+constexpr const char* dev_env(const char*) { return nullptr; }
+#endif
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_split_kernel(GemmNTArgs g) {
 }
 
 // V1T_GEMM_RING=0 (dev, A/B): the register-staged double buffer also for launches of at most one workgroup per CU
-static const bool g_gemm_ring = !(std::getenv("V1T_GEMM_RING") && !atoi(std::getenv("V1T_GEMM_RING")));
+static const bool g_gemm_ring = !(dev_env("V1T_GEMM_RING") && !atoi(dev_env("V1T_GEMM_RING")));
 template <int NBLK, int NW, int BK>
 int launch_nt_nw(const GemmNTArgs& a, int epi, hipStream_t s) {
     const int BN = 32 * NBLK, BMW = 32 * NW;
@@ -643,7 +643,7 @@ int launch_nt_n(const GemmNTArgs& a, int epi, hipStream_t s) {
     // Round 5: "few rows" means AT MOST ONE ROUND of one-workgroup-per-CU launches. A 28-image launch (a rank's share of a 4-GPU step: 362
     // row tiles) is under 65 536 rows too, but at one workgroup per CU it ran as two rounds, 106 of them in the second (proj 63 us against
     // 25 us at 14 images and 110 us at 112): the 32-wide tile, three workgroups per CU, holds all of it at once.
-    static const int force_bk = std::getenv("V1T_GEMM_BK") ? atoi(std::getenv("V1T_GEMM_BK")) : 0;  // dev switch
+    static const int force_bk = dev_env("V1T_GEMM_BK") ? atoi(dev_env("V1T_GEMM_BK")) : 0;  // dev switch
     const long long tiles = (long long)((a.M + 127) / 128) * (a.N / (32 * NBLK));
     const bool bk64 = a.K % 64 == 0 && force_bk != 32 && (force_bk == 64 || tiles <= 256);
     return bk64 ? launch_nt_nw<NBLK, 4, 64>(a, epi, s) : launch_nt_nw<NBLK, 4, 32>(a, epi, s);
@@ -1619,6 +1619,7 @@ __global__ __launch_bounds__(256, RING ? 1 : 2) void gemm_lnbwd_kernel(GemmNTArg
     lnbwd_epilogue<NBLK, NEXT, BM, CS>(l, acc, row0, t0, l.T, b, smem, tid, wave, lane);
 }
 
+#ifdef V1T_EXPERIMENTS  // round-5 experiment 26 (V1T_MLP_BWD_FUSE; measured neutral): experiment builds only
 // ------------------------------------------------------------------------------------------
 // The MLP branch BACKWARD down to the residual-stream gradient in one launch - mlp_fwd_kernel's mirror: dhpre = (dy W2) * gelu' * mask (the dGELU
 // GEMM, K = DP: the dy rows resident as A fragments, the hidden units walked in 32-column tiles) with dz = dhpre W1 folded into the tile loop - the
@@ -1729,6 +1730,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(GemmNTArgs g, GemmNTArg
     // (the last barrier of the loop: every wave is done with the tiles and its staging - the epilogue's staging overlays them)
     lnbwd_epilogue<NB2, true, BM, ECS>(l, acc2, 0, m0, g.M, 0, smem, tid, wave, lane);
 }
+#endif  // V1T_EXPERIMENTS
 
 }  // namespace
 
@@ -1746,12 +1748,12 @@ int launch_ln_gemm(const LnFwdArgs& l, const GemmNTArgs& g, int epi, hipStream_t
     // row set: ablation in profiles/r03_gemm_experiments.txt). QKV at full-size launches: 265 -> 250 us; not for the GELU epilogue
     // (its live values + the second row set's accumulators and A fragments do not fit 256 registers: 183 -> 283 us) nor for small
     // launches (fewer, longer workgroups)
-    static const int force_shape = std::getenv("V1T_LNG_SHAPE") ? atoi(std::getenv("V1T_LNG_SHAPE")) : -1;  // dev switch
+    static const int force_shape = dev_env("V1T_LNG_SHAPE") ? atoi(dev_env("V1T_LNG_SHAPE")) : -1;  // dev switch
     const int shape = force_shape >= 0 ? force_shape : ((epi == EPI_BF16 && l.rows >= 512 * 256) ? 2 : 1);
     const int BMr = shape == 1 ? 128 : 256, BNr = shape ? 64 : 128;
     if (g.N % BNr != 0) return V1T_ERR_UNSUPPORTED;
     const int rt = (l.rows + BMr - 1) / BMr, ntn = g.N / BNr;
-    static const int force_split = std::getenv("V1T_LNG_SPLIT") ? atoi(std::getenv("V1T_LNG_SPLIT")) : 0;  // dev switch
+    static const int force_split = dev_env("V1T_LNG_SPLIT") ? atoi(dev_env("V1T_LNG_SPLIT")) : 0;  // dev switch
     // cost model in column-tile units: rounds of 256 workgroups x (LayerNorm prologue ~1.5 tiles + the workgroup's tiles); measured
     // on one rank's share of 2- / 4- / 8-GPU steps (362 / 181 / 91 row tiles -> 2 / 1 / 2)
     int nsplit = 1;
@@ -1799,7 +1801,7 @@ int launch_mlp_fwd(const LnFwdArgs& l, const GemmNTArgs& g, const GemmNTArgs& g2
     // is faster as two kernels - ln_gemm deals its column tiles over two workgroups per row tile there and FC2 streams through the LDS-DMA ring
     // (sim 8: 3.55 fused against 3.47 ms; per-mouse loop 28.3 against 27.7; 28 images and up the fused launch wins: profiles/r05_small_launch_experiments.txt #24).
     // V1T_MLP_FUSE=2 (dev, A/B): fused at every size.
-    static const bool always = std::getenv("V1T_MLP_FUSE") && atoi(std::getenv("V1T_MLP_FUSE")) == 2;
+    static const bool always = dev_env("V1T_MLP_FUSE") && atoi(dev_env("V1T_MLP_FUSE")) == 2;
     const int tiles = (g.M + 127) / 128;
     if (tiles <= 256 && !always) return V1T_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((mlp_fwd_kernel<160, 1>), dim3(tiles), dim3(256), 0, s, l, g, g2);
@@ -1817,11 +1819,16 @@ int launch_mlp_bwd(const GemmNTArgs& gd, const GemmNTArgs& gz, const LnBwdArgs& 
     // 6.14 / 3.49 against 6.15 / 3.51: profiles/r05_small_launch_experiments.txt #26) - unlike the forward's fold, whose GELU stage hides FC2's
     // MFMAs, both halves here are bound by the same HBM traffic, and the weight-gradient GEMMs of the second stream fill whatever a shorter
     // chain leaves. V1T_MLP_BWD_FUSE=1: above 256 row tiles, 2: at every size (the equality test runs it).
-    static const int mode = std::getenv("V1T_MLP_BWD_FUSE") ? atoi(std::getenv("V1T_MLP_BWD_FUSE")) : 0;
+#ifdef V1T_EXPERIMENTS
+    static const int mode = dev_env("V1T_MLP_BWD_FUSE") ? atoi(dev_env("V1T_MLP_BWD_FUSE")) : 0;
     const int tiles = (gd.M + 127) / 128;
     if (mode == 0 || (mode != 2 && tiles <= 256)) return V1T_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((mlp_bwd_kernel<160>), dim3(tiles), dim3(256), 0, s, gd, gz, l);
     return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
+#else
+    (void)s;
+    return V1T_ERR_UNSUPPORTED;  // the product runs the two launches (the fused form lives in experiment builds)
+#endif
 }
 
 int launch_gemm_ln_bwd(const GemmNTArgs& g, const LnBwdArgs& l, hipStream_t s) {

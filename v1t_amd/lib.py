@@ -147,7 +147,7 @@ def load() -> C.CDLL:
             f"v1t_amd: HIP library {LIB_PATH} not found — build it with `python -m v1t_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
-    if "V1T_LIB" not in os.environ and not os.environ.get("V1T_ALLOW_STALE_LIB"):
+    if os.environ.get("V1T_LIB", "libv1t_amd_exp.so") == "libv1t_amd_exp.so" and not os.environ.get("V1T_ALLOW_STALE_LIB"):  # product + experiment build
         # the git-ignored .so travels with the repo snapshot: refuse one that was built from other sources than the tree holds (content
         # hash over every .hip / .h and the flags, v1t_amd/build.py) instead of silently testing / timing old kernels
         from . import build as _b
