@@ -132,6 +132,13 @@ int v1t_vit_backward_input(const v1t_vit* h, const float* arena, const void* sha
                            const float* path_scale, const float* gout, float* grads, void* const* block_done,
                            float* dimages, void* stream);
 
+/* Optional hook for the caller's own side-stream work (the fused trainer's readout / shifter parameter gradients and the mice's AdamW,
+ * train.py:97-111, 216-223: HBM-bound and independent of the core's backward once dz exists): `event` (a hipEvent_t, or NULL to clear) is
+ * recorded on the backward's stream in front of the FIRST attention backward of every following v1t_vit_backward* call on this plan - the
+ * first MFMA-bound kernel of the backward, beside which bandwidth-bound work is nearly free, while beside the HBM-bound GEMMs in front of
+ * it, it costs its full time. NB = 0 plans never record it. */
+int v1t_vit_set_attention_backward_event(const v1t_vit* h, void* event);
+
 /* 1 when v1t_vit_backward* of `batch` images hands its weight-gradient GEMMs (dW = dY^T X of the four linear layers of a block) to a second
  * stream that runs them beside the next block's dX / attention kernels (launches under 262 144 token rows), 0 when everything runs on
  * `stream`. The gradients are complete on `stream` when the call's work is, either way. */
@@ -299,6 +306,14 @@ int v1t_gemm_tn_slab(const void* Y, int ldy, const void* X, int ldx, int M, int 
 int v1t_attention_forward(const void* qkv, int B, int H, int T, int DP, const float* scale,
                           int scale_per_head, int mask_diag, float dropout_p, uint64_t seed,
                           uint32_t stream_id, void* o, float* lse2, void* stream);
+/* the same pair over the planes the ViT core itself uses: the attention output as ONE fp16 plane (vit.py:264-265's `out`, 2^-12 instead
+ * of bf16's 2^-9), which the backward's row constants delta = rowsum(dO o O) read (kernel-level tests of the production configuration) */
+int v1t_attention_forward_f16o(const void* qkv, int B, int H, int T, int DP, const float* scale, int scale_per_head, int mask_diag,
+                               float dropout_p, uint64_t seed, uint32_t stream_id, void* o_f16, float* lse2, void* stream);
+int v1t_attention_backward_ws_f16o(const void* qkv, const void* o_f16, const void* dO, const float* lse2, int B, int H, int T, int DP,
+                                   const float* scale, int scale_per_head, int mask_diag, float dropout_p, uint64_t seed,
+                                   uint32_t stream_id, float* delta_ws, void* dqkv, float* dscale, void* ds_ws, long long ds_bytes,
+                                   void* stream);
 int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const float* lse2, int B,
                            int H, int T, int DP, const float* scale, int scale_per_head, int mask_diag,
                            float dropout_p, uint64_t seed, uint32_t stream_id, float* delta_ws,

@@ -594,10 +594,13 @@ def test_attention_backward_extreme_scores(ctx, p):
     x[:, 2] *= 1.5
     qkv = x.reshape(B * T, 3 * H * DP).to(dev).bfloat16().requires_grad_(True)
     scale = torch.tensor([DP ** -0.5], device=dev)
-    o = torch.empty(B * T, H * DP, device=dev, dtype=torch.bfloat16)
+    # the planes the ViT core uses: the attention output as ONE fp16 plane (2^-12), which the backward's delta = rowsum(dO o O) reads. (With the
+    # bf16 output of v1t_attention_forward the one-hot rows of this test - P ~ 1, dP - delta ~ 0 by cancellation - carry delta's rounding
+    # error straight into dQ: 6.5e-2 of the tensor's max, GPUTEST of round 6.)
+    o = torch.empty(B * T, H * DP, device=dev, dtype=torch.float16)
     lse = torch.empty(B, H, T, device=dev)
     seed, sid = 99, 8
-    L.check(lib.v1t_attention_forward(qkv.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid, o.data_ptr(), lse.data_ptr(), L.stream()))
+    L.check(lib.v1t_attention_forward_f16o(qkv.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid, o.data_ptr(), lse.data_ptr(), L.stream()))
     mask = None
     if p > 0:
         mask = torch.empty(B * H * T, T, device=dev, dtype=torch.uint8)
@@ -617,12 +620,17 @@ def test_attention_backward_extreme_scores(ctx, p):
     nb = int(lib.v1t_attention_backward_ws_bytes(B, H, T))
     ws = torch.full((nb,), 0xFF, dtype=torch.uint8, device=dev)
     d2 = torch.zeros_like(qkv)
-    L.check(lib.v1t_attention_backward_ws(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid,
-                                          delta.data_ptr(), d2.data_ptr(), None, ws.data_ptr(), nb, L.stream()))
+    L.check(lib.v1t_attention_backward_ws_f16o(qkv.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), B, H, T, DP, scale.data_ptr(), 0, 0, p, seed, sid,
+                                               delta.data_ptr(), d2.data_ptr(), None, ws.data_ptr(), nb, L.stream()))
     assert bool(torch.isfinite(d2.float()).all())
     gq, e = gq.view(B * T, 3, H * DP), d2.float().view(B * T, 3, H * DP)
+    errs = []
     for i, nm in enumerate("qkv"):
-        check_grad(f"extreme scores p={p}: d{nm} (dkv2 + dq2)", e[:, i].cpu(), gq[:, i].cpu(), 1.2e-2)
+        try:
+            check_grad(f"extreme scores p={p}: d{nm} (dkv2 + dq2, fp16 O plane)", e[:, i].cpu(), gq[:, i].cpu(), 1.2e-2)
+        except AssertionError as ex:  # all three tensors are measured (the margins table) before the test fails
+            errs.append(str(ex))
+    assert not errs, errs
 
 
 def test_multi_unit_entry_points_beyond_one_table(ctx):

@@ -32,14 +32,15 @@ def _noop_optimizer(tr):
     tr.opt.step_arena = lambda arena, ranges, zero_grad=True: None  # gradients stay in the arenas, parameters unchanged
 
 
-def test_c2_native_step_gradients_vs_oracle_direct(dev):
+@pytest.mark.parametrize("regime", ["flat", "sharp"])
+def test_c2_native_step_gradients_vs_oracle_direct(dev, regime):
     from v1t_amd.synthetic import make_ds
     from v1t_amd.trainer import Trainer
 
     B = 16
     cfg = W.config_c2({"A": 8000})
     cfg.p_dropout = cfg.t_dropout = 0.0
-    sd = W.make_state_dict(cfg, 1234)
+    sd = (W.make_sharp_state_dict if regime == "sharp" else W.make_state_dict)(cfg, 1234)
     batch = W.make_batch(cfg, "A", B, 4321)
     eps = W.make_eps(cfg, "A", B, 4321)
     model, args = build_native_model(cfg, sd, dev)
@@ -63,7 +64,8 @@ def test_c2_native_step_gradients_vs_oracle_direct(dev):
     finally:
         torch.set_num_threads(nthr)
     lo = float(ol)
-    record_margin("c2 direct: native-step loss vs oracle", abs(float(out["loss"]) - lo), 1e-4 * abs(lo))
+    errs = []
+    record_margin(f"c2 direct [{regime}]: native-step loss vs oracle", abs(float(out["loss"]) - lo), 1e-4 * abs(lo))
     assert abs(float(out["loss"]) - lo) <= 1e-4 * abs(lo)
     n = 0
     for k, p in model.named_parameters():
@@ -74,8 +76,12 @@ def test_c2_native_step_gradients_vs_oracle_direct(dev):
         if float(ref.abs().max()) == 0.0:
             assert float(p.grad.abs().max()) == 0.0, k
         else:
-            check_grad(f"c2 direct: native-step grad {k} vs oracle", p.grad.detach().cpu().reshape(ref.shape), ref, G_TOL)
+            try:
+                check_grad(f"c2 direct [{regime}]: native-step grad {k} vs oracle", p.grad.detach().cpu().reshape(ref.shape), ref, G_TOL)
+            except AssertionError as ex:
+                errs.append(str(ex))
         n += 1
+    assert not errs, errs
     assert n >= 60, n  # 4 blocks x 12 + patch embedding + BehaviorMLPs + readout + shifter
 
 
@@ -133,6 +139,7 @@ def test_c2_native_step_dropout_on_vs_oracle_replayed_masks(dev, case):
     finally:
         torch.set_num_threads(nthr)
     lo = float(ol)
+    errs = []
     record_margin(f"{case} dropout-on: native-step loss vs oracle", abs(float(out["loss"]) - lo), 1e-4 * abs(lo))
     assert abs(float(out["loss"]) - lo) <= 1e-4 * abs(lo)
     n = 0
@@ -144,8 +151,12 @@ def test_c2_native_step_dropout_on_vs_oracle_replayed_masks(dev, case):
         if float(ref.abs().max()) == 0.0:
             assert float(p.grad.abs().max()) == 0.0, k
         else:
-            check_grad(f"{case} dropout-on: native-step grad {k} vs oracle", p.grad.detach().cpu().reshape(ref.shape), ref, G_TOL)
+            try:
+                check_grad(f"{case} dropout-on: native-step grad {k} vs oracle", p.grad.detach().cpu().reshape(ref.shape), ref, G_TOL)
+            except AssertionError as ex:  # every tensor is measured (the margins table) before the test fails
+                errs.append(str(ex))
         n += 1
+    assert not errs, errs
     assert n >= 60, n
 
 

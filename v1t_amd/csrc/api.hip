@@ -70,6 +70,7 @@ struct v1t_vit {
     // backward of SMALL launches (a rank's share of a multi-GPU step): the four weight-gradient GEMMs of a block run on a second stream beside
     // the dX GEMMs of the same gradients (created by the first such backward)
     mutable hipStream_t dw_stream = nullptr;
+    mutable void* attn_bwd_event = nullptr;  // v1t_vit_set_attention_backward_event: recorded in front of the first attention backward of a backward call
     mutable hipEvent_t dw_ready[4] = {}, dw_done[4] = {};
 
     long long add(const std::string& name, std::initializer_list<long long> shape, bool is_param, long long& cursor) {
@@ -1006,7 +1007,10 @@ int v1t_vit_backward_input(const v1t_vit* h, const float* arena, const void* sha
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->HEP; t.xseg_valid = h->HE; t.alpha = 1.f;
         t.m_chunk = tp.mc_proj;
         CHECK(launch_dw(t, 2));  // reads dyp, o
-        CHECK(flush_dw(k));      // group k: dWqkv of block k + 1 (queued there), dW2, dW1, dWo of this block - one event each way
+        // group k: dWqkv of block k + 1 (queued there), dW2, dW1, dWo of this block - one event each way. V1T_DW_FLUSH_LATE=1 (dev, A/B): handed over
+        // behind the dO GEMM instead of in front of it, so that the HBM-bound group starts beside the MFMA-bound dK/dV kernel, not beside the dO GEMM
+        static const bool flush_late = dev_env("V1T_DW_FLUSH_LATE") && atoi(dev_env("V1T_DW_FLUSH_LATE"));
+        if (!flush_late) CHECK(flush_dw(k));
         // dO = dy . Wo
         g = GemmNTArgs{};
         g.A = dyp; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_proj_t); g.ldb = DP; g.M = R; g.N = HDP; g.K = DP; g.C = dO; g.ldc = HDP;
@@ -1030,6 +1034,8 @@ int v1t_vit_backward_input(const v1t_vit* h, const float* arena, const void* sha
         CHECK(launch_gemm_nt(g, EPI_BF16, s));
         if (!rowdot) CHECK(launch_attn_delta(at, h->HEP, delta, s));
         else if (k == h->NB - 1) CHECK(launch_attn_rc_pad(at, s));  // the pad rows are constants and only this call writes them: once per backward
+        if (flush_late) CHECK(flush_dw(k));
+        if (k == h->NB - 1 && h->attn_bwd_event && hipEventRecord((hipEvent_t)h->attn_bwd_event, s) != hipSuccess) return V1T_ERR_LAUNCH;
         CHECK(launch_attn_bwd(at, h->HEP, s));
         // dWqkv += dqkv^T z1
         t = GemmTNArgs{};
@@ -1199,6 +1205,11 @@ int v1t_dropout_mask(uint64_t seed, uint32_t stream_id, float p, long long rows,
     return launch_dropout_mask(out, rows, cols, make_drop(true, p, seed, stream_id), (hipStream_t)stream);
 }
 
+int v1t_vit_set_attention_backward_event(const v1t_vit* h, void* event) {
+    if (!h) return V1T_ERR_ARG;
+    h->attn_bwd_event = event;
+    return V1T_OK;
+}
 int v1t_vit_backward_second_stream(const v1t_vit* h, int batch) {
     if (!h || batch <= 0) return 0;
     const long long R = (long long)batch * h->T;
@@ -1376,6 +1387,31 @@ int v1t_attention_backward(const void* qkv, const void* o, const void* dO, const
                            uint32_t stream_id, float* delta_ws, void* dqkv, float* dscale, void* stream) {
     return v1t_attention_backward_ws(qkv, o, dO, lse2, B, H, T, DP, scale, scale_per_head, mask_diag, dropout_p, seed, stream_id, delta_ws, dqkv,
                                      dscale, nullptr, 0, stream);
+}
+// The planes the ViT core itself uses: the attention output as ONE fp16 plane (2^-12), which the backward's row constants
+// delta = rowsum(dO o O) read - eight times finer than the bf16 plane of v1t_attention_forward / _backward_ws.
+int v1t_attention_forward_f16o(const void* qkv, int B, int H, int T, int DP, const float* scale, int scale_per_head, int mask_diag,
+                               float dropout_p, uint64_t seed, uint32_t stream_id, void* o_f16, float* lse2, void* stream) {
+    if (!qkv || !scale || !o_f16 || !lse2) return V1T_ERR_ARG;
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.o = nullptr; a.o_lo = (bf16_t*)o_f16; a.lo_f16 = 1; a.ldo = H * DP; a.lse2 = lse2; a.B = B; a.H = H; a.T = T;
+    a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
+    a.adrop = make_adrop(dropout_p > 0.f, dropout_p, seed, stream_id);
+    return launch_attn_fwd(a, DP, (hipStream_t)stream);
+}
+int v1t_attention_backward_ws_f16o(const void* qkv, const void* o_f16, const void* dO, const float* lse2, int B, int H, int T, int DP,
+                                   const float* scale, int scale_per_head, int mask_diag, float dropout_p, uint64_t seed,
+                                   uint32_t stream_id, float* delta_ws, void* dqkv, float* dscale, void* ds_ws, long long ds_bytes,
+                                   void* stream) {
+    if (ds_ws && ds_bytes < (long long)attn_ds_bytes(B, H, T)) return V1T_ERR_WORKSPACE;
+    AttnArgs a{};
+    if (ds_ws) { a.ds = (bf16_t*)ds_ws; a.ldds = attn_ds_ld(T); }
+    a.qkv = (const bf16_t*)qkv; a.ldqkv = 3 * H * DP; a.o = (bf16_t*)o_f16; a.o_f16 = 1; a.ldo = H * DP; a.lse2 = (float*)lse2; a.B = B; a.H = H; a.T = T;
+    a.scale = scale; a.scale_per_head = scale_per_head; a.mask_diag = mask_diag;
+    a.adrop = make_adrop(dropout_p > 0.f, dropout_p, seed, stream_id);
+    a.dO = (const bf16_t*)dO; a.lddo = H * DP; a.delta = delta_ws; a.dqkv = (bf16_t*)dqkv; a.lddqkv = 3 * H * DP; a.dscale = dscale;
+    CHECK(launch_attn_delta(a, DP, delta_ws, (hipStream_t)stream));
+    return launch_attn_bwd(a, DP, (hipStream_t)stream);
 }
 long long v1t_attention_backward_ws_bytes(int B, int H, int T) { return (long long)attn_ds_bytes(B, H, T); }
 int v1t_attention_backward_ws(const void* qkv, const void* o, const void* dO, const float* lse2, int B, int H, int T, int DP,
