@@ -132,13 +132,6 @@ int v1t_vit_backward_input(const v1t_vit* h, const float* arena, const void* sha
                            const float* path_scale, const float* gout, float* grads, void* const* block_done,
                            float* dimages, void* stream);
 
-/* Optional hook for the caller's own side-stream work (the fused trainer's readout / shifter parameter gradients and the mice's AdamW,
- * train.py:97-111, 216-223: HBM-bound and independent of the core's backward once dz exists): `event` (a hipEvent_t, or NULL to clear) is
- * recorded on the backward's stream in front of the FIRST attention backward of every following v1t_vit_backward* call on this plan - the
- * first MFMA-bound kernel of the backward, beside which bandwidth-bound work is nearly free, while beside the HBM-bound GEMMs in front of
- * it, it costs its full time. NB = 0 plans never record it. */
-int v1t_vit_set_attention_backward_event(const v1t_vit* h, void* event);
-
 /* 1 when v1t_vit_backward* of `batch` images hands its weight-gradient GEMMs (dW = dY^T X of the four linear layers of a block) to a second
  * stream that runs them beside the next block's dX / attention kernels (launches under 262 144 token rows), 0 when everything runs on
  * `stream`. The gradients are complete on `stream` when the call's work is, either way. */

@@ -70,7 +70,6 @@ struct v1t_vit {
     // backward of SMALL launches (a rank's share of a multi-GPU step): the four weight-gradient GEMMs of a block run on a second stream beside
     // the dX GEMMs of the same gradients (created by the first such backward)
     mutable hipStream_t dw_stream = nullptr;
-    mutable void* attn_bwd_event = nullptr;  // v1t_vit_set_attention_backward_event: recorded in front of the first attention backward of a backward call
     mutable hipEvent_t dw_ready[4] = {}, dw_done[4] = {};
 
     long long add(const std::string& name, std::initializer_list<long long> shape, bool is_param, long long& cursor) {
@@ -1007,10 +1006,10 @@ int v1t_vit_backward_input(const v1t_vit* h, const float* arena, const void* sha
         t.yseg_pad = DP; t.yseg_valid = D; t.xseg_pad = h->HEP; t.xseg_valid = h->HE; t.alpha = 1.f;
         t.m_chunk = tp.mc_proj;
         CHECK(launch_dw(t, 2));  // reads dyp, o
-        // group k: dWqkv of block k + 1 (queued there), dW2, dW1, dWo of this block - one event each way. V1T_DW_FLUSH_LATE=1 (dev, A/B): handed over
-        // behind the dO GEMM instead of in front of it, so that the HBM-bound group starts beside the MFMA-bound dK/dV kernel, not beside the dO GEMM
-        static const bool flush_late = dev_env("V1T_DW_FLUSH_LATE") && atoi(dev_env("V1T_DW_FLUSH_LATE"));
-        if (!flush_late) CHECK(flush_dw(k));
+        // group k: dWqkv of block k + 1 (queued there), dW2, dW1, dWo of this block - one event each way. (Round 6, experiment 1: handing the group
+        // over BEHIND the dO GEMM, so that it starts beside the MFMA-bound dK/dV kernel instead of beside that HBM-bound GEMM: the dO GEMM
+        // 250 -> 142 us, the dK/dV kernel 1.90 -> 2.00 ms, the step 20.78 vs 20.77 ms - the work is conserved. profiles/r06_experiments.txt)
+        CHECK(flush_dw(k));
         // dO = dy . Wo
         g = GemmNTArgs{};
         g.A = dyp; g.lda = DP; g.B = (const bf16_t*)(sh + b.s_proj_t); g.ldb = DP; g.M = R; g.N = HDP; g.K = DP; g.C = dO; g.ldc = HDP;
@@ -1034,8 +1033,6 @@ int v1t_vit_backward_input(const v1t_vit* h, const float* arena, const void* sha
         CHECK(launch_gemm_nt(g, EPI_BF16, s));
         if (!rowdot) CHECK(launch_attn_delta(at, h->HEP, delta, s));
         else if (k == h->NB - 1) CHECK(launch_attn_rc_pad(at, s));  // the pad rows are constants and only this call writes them: once per backward
-        if (flush_late) CHECK(flush_dw(k));
-        if (k == h->NB - 1 && h->attn_bwd_event && hipEventRecord((hipEvent_t)h->attn_bwd_event, s) != hipSuccess) return V1T_ERR_LAUNCH;
         CHECK(launch_attn_bwd(at, h->HEP, s));
         // dWqkv += dqkv^T z1
         t = GemmTNArgs{};
@@ -1205,11 +1202,6 @@ int v1t_dropout_mask(uint64_t seed, uint32_t stream_id, float p, long long rows,
     return launch_dropout_mask(out, rows, cols, make_drop(true, p, seed, stream_id), (hipStream_t)stream);
 }
 
-int v1t_vit_set_attention_backward_event(const v1t_vit* h, void* event) {
-    if (!h) return V1T_ERR_ARG;
-    h->attn_bwd_event = event;
-    return V1T_OK;
-}
 int v1t_vit_backward_second_stream(const v1t_vit* h, int batch) {
     if (!h || batch <= 0) return 0;
     const long long R = (long long)batch * h->T;

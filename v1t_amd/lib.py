@@ -87,7 +87,6 @@ SIGNATURES: t.Dict[str, t.Tuple[t.Any, t.List[t.Any]]] = {
     "v1t_vit_scratch_bytes_input": (c_ll, [c_void_p, c_int]),
     "v1t_vit_backward_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_ll, c_int, c_u64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "v1t_vit_backward_second_stream": (c_int, [c_void_p, c_int]),
-    "v1t_vit_set_attention_backward_event": (c_int, [c_void_p, c_void_p]),
     "v1t_gaussian2d_forward": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "v1t_gaussian2d_backward": (c_int, [c_void_p, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_void_p, c_void_p]),
     "v1t_gather_transform": (c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_void_p, c_void_p]),

@@ -303,7 +303,6 @@ class _NativeStep:
         self.tails = []
         zo = len(units) + 1
         self.loss_total = None  # the step's total loss: a FRESH one-element tensor per step (the caller may keep it; `run`)
-        self.attn_ev = None     # recorded by the core's backward in front of its first attention backward (`run`)
         self.units_c = None  # ctypes table of v1t_tail_unit, rebuilt with the pointers
         self.mice_stepped = False
         C_, gh, gw = core.output_shape
@@ -465,25 +464,15 @@ class _NativeStep:
         core._arena.attach_grads()
         evs = core._block_events
         ev_arr = (C.c_void_p * len(evs))(*[e.cuda_event for e in evs]) if evs is not None else None
-        # the side stream's work below (HBM-bound: the tails' parameter gradients, the mice's AdamW) is released by an event the backward records
-        # in front of its first attention backward - the first MFMA-bound kernel, beside which it is nearly free - instead of by `dz_done`,
-        # which put it beside the HBM-bound dGELU / dX GEMMs at the head of the backward (336 instead of 113 us for the first of them,
-        # profiles/r05_step_timeline.txt). V1T_TAILS_EARLY=1 (dev, A/B): the round-5 order.
-        late = side is not None and core.num_blocks > 0 and os.environ.get("V1T_TAILS_EARLY", "0") != "1"
-        if late:
-            if self.attn_ev is None:
-                self.attn_ev = torch.cuda.Event()
-                self.attn_ev.record(main)  # created by a first record
-            L.check(lib.v1t_vit_set_attention_backward_event(core._plan, self.attn_ev.cuda_event), "set_attention_backward_event")
         L.check(lib.v1t_vit_backward_events(core._plan, core._arena.data.data_ptr(), core._shadow.data_ptr(), self.img.data_ptr(), L.ptr(self.beh), 0, self.B,
                                             self.ws.data_ptr(), self.scratch.data_ptr(), self.sb, 1, seed, None, self.gout.data_ptr(), core._arena.grad.data_ptr(),
                                             ev_arr, st), "vit_backward")
         # ---- what the core's backward does not wait for: the tails' parameter gradients (and, on one GPU, the mice's optimizer step)
         own_opt = trainer.sharding.world == 1 and side is not None
-        if late:
-            L.check(lib.v1t_vit_set_attention_backward_event(core._plan, None), "set_attention_backward_event")  # other callers of this plan record nothing
         if side is not None:
-            side.wait_event(self.attn_ev if late else dz_done)
+            # (round 6, experiment 2: releasing this HBM-bound side work at the backward's first attention kernel instead of here, beside the
+            # dGELU / dX GEMMs: 20.79-20.83 against 20.75-20.76 ms per step - no gain, profiles/r06_experiments.txt)
+            side.wait_event(dz_done)
         with on_side():
             s_ = torch.cuda.current_stream().cuda_stream
             L.check(lib.v1t_tails_backward(self.units_c, nu, zptr, T * DP, DP, C_, gh, gw, s_), "tails_backward")
