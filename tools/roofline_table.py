@@ -64,7 +64,10 @@ rows.sort(reverse=True)
 out = [f"# Counter-backed roofline of every kernel of the C2 training step ({rnd})", "",
        f"Source: `profiles/{rnd}_pmc_all{tag}.json` (`tools/pmc_all.sh`: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, KiB per launch; durations from",
        "`--kernel-trace --stats` passes, *alone* = `V1T_DW_SIDE=0` (every kernel has the chip), *live* = as the step runs (weight-gradient GEMMs beside the main stream).",
-       "traffic = FETCH_SIZE x 2 + WRITE_SIZE (the guide's gfx950 correction; the counters sit on the L2's fabric side, Infinity-Cache hits included).",
+       "traffic = FETCH_SIZE x 2 + WRITE_SIZE (the guide's gfx950 correction; the counters sit on the L2's fabric side, Infinity-Cache hits included). The x 2 is",
+       f"calibrated per kernel here: `profiles/{rnd}_pmc_readsize.json` (`tools/pmc_readsize.sh`: TCC_EA0_RDREQ by request size) shows EVERY read request of every kernel of",
+       "the step is a 128-B request (32-B: 0, 64-B: < 0.3 %), which FETCH_SIZE tallies at 64 B - so the doubling holds for the strided 16-B row reads of `ln_gemm` / `mlp_fwd` too,",
+       "whose 2 x 113 MiB for a 113-MiB residual stream is a real second fabric fetch of half of every line (8 waves x 20 KB of rows in flight per CU thrash the 16-KB L1 and the XCD's L2).",
        "TB/s = traffic / alone duration; ceilings on this chip (profiles/r04_hbm_stream.txt): read 6.4, write 4.7, copy 5.2 TB/s, nominal 8.",
        f"Kernels below 0.3 % of the step omitted. Kernel time of one step (alone, sum): {step_ms_alone:.2f} ms.", "",
        "| kernel | what | per step | alone us | live us | read GB | written GB | TB/s | of 8 | of ceiling | alg. GB | traffic / alg. | TFLOP/s | bound |",
