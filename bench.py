@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_attention.json")  # collected by tools/pmc_bench.sh on the GPU box (separate --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_attention.json")  # collected by tools/pmc_bench.sh on the GPU box (separate --pmc passes)
 
 
 def algorithmic_flops(args, n_neurons: int) -> dict:
@@ -184,6 +184,7 @@ def pmc_traffic(kernel: str, images: int, H: int, T: int, DP: int):
     return (2 * k["fetch_kib"] + k["write_kib"]) * 1024.0 * images / k["images"]
 
 
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s nominal (6.3-6.4 TB/s achievable by a streaming read on this chip)
 KERNELS = {0: ("attn_fwd", "attn_fwd (S = QK^T, softmax, dropout, P.V)", 1.0),
            1: ("attn_bwd_dq2", "attn_bwd_dq2 (dQ = dS' . K over the materialised dS')", 0.5),
            2: ("attn_bwd_dkv2", "attn_bwd_dkv2 (producer/consumer dK/dV + dS': the products S, dP, dV, dK)", 2.0)}
@@ -718,6 +719,17 @@ def run_training(a, wd, state):
     L.check(lib.v1t_profile_read(C.byref(launches), C.byref(total_ms)))
     L.check(lib.v1t_profile_enable(-1, 0))
     loss = float(out)
+    # the second-largest kernel family is HBM-bound: the dQ GEMM over the materialised dS' (class 1). Timed live the same way over a few EXTRA,
+    # un-timed steps behind the windows (the event timing serves one kernel class at a time) -> `roofline_hbm` of the line
+    hbm_launches, hbm_ms = C.c_int(), C.c_double()
+    if world == 1 and a.profile_class == 2:
+        wd.mark("roofline_hbm steps")
+        L.check(lib.v1t_profile_enable(1, 4 * 3 * max(units_per_step, 1) * args.num_blocks + 8))
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        L.check(lib.v1t_profile_read(C.byref(hbm_launches), C.byref(hbm_ms)))
+        L.check(lib.v1t_profile_enable(-1, 0))
     wd.mark("measured-peak probe / report")
     # un-timed, BEHIND the timed windows (75 ms of back-to-back MFMAs in front of them would hand the first window a pre-heated chip):
     # the chip is as warm as the step left it, so the clock the probe reports is the loaded one
@@ -781,6 +793,16 @@ def run_training(a, wd, state):
             line["roofline"]["shares_gpu_with"] = ("gemm_tn2 / tn_reduce_multi of the previous block on a second stream (weight gradients; "
                                                    "V1T_DW_SIDE=0 runs everything on one stream: this kernel ~12 % shorter, the step ~1.3 % slower)")
         line["model_frac_of_measured_peak"] = round(fl["train_per_image"] * images / dt / 1e12 / (peak_m["tflops"] * world), 4)
+        if hbm_launches.value > 0 and DPad == 160:
+            # algorithmic bytes of one dQ-GEMM launch: dS' read once (bf16, T padded to 128 both ways) + k read + dQ written
+            TPQ = (fl["T"] + 127) // 128 * 128
+            alg = imgs_launch * args.num_heads * (TPQ * TPQ * 2 + 2 * fl["T"] * DPad * 2)
+            h_ms = hbm_ms.value / hbm_launches.value
+            h_traffic = pmc_traffic("attn_bwd_dq2", imgs_launch, args.num_heads, fl["T"], DPad) if not a.no_pmc else None
+            line["roofline_hbm"] = {"kernel": KERNELS[1][1], "bound": "hbm", "achieved": round(alg / (h_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(alg / (h_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": h_traffic, "launches": hbm_launches.value, "avg_ms": round(h_ms, 4),
+                                    "bytes_per_launch": alg, "how": "hipEvents around every launch over 3 extra un-timed steps behind the timed windows; every other "
+                                    "kernel of the step: profiles/r06_roofline_table.md (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, duration alone and live)"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

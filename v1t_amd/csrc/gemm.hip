@@ -1131,14 +1131,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs g) {
 // buffered; rows past the end of the chunk are clamped for the fetch and masked in the 1-block operand.
 constexpr int TN2_ROWS = 64, TN2_STR = 160, TN2_CPR = TN2_STR / 8;
 
-template <int YB, int XB, bool XF16 = false>
-__global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs g) {
+// NST (round 6): stages of the operand ring. 2 = double buffer (rounds 1-5): ONE 41-KB stage in flight per workgroup while it computes, and the
+// 82 KB of LDS allow one workgroup per CU anyway - at the small launches of the per-mouse loop or of a rank's share (20-40 stages per workgroup,
+// ~250 workgroups) a stage then costs its DMA latency + transfer. 3 = two stages in flight behind a counted vmcnt (123 KB, still one workgroup per CU).
+template <int YB, int XB, bool XF16 = false, int NST = 3>
+__global__ __launch_bounds__(256, 1) void gemm_tn2_kernel(GemmTNArgs g) {
     constexpr int WY = (YB == 1) ? 4 : 1, WX = 4 / WY;
     constexpr int YW = 32 * YB * WY, XW = 32 * XB * WX;
     static_assert(YW <= TN2_STR && XW <= TN2_STR, "tile");
     constexpr int NI = TN2_ROWS * TN2_CPR / 64 / 4;  // DMA instructions per wave per operand tile (5)
-    __shared__ __attribute__((aligned(16))) bf16_t sY[2][TN2_ROWS * TN2_STR];
-    __shared__ __attribute__((aligned(16))) bf16_t sX[2][TN2_ROWS * TN2_STR];
+    __shared__ __attribute__((aligned(16))) bf16_t sY[NST][TN2_ROWS * TN2_STR];
+    __shared__ __attribute__((aligned(16))) bf16_t sX[NST][TN2_ROWS * TN2_STR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = (WY == 4) ? wave : 0, wx = (WX == 4) ? wave : 0;
     // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs in linear (x, y, z) order; after the remap the tiles of
@@ -1232,19 +1235,41 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs g) {
         }
     };
 
-    if (nt > 0) issue(0, 0);
-    dma_wait_and_barrier();
-    for (int t = 0; t < nt - 1; ++t) {
-        const int buf = t & 1;
-        issue(t + 1, buf ^ 1);
-        if (wave_on) compute(std::false_type{}, buf, TN2_ROWS);
+    if constexpr (NST == 2) {
+        if (nt > 0) issue(0, 0);
         dma_wait_and_barrier();
+        for (int t = 0; t < nt - 1; ++t) {
+            const int buf = t & 1;
+            issue(t + 1, buf ^ 1);
+            if (wave_on) compute(std::false_type{}, buf, TN2_ROWS);
+            dma_wait_and_barrier();
+        }
+    } else {
+        // every wave issues exactly 2 NI DMA operations per stage (both forms of `issue`), so "all but the newest stage have landed" is one
+        // counted vmcnt; stage t + 2 goes into the buffer stage t - 1 left behind the previous barrier
+        static_assert(DmaY::PW == NI && DmaX::PW == NI && DmaX::NINST == 4 * NI, "2 NI operations per stage and wave");
+        if (nt > 0) issue(0, 0);
+        if (nt > 1) issue(1, 1);
+        if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int buf = 0;
+        for (int t = 0; t < nt - 1; ++t) {
+            const int nb = buf + 2 >= NST ? buf + 2 - NST : buf + 2;
+            if (t + 2 < nt) issue(t + 2, nb);
+            if (wave_on) compute(std::false_type{}, buf, TN2_ROWS);
+            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf = buf + 1 == NST ? 0 : buf + 1;
+        }
     }
     if (!wave_on || nt <= 0) return;
     {
         const int valid = me - mb - TN2_ROWS * (nt - 1);
-        if (valid < TN2_ROWS) compute(std::true_type{}, (nt - 1) & 1, valid);
-        else compute(std::false_type{}, (nt - 1) & 1, TN2_ROWS);
+        const int lb = (nt - 1) % NST;
+        if (valid < TN2_ROWS) compute(std::true_type{}, lb, valid);
+        else compute(std::false_type{}, lb, TN2_ROWS);
     }
     if (g.slab) {
         // partial tile -> slab in accumulator-fragment order (16 floats per lane per block, plain 16-B stores);
@@ -1889,6 +1914,7 @@ static int launch_gemm_tn_impl(const GemmTNArgs& a, hipStream_t s, TnReduceMulti
     if (a.x_f16 && !gemm_tn_takes_f16_x(a.NY, a.NX, a.m_chunk)) return V1T_ERR_UNSUPPORTED;
     if (a.M <= 0) return V1T_OK;
     const int gz = (a.M + a.m_chunk - 1) / a.m_chunk;
+    static const int tn2_nst = dev_env("V1T_TN2_NST") ? atoi(dev_env("V1T_TN2_NST")) : 3;  // dev (A/B): 2 = the double buffer of rounds 1-5
     auto reduce = [&](int shape, int gx, int gy2) {
         if (!a.slab) return;
         if (defer && defer->n < TN_MULTI) {
@@ -1902,14 +1928,20 @@ static int launch_gemm_tn_impl(const GemmTNArgs& a, hipStream_t s, TnReduceMulti
     };
     if (a.m_chunk % TN2_ROWS == 0 && a.NY % 160 == 0 && a.NX % 128 == 0 && a.NY <= 320) {
         const int gx = a.NY / 160, gy2 = a.NX / 128;
-        if (a.x_f16) hipLaunchKernelGGL((gemm_tn2_kernel<5, 1, true>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_tn2_kernel<5, 1>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+        if (tn2_nst == 2) {
+            if (a.x_f16) hipLaunchKernelGGL((gemm_tn2_kernel<5, 1, true, 2>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gemm_tn2_kernel<5, 1, false, 2>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+        } else {
+            if (a.x_f16) hipLaunchKernelGGL((gemm_tn2_kernel<5, 1, true>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gemm_tn2_kernel<5, 1>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+        }
         reduce(0, gx, gy2);
         return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
     }
     if (a.m_chunk % TN2_ROWS == 0 && a.NX % 160 == 0) {
         const int gx = (a.NY + 127) / 128, gy2 = a.NX / 160;
-        hipLaunchKernelGGL((gemm_tn2_kernel<1, 5>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+        if (tn2_nst == 2) hipLaunchKernelGGL((gemm_tn2_kernel<1, 5, false, 2>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_tn2_kernel<1, 5>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
         reduce(1, gx, gy2);
         return hipGetLastError() == hipSuccess ? V1T_OK : V1T_ERR_LAUNCH;
     }
