@@ -1134,22 +1134,26 @@ constexpr int TN2_ROWS = 64, TN2_STR = 160, TN2_CPR = TN2_STR / 8;
 // NST (round 6): stages of the operand ring. 2 = double buffer (rounds 1-5): ONE 41-KB stage in flight per workgroup while it computes, and the
 // 82 KB of LDS allow one workgroup per CU anyway - at the small launches of the per-mouse loop or of a rank's share (20-40 stages per workgroup,
 // ~250 workgroups) a stage then costs its DMA latency + transfer. 3 = two stages in flight behind a counted vmcnt (123 KB, still one workgroup per CU).
-// The body takes the workgroup's LINEAR id inside its own (gx, gy, gz) grid: the stand-alone kernel passes blockIdx, the group kernel below the id
-// behind its GEMM's first workgroup (starts are multiples of 8, so id % 8 is still the XCD the hardware dealt the workgroup to).
-template <int YB, int XB, bool XF16, int NST>
-DEVFN void tn2_body(const GemmTNArgs& g, int lin, int gdx, int gdy, int gdz, bf16_t (*sY)[TN2_ROWS * TN2_STR], bf16_t (*sX)[TN2_ROWS * TN2_STR]) {
+template <int YB, int XB, bool XF16 = false, int NST = 3>
+__global__ __launch_bounds__(256, 1) void gemm_tn2_kernel(GemmTNArgs g) {
     constexpr int WY = (YB == 1) ? 4 : 1, WX = 4 / WY;
     constexpr int YW = 32 * YB * WY, XW = 32 * XB * WX;
     static_assert(YW <= TN2_STR && XW <= TN2_STR, "tile");
     constexpr int NI = TN2_ROWS * TN2_CPR / 64 / 4;  // DMA instructions per wave per operand tile (5)
+    __shared__ __attribute__((aligned(16))) bf16_t sY[NST][TN2_ROWS * TN2_STR];
+    __shared__ __attribute__((aligned(16))) bf16_t sX[NST][TN2_ROWS * TN2_STR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = (WY == 4) ? wave : 0, wx = (WX == 4) ? wave : 0;
     // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs in linear (x, y, z) order; after the remap the tiles of
     // one m-chunk - which all read the same rows of the narrow operand - are neighbours inside ONE XCD's share and find those rows in its L2
     // (dWo: the 59 MB of dy were fetched once per X tile, 5 times)
-    const int nwg = gdx * gdy * gdz;
-    const int lid = xcd_remap(lin, nwg);
-    const int bx = lid % gdx, by = (lid / gdx) % gdy, bz = lid / (gdx * gdy);
+#ifndef V1T_TN2_NOREMAP
+    const int nwg = gridDim.x * gridDim.y * gridDim.z;
+    const int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nwg);
+    const int bx = lid % gridDim.x, by = (lid / gridDim.x) % gridDim.y, bz = lid / (gridDim.x * gridDim.y);
+#else
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#endif
     const int n0 = bx * YW, x0 = by * XW;
     const int mb = bz * g.m_chunk;
     const int me = min(g.M, mb + g.m_chunk);
@@ -1270,7 +1274,7 @@ DEVFN void tn2_body(const GemmTNArgs& g, int lin, int gdx, int gdy, int gdz, bf1
     if (g.slab) {
         // partial tile -> slab in accumulator-fragment order (16 floats per lane per block, plain 16-B stores);
         // tn_reduce_kernel sums the chunks and applies the index maps. ~3x cheaper than 41 MB of fp32 atomics.
-        float* sl = g.slab + ((((size_t)bz * gdy + by) * gdx + bx) * 4 + wave) * (YB * XB * 1024) + lane * 16;
+        float* sl = g.slab + ((((size_t)bz * gridDim.y + by) * gridDim.x + bx) * 4 + wave) * (YB * XB * 1024) + lane * 16;
 #pragma unroll
         for (int i = 0; i < YB * XB; ++i)
 #pragma unroll
@@ -1300,36 +1304,6 @@ DEVFN void tn2_body(const GemmTNArgs& g, int lin, int gdx, int gdy, int gdz, bf1
         }
 }
 
-
-template <int YB, int XB, bool XF16 = false, int NST = 3>
-__global__ __launch_bounds__(256, 1) void gemm_tn2_kernel(GemmTNArgs g) {
-    __shared__ __attribute__((aligned(16))) bf16_t sY[NST][TN2_ROWS * TN2_STR];
-    __shared__ __attribute__((aligned(16))) bf16_t sX[NST][TN2_ROWS * TN2_STR];
-    tn2_body<YB, XB, XF16, NST>(g, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z, sY, sX);
-}
-// A block's weight-gradient GEMMs as ONE launch (round 6): on the second stream they ran back to back, each alone on the chip - at the small
-// launches of the per-mouse loop / a rank's share ~250 workgroups of 9-20 stages each, whose fixed parts (prologue, a 80-100-KB partial tile to the
-// slab, the reduction's read of it) cost more than their loop. Fused, the group fills the chip with a QUARTER of the m-chunks per GEMM: four times
-// the stages per workgroup, a quarter of the slab traffic. Workgroup ranges start at multiples of 8 (XCD-aligned, see tn2_body); shape as TnReduceMulti
-// (0: <5, 1>, 1: <1, 5>), xf16: the X operand is an fp16 plane (shape 0 only).
-constexpr int TN_GROUP = 4;
-struct TnGroup {
-    GemmTNArgs g[TN_GROUP];
-    int gx[TN_GROUP], gy[TN_GROUP], gz[TN_GROUP], shape[TN_GROUP];
-    int start[TN_GROUP + 1];
-    int n;
-};
-__global__ __launch_bounds__(256, 1) void gemm_tn2_group_kernel(TnGroup m) {
-    __shared__ __attribute__((aligned(16))) bf16_t sY[3][TN2_ROWS * TN2_STR];
-    __shared__ __attribute__((aligned(16))) bf16_t sX[3][TN2_ROWS * TN2_STR];
-    int u = 0;
-    while (u + 1 < m.n && (int)blockIdx.x >= m.start[u + 1]) ++u;  // workgroup-uniform
-    const int lin = blockIdx.x - m.start[u];
-    if (lin >= m.gx[u] * m.gy[u] * m.gz[u]) return;  // padding up to the next multiple of 8
-    if (m.shape[u] == 1) tn2_body<1, 5, false, 3>(m.g[u], lin, m.gx[u], m.gy[u], m.gz[u], sY, sX);
-    else if (m.g[u].x_f16) tn2_body<5, 1, true, 3>(m.g[u], lin, m.gx[u], m.gy[u], m.gz[u], sY, sX);
-    else tn2_body<5, 1, false, 3>(m.g[u], lin, m.gx[u], m.gy[u], m.gz[u], sY, sX);
-}
 
 // Sums the partial tiles gemm_tn2 left in the slab over the m-chunks and adds them into dW / dbias (plain
 // read-modify-write: exactly one thread owns each output element). Thread = 4 accumulator registers of one
@@ -1983,39 +1957,7 @@ static int launch_gemm_tn_impl(const GemmTNArgs& a, hipStream_t s, TnReduceMulti
 }
 int launch_gemm_tn(const GemmTNArgs& a, hipStream_t s) { return launch_gemm_tn_impl(a, s, nullptr); }
 // n GEMMs (distinct slab regions) back to back on `s`, then ONE launch for all their slab reductions
-// shape of the tn2 path a GEMM takes (0: <5, 1>, 1: <1, 5>), -1: another kernel
-static int tn2_shape(const GemmTNArgs& a) {
-    if (a.NY % 32 != 0 || a.NX % 32 != 0 || a.m_chunk % TN2_ROWS != 0 || (a.ldy % 8) || (a.ldx % 8) || a.M <= 0 || !a.slab) return -1;
-    if (a.NY % 160 == 0 && a.NX % 128 == 0 && a.NY <= 320) return 0;
-    if (a.NX % 160 == 0 && !a.x_f16) return 1;
-    return -1;
-}
-static const bool g_tn_fuse = !(dev_env("V1T_TN_GROUP_FUSE") && !atoi(dev_env("V1T_TN_GROUP_FUSE")));  // dev (A/B): 0 = one launch per GEMM
 int launch_gemm_tn_group(const GemmTNArgs* a, int n, hipStream_t s) {
-    static_assert(TN_GROUP == TN_MULTI, "one reduction launch per fused group");
-    bool fuse = g_tn_fuse && n >= 2;
-    for (int i = 0; i < n && fuse; ++i) fuse = tn2_shape(a[i]) >= 0;
-    if (fuse) {
-        for (int i0 = 0; i0 < n; i0 += TN_GROUP) {
-            TnGroup m{};
-            TnReduceMulti r{};
-            for (int i = i0; i < std::min(n, i0 + TN_GROUP); ++i) {
-                const int u = m.n++, sh = tn2_shape(a[i]);
-                m.g[u] = a[i]; m.shape[u] = sh;
-                m.gx[u] = sh == 0 ? a[i].NY / 160 : (a[i].NY + 127) / 128;
-                m.gy[u] = sh == 0 ? a[i].NX / 128 : a[i].NX / 160;
-                m.gz[u] = (a[i].M + a[i].m_chunk - 1) / a[i].m_chunk;
-                m.start[u + 1] = m.start[u] + (m.gx[u] * m.gy[u] * m.gz[u] + 7) / 8 * 8;
-                r.g[u] = a[i]; r.gx[u] = m.gx[u]; r.gy[u] = m.gy[u]; r.gz[u] = m.gz[u]; r.shape[u] = sh;
-                r.start[u + 1] = r.start[u] + m.gx[u] * m.gy[u] * 20;
-                r.n = m.n;
-            }
-            hipLaunchKernelGGL(gemm_tn2_group_kernel, dim3(m.start[m.n]), dim3(256), 0, s, m);
-            hipLaunchKernelGGL(tn_reduce_multi_kernel, dim3(r.start[r.n]), dim3(256), 0, s, r);
-            if (hipGetLastError() != hipSuccess) return V1T_ERR_LAUNCH;
-        }
-        return V1T_OK;
-    }
     for (int i0 = 0; i0 < n; i0 += TN_MULTI) {
         TnReduceMulti m{};
         for (int i = i0; i < std::min(n, i0 + TN_MULTI); ++i) {
