@@ -1,8 +1,8 @@
-# usage (GPU box): bash tools/pmc_bench.sh  -> gpurun_out/${RND:-r05}_pmc_attention.json + .txt: per-launch FETCH_SIZE / WRITE_SIZE (KiB) of the
+# usage (GPU box): bash tools/pmc_bench.sh  -> gpurun_out/${RND:-r06}_pmc_attention.json + .txt: per-launch FETCH_SIZE / WRITE_SIZE (KiB) of the
 # attention kernels inside bench.py (112-image training launches, dropout on) and inside the C5 eval pass (256-image launches),
 # separate --pmc passes as MI355X_MICROARCH.md prescribes; FETCH_SIZE needs x2 on gfx950 (applied by bench.py, not here).
-# Copy the two files to profiles/ (tracked) - bench.py reads profiles/${RND:-r05}_pmc_attention.json at run time.
-export RND=${RND:-r05}
+# Copy the two files to profiles/ (tracked) - bench.py reads profiles/${RND:-r06}_pmc_attention.json at run time.
+export RND=${RND:-r06}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmcb_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-pmc > /tmp/pmcb_$C.log 2>&1

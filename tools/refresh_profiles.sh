@@ -1,5 +1,5 @@
-# usage (GPU box): bash tools/refresh_profiles.sh  -> gpurun_out/${RND:-r05}_*: everything profiles/ holds for this round (copy over afterwards)
-export RND=${RND:-r05}
+# usage (GPU box): bash tools/refresh_profiles.sh  -> gpurun_out/${RND:-r06}_*: everything profiles/ holds for this round (copy over afterwards)
+export RND=${RND:-r06}
 O=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $O
 bash $GRAFT_REPO_ROOT/tools/pmc_bench.sh > $O/pmc_bench.log 2>&1
