@@ -170,16 +170,17 @@ def cpu_baseline() -> dict:
 
 def pmc_traffic(kernel: str, images: int, H: int, T: int, DP: int):
     """HBM bytes per launch of `kernel` from the tracked PMC summary (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes:
-    tools/pmc_bench.sh, MI355X_MICROARCH.md). Fails when the file is missing or was measured on another launch shape
+    tools/pmc_bench.sh, MI355X_MICROARCH.md); None when the file is missing or was measured on another launch shape
     (the traffic of these kernels is proportional to the images of a launch; heads, tokens and head dim must be equal)."""
+    # a missing / mismatching summary costs the line its `traffic` (null, as the contract allows), never the measurement
     if not os.path.exists(PMC_FILE):
-        raise SystemExit(f"bench.py: {PMC_FILE} is missing (collect it with tools/pmc_bench.sh on the GPU box)")
+        print(f"[bench] {PMC_FILE} is missing (collect it with tools/pmc_bench.sh on the GPU box): roofline.traffic = null", file=sys.stderr, flush=True)
+        return None
     d = json.load(open(PMC_FILE))
     sh = d["shape"]
-    if (sh["H"], sh["T"], sh["DP"]) != (H, T, DP):
-        raise SystemExit(f"bench.py: {PMC_FILE} was measured on shape {sh}, this run launches H={H} T={T} DP={DP}")
-    if kernel not in d["kernels"]:
-        raise SystemExit(f"bench.py: {PMC_FILE} has no entry for kernel {kernel}")
+    if (sh["H"], sh["T"], sh["DP"]) != (H, T, DP) or kernel not in d["kernels"]:
+        print(f"[bench] {PMC_FILE} was measured on shape {sh} / has no entry for {kernel}; this run launches H={H} T={T} DP={DP}: roofline.traffic = null", file=sys.stderr, flush=True)
+        return None
     k = d["kernels"][kernel]
     return (2 * k["fetch_kib"] + k["write_kib"]) * 1024.0 * images / k["images"]
 
