@@ -52,8 +52,10 @@ def check_rel(name: str, got, ref, tol: float) -> float:
     return e
 
 
-G_L2_TOL = 4e-2    # relative L2 error of a gradient tensor, ||g - ref|| / ||ref||
-G_COS_TOL = 1e-3   # 1 - cosine(g, ref)
+# ~2-3 x the worst measured over the whole GPU suite of round 6 (1.2e-2 / 6.7e-5: the class-token gradient of the trained-regime step with dropout on;
+# everything in the flat regime stays below 4.6e-3 / 1.0e-5)
+G_L2_TOL = 2.5e-2  # relative L2 error of a gradient tensor, ||g - ref|| / ||ref||
+G_COS_TOL = 2e-4   # 1 - cosine(g, ref)
 
 
 def check_grad(name: str, got, ref, tol_max: float, tol_l2: float = G_L2_TOL, tol_cos: float = G_COS_TOL) -> float:

@@ -1133,9 +1133,10 @@ constexpr int TN2_ROWS = 64, TN2_STR = 160, TN2_CPR = TN2_STR / 8;
 
 // NST (round 6): stages of the operand ring. 2 = double buffer (rounds 1-5): ONE 41-KB stage in flight per workgroup while it computes, and the
 // 82 KB of LDS allow one workgroup per CU anyway - at the small launches of the per-mouse loop or of a rank's share (20-40 stages per workgroup,
-// ~250 workgroups) a stage then costs its DMA latency + transfer. 3 = two stages in flight behind a counted vmcnt (123 KB, still one workgroup per CU).
+// ~250 workgroups) a stage then costs its DMA latency + transfer. 3 = two stages in flight behind a counted vmcnt (123 KB: one workgroup per CU - the
+// double buffer's 81 920 B fit a CU's 160 KB exactly TWICE, which is what full-size launches want; the launcher picks by workgroup count).
 template <int YB, int XB, bool XF16 = false, int NST = 3>
-__global__ __launch_bounds__(256, 1) void gemm_tn2_kernel(GemmTNArgs g) {
+__global__ __launch_bounds__(256, (NST == 2 ? 2 : 1)) void gemm_tn2_kernel(GemmTNArgs g) {
     constexpr int WY = (YB == 1) ? 4 : 1, WX = 4 / WY;
     constexpr int YW = 32 * YB * WY, XW = 32 * XB * WX;
     static_assert(YW <= TN2_STR && XW <= TN2_STR, "tile");
@@ -1914,7 +1915,10 @@ static int launch_gemm_tn_impl(const GemmTNArgs& a, hipStream_t s, TnReduceMulti
     if (a.x_f16 && !gemm_tn_takes_f16_x(a.NY, a.NX, a.m_chunk)) return V1T_ERR_UNSUPPORTED;
     if (a.M <= 0) return V1T_OK;
     const int gz = (a.M + a.m_chunk - 1) / a.m_chunk;
-    static const int tn2_nst = dev_env("V1T_TN2_NST") ? atoi(dev_env("V1T_TN2_NST")) : 3;  // dev (A/B): 2 = the double buffer of rounds 1-5
+    // the 3-stage ring (123 KB) is for launches of at most one workgroup per CU; above that the double buffer's 81 920 B let TWO workgroups share a
+    // CU's 160 KB, which hides more latency than a deeper ring (112-image launch, alone: 113 / 110 us per GEMM against 174 / 136 with the ring -
+    // profiles/r06_experiments.txt #4). V1T_TN2_NST=2 / 3 (dev, A/B) forces either.
+    static const int tn2_force = dev_env("V1T_TN2_NST") ? atoi(dev_env("V1T_TN2_NST")) : 0;
     auto reduce = [&](int shape, int gx, int gy2) {
         if (!a.slab) return;
         if (defer && defer->n < TN_MULTI) {
@@ -1928,6 +1932,7 @@ static int launch_gemm_tn_impl(const GemmTNArgs& a, hipStream_t s, TnReduceMulti
     };
     if (a.m_chunk % TN2_ROWS == 0 && a.NY % 160 == 0 && a.NX % 128 == 0 && a.NY <= 320) {
         const int gx = a.NY / 160, gy2 = a.NX / 128;
+        const int tn2_nst = tn2_force ? tn2_force : (gx * gy2 * gz <= 256 ? 3 : 2);
         if (tn2_nst == 2) {
             if (a.x_f16) hipLaunchKernelGGL((gemm_tn2_kernel<5, 1, true, 2>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_tn2_kernel<5, 1, false, 2>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
@@ -1940,6 +1945,7 @@ static int launch_gemm_tn_impl(const GemmTNArgs& a, hipStream_t s, TnReduceMulti
     }
     if (a.m_chunk % TN2_ROWS == 0 && a.NX % 160 == 0) {
         const int gx = (a.NY + 127) / 128, gy2 = a.NX / 160;
+        const int tn2_nst = tn2_force ? tn2_force : (gx * gy2 * gz <= 256 ? 3 : 2);
         if (tn2_nst == 2) hipLaunchKernelGGL((gemm_tn2_kernel<1, 5, false, 2>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_tn2_kernel<1, 5>), dim3(gx, gy2, gz), dim3(256), 0, s, a);
         reduce(1, gx, gy2);
