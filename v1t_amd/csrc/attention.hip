@@ -1941,6 +1941,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq2_kernel(AttnArgs a) {
     for (int c = 0; c < 4; ++c)
         aoffs[c] = (gi & 1) * 512 + ahalf * 256 + ((akey + 16 * (c >> 1) + 4 * (c & 1) - 4 * ahalf) & 31) * 8 + (li & 1) * 4;
     const int nst = nkb;  // 32-key stages
+    const bool ds_nt = a.ds_nt != 0;  // kernel-uniform
     // vector-memory operations this wave issues per stage: its own dS' blocks (2 pieces each) + its share of the K tile
     const int nk_ops = min(DmaK::PW, max(0, DmaK::NINST - wave * DmaK::PW)), ns_ops = 2 * nact;
     const int nops = ns_ops + nk_ops;
@@ -1950,7 +1951,16 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq2_kernel(AttnArgs a) {
         for (int u = 0; u < QPW; ++u)
             if (u < nact) {
                 const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&sS[buf][wave][u][0]);
-                TileDma<DP, G::RSTR>::template group<2>(sbase[u] + (size_t)st * 2048, l0, svoff, svoff, 0, 0);
+                // dS' is read exactly once: the non-temporal policy (streams past the L2's / Infinity Cache's LRU; tools/microbench/hbm_stream: LDS-DMA reads
+                // 7.1 against 6.4 TB/s) - round 6; V1T_DQ2_NT=0 (dev, A/B): the plain policy of rounds 2-5
+                if (ds_nt) {
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024 nt\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "s"(l0), "v"(svoff), "s"(sbase[u] + (size_t)st * 2048) : "memory");
+                } else {
+                    TileDma<DP, G::RSTR>::template group<2>(sbase[u] + (size_t)st * 2048, l0, svoff, svoff, 0, 0);
+                }
             }
     };
     auto stage_k = [&](int st) { dmaK.issue(kbase, KT * st, a.T, sK[st % NBK]); };
@@ -2020,7 +2030,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq2_kernel(AttnArgs a) {
 }
 
 template <int DP, bool DROP, bool DIAG>
-int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
+int launch_bwd_t(const AttnArgs& a_in, hipStream_t s) {
+    const AttnArgs& a = a_in;
     const int n = ((a.T + 127) / 128) * a.H * a.B;
     // the producer / consumer pair is laid out for head dim 160 (10.5 DMA pieces per 32-row tile dealt 3 / 3 / 3 / 2 over the wave pairs, the
     // row constants riding in pair 3's free piece): at head dim 128 pair 3 would issue pieces that do not exist - the first test at that
@@ -2033,6 +2044,9 @@ int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
             static const bool dq_deep = !(dev_env("V1T_DQ2_DEEP") && !atoi(dev_env("V1T_DQ2_DEEP")));  // dev (A/B): 0 = the one 3-deep ring
+            static const bool dq_nt = !(dev_env("V1T_DQ2_NT") && !atoi(dev_env("V1T_DQ2_NT")));
+            AttnArgs a = a_in;
+            a.ds_nt = dq_nt ? 1 : 0;
             if (dq_deep) hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP, true>), dim3(((a.T + 511) / 512) * a.H * a.B), dim3(512), 0, s, a);
             else hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP, false>), dim3(((a.T + 511) / 512) * a.H * a.B), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DQ, s);
