@@ -1954,10 +1954,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq2_kernel(AttnArgs a) {
                 // dS' is read exactly once: the non-temporal policy (streams past the L2's / Infinity Cache's LRU; tools/microbench/hbm_stream: LDS-DMA reads
                 // 7.1 against 6.4 TB/s) - round 6; V1T_DQ2_NT=0 (dev, A/B): the plain policy of rounds 2-5
                 if (ds_nt) {
-                    unsigned keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024 nt\n\t"
-                                 "s_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "s"(l0), "v"(svoff), "s"(sbase[u] + (size_t)st * 2048) : "memory");
+                    TileDma<DP, G::RSTR>::template group<2, true>(sbase[u] + (size_t)st * 2048, l0, svoff, svoff, 0, 0);
                 } else {
                     TileDma<DP, G::RSTR>::template group<2>(sbase[u] + (size_t)st * 2048, l0, svoff, svoff, 0, 0);
                 }

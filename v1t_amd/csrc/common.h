@@ -201,28 +201,33 @@ struct TileDma {
 #pragma unroll
         for (int i = 0; i < PW; ++i) voff[i] = lane_off(i, ROWS - 1);
     }
-    template <int CNT>
+    // NTP: the non-temporal policy on every piece (an operand that is read exactly once: it streams past the L2's / Infinity Cache's LRU;
+    // tools/microbench/hbm_stream: LDS-DMA reads 7.1 against 6.4 TB/s)
+    template <int CNT, bool NTP = false>
     DEVFN static void group(const char* base, unsigned m0v, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
         unsigned keep;
-        if constexpr (CNT == 4)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\tglobal_load_lds_dwordx4 %3, %6 offset:1024\n\t"
-                         "global_load_lds_dwordx4 %4, %6 offset:2048\n\tglobal_load_lds_dwordx4 %5, %6 offset:3072\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base) : "memory");
-        else if constexpr (CNT == 3)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\tglobal_load_lds_dwordx4 %3, %5 offset:1024\n\t"
-                         "global_load_lds_dwordx4 %4, %5 offset:2048\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "v"(v2), "s"(base) : "memory");
-        else if constexpr (CNT == 2)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %3, %4 offset:1024\n\t"
-                         "s_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "s"(base) : "memory");
-        else if constexpr (CNT == 1)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+#define V1T_DMA_GROUP(NTS)                                                                                                                              \
+        if constexpr (CNT == 4)                                                                                                                         \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6" NTS "\n\tglobal_load_lds_dwordx4 %3, %6 offset:1024" NTS "\n\t" \
+                         "global_load_lds_dwordx4 %4, %6 offset:2048" NTS "\n\tglobal_load_lds_dwordx4 %5, %6 offset:3072" NTS "\n\ts_mov_b32 m0, %0"         \
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base) : "memory");                                             \
+        else if constexpr (CNT == 3)                                                                                                                    \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5" NTS "\n\tglobal_load_lds_dwordx4 %3, %5 offset:1024" NTS "\n\t" \
+                         "global_load_lds_dwordx4 %4, %5 offset:2048" NTS "\n\ts_mov_b32 m0, %0"                                                        \
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "v"(v2), "s"(base) : "memory");                                                      \
+        else if constexpr (CNT == 2)                                                                                                                    \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4" NTS "\n\tglobal_load_lds_dwordx4 %3, %4 offset:1024" NTS "\n\t" \
+                         "s_mov_b32 m0, %0"                                                                                                             \
+                         : "=&s"(keep) : "s"(m0v), "v"(v0), "v"(v1), "s"(base) : "memory");                                                               \
+        else if constexpr (CNT == 1)                                                                                                                    \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" NTS "\n\ts_mov_b32 m0, %0"                \
                          : "=&s"(keep) : "s"(m0v), "v"(v0), "s"(base) : "memory");
+        if constexpr (NTP) { V1T_DMA_GROUP(" nt") } else { V1T_DMA_GROUP("") }
+#undef V1T_DMA_GROUP
     }
     // img: element (row 0, col 0) of this (image, head) slice; t0: first row of the tile; lds: tile base (LDS_ELEMS elements)
     // MAY_RAG = false: the caller knows that the tile lies wholly inside T (no ragged check in the issue)
-    template <bool MAY_RAG = true>
+    template <bool MAY_RAG = true, bool NTP = false>
     DEVFN void issue(const bf16_t* img, int t0_, int T, bf16_t* lds) const {
         // a tile that lies WHOLLY beyond T (the dQ GEMM walks the 128-key padded width of dS': up to three such 32-key tiles when T % 128 <= 96 -
         // first met at T = 34 114, tests/test_gpu_longseq.py; T = 1654 has none) is fetched as T - 1 repeated: without the clamp the row clamp below
@@ -249,10 +254,10 @@ struct TileDma {
             const int cnt = UNIFORM ? min(4, PW - 4 * g) : min(min(4, PW - 4 * g), NINST - n0);  // pieces of this group that exist (UNIFORM: compile-time)
             const unsigned m0v = __builtin_amdgcn_readfirstlane(l0 + 1024u * (unsigned)n0);
             auto at = [&](int k) { return v[4 * g + k < PW ? 4 * g + k : PW - 1]; };
-            if (cnt >= 4) group<4>(base, m0v, at(0), at(1), at(2), at(3));
-            else if (cnt == 3) group<3>(base, m0v, at(0), at(1), at(2), 0);
-            else if (cnt == 2) group<2>(base, m0v, at(0), at(1), 0, 0);
-            else if (cnt == 1) group<1>(base, m0v, at(0), 0, 0, 0);
+            if (cnt >= 4) group<4, NTP>(base, m0v, at(0), at(1), at(2), at(3));
+            else if (cnt == 3) group<3, NTP>(base, m0v, at(0), at(1), at(2), 0);
+            else if (cnt == 2) group<2, NTP>(base, m0v, at(0), at(1), 0, 0);
+            else if (cnt == 1) group<1, NTP>(base, m0v, at(0), 0, 0, 0);
         }
     }
 };

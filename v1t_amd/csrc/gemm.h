@@ -75,6 +75,7 @@ struct GemmTNArgs {
     // X holds fp16 values (the forward's second plane of the attention output / GELU output): converted to bf16 fragment by fragment.
     // Only where gemm_tn_takes_f16_x() says so (the 160 x 128 workgroup shape, one X block per wave).
     int x_f16;
+    int nt;  // set by the launcher: the once-read operand of gemm_tn2 through the non-temporal policy
 };
 bool gemm_tn_takes_f16_x(int NY, int NX, int m_chunk);
 size_t gemm_tn_slab_bytes(int M, int NY, int NX, int m_chunk);

@@ -1185,13 +1185,19 @@ __global__ __launch_bounds__(256, (NST == 2 ? 2 : 1)) void gemm_tn2_kernel(GemmT
 #endif
     DmaY dmaY;
     DmaX dmaX;
+    const bool tn_nt = g.nt != 0;  // kernel-uniform
     dmaY.init(lane, wave, g.ldy);
     dmaX.init(lane, wave, g.ldx);
     auto issue = [&](int t, int buf) {
         const int mt = mb + TN2_ROWS * t;
         if (whole) {
-            dmaY.issue(g.Y + n0, mt, me, sY[buf]);
-            dmaX.issue(g.X + x0, mt, me, sX[buf]);
+            // the operand whose tile columns belong to THIS workgroup alone is read exactly once (<1, 5>: Y - dqkv / dh; <5, 1>: X - the attention
+            // output / activation plane): non-temporal. The narrow operand is re-read by every column tile through the L2 and keeps the default
+            // policy. V1T_TN2_NT=0 (dev, A/B): both plain, as in rounds 1-5.
+            if (tn_nt && YB == 1) dmaY.template issue<true, true>(g.Y + n0, mt, me, sY[buf]);
+            else dmaY.issue(g.Y + n0, mt, me, sY[buf]);
+            if (tn_nt && YB != 1) dmaX.template issue<true, true>(g.X + x0, mt, me, sX[buf]);
+            else dmaX.issue(g.X + x0, mt, me, sX[buf]);
             return;
         }
 #pragma unroll
@@ -1910,7 +1916,10 @@ bool gemm_tn_takes_f16_x(int NY, int NX, int m_chunk) { return m_chunk % TN2_ROW
 
 // `defer`: launch the GEMM only and describe its slab reduction in *defer (the caller runs launch_tn_reduce_group over several of them);
 // GEMMs without a slab, or of a shape without one, ignore it.
-static int launch_gemm_tn_impl(const GemmTNArgs& a, hipStream_t s, TnReduceMulti* defer) {
+static int launch_gemm_tn_impl(const GemmTNArgs& a_in, hipStream_t s, TnReduceMulti* defer) {
+    static const bool tn_nt = !(dev_env("V1T_TN2_NT") && !atoi(dev_env("V1T_TN2_NT")));
+    GemmTNArgs a = a_in;
+    a.nt = tn_nt ? 1 : 0;
     if (a.NY % 32 != 0 || a.NX % 32 != 0 || a.m_chunk % 32 != 0 || (a.ldy % 8) || (a.ldx % 8)) return V1T_ERR_ARG;
     if (a.x_f16 && !gemm_tn_takes_f16_x(a.NY, a.NX, a.m_chunk)) return V1T_ERR_UNSUPPORTED;
     if (a.M <= 0) return V1T_OK;
