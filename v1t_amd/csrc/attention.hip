@@ -522,12 +522,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void attn_fwd_kernel(AttnArgs a)
                     wl[j] = aux_plane(v, w[j], a.lo_f16);
                 }
                 if (a.o) *(bf16x4*)(a.o + orow + 32 * d + 8 * rq + 4 * h2) = w;
-                if (a.o_lo) {
-                    // the output plane is written once and read back a kernel later from HBM either way (237 MB per 112-image launch): streamed past
-                    // the L2, where this launch's K / V tiles are re-read by seven query blocks each. out_nt = 0 (dev, A/B): the plain store of rounds 1-5
-                    if (a.out_nt) __builtin_nontemporal_store(wl, (bf16x4*)(a.o_lo + orow + 32 * d + 8 * rq + 4 * h2));
-                    else *(bf16x4*)(a.o_lo + orow + 32 * d + 8 * rq + 4 * h2) = wl;
-                }
+                if (a.o_lo) *(bf16x4*)(a.o_lo + orow + 32 * d + 8 * rq + 4 * h2) = wl;
             }
     }
 }
@@ -1272,8 +1267,6 @@ static void choose_fwd_split_uncached(int B, int H, int T, int& F, int& Hh, int&
 template <int DP, bool DROP, bool DIAG>
 int launch_fwd_t(const AttnArgs& a_in, hipStream_t s) {
     AttnArgs a = a_in;
-    static const bool out_nt = !(dev_env("V1T_ATTN_NT_OUT") && !atoi(dev_env("V1T_ATTN_NT_OUT")));
-    a.out_nt = out_nt ? 1 : 0;
     dim3 grid(((a.T + 32 * FWD_WAVES - 1) / (32 * FWD_WAVES)) * a.H * a.B);  // the natural cover (the experiment kernels below)
     choose_fwd_split(a.B, a.H, a.T, a.fwd_full, a.fwd_half, a.fwd_lpt);
     const dim3 grid_main((a.fwd_full + a.fwd_half) * a.H * a.B);
@@ -1877,13 +1870,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
                 const u32x4 xk = *(const u32x4*)(tk + row * G::RSTR + 8 * ch);
                 const u32x4 xv = *(const u32x4*)(tv + row * G::RSTR + 8 * ch);
                 bf16_t* o = obase + (size_t)row * a.lddqkv + 8 * ch;
-                if (a.out_nt) {
-                    __builtin_nontemporal_store(xk, (u32x4*)(o + HD));
-                    __builtin_nontemporal_store(xv, (u32x4*)(o + 2 * HD));
-                } else {
-                    *(u32x4*)(o + HD) = xk;
-                    *(u32x4*)(o + 2 * HD) = xv;
-                }
+                *(u32x4*)(o + HD) = xk;
+                *(u32x4*)(o + 2 * HD) = xv;
             }
         }
     }
@@ -2048,11 +2036,8 @@ int launch_bwd_t(const AttnArgs& a_in, hipStream_t s) {
     if constexpr (DP == 160 && !DIAG) {
         if (a.ds) {
             if (a.ldds != attn_ds_ld(a.T)) return V1T_ERR_ARG;
-            static const bool out_nt = !(dev_env("V1T_ATTN_NT_OUT") && !atoi(dev_env("V1T_ATTN_NT_OUT")));
-            AttnArgs ak = a_in;
-            ak.out_nt = out_nt ? 1 : 0;
             prof_begin(PROF_ATTN_DKV, s);
-            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, ak);
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
             static const bool dq_deep = !(dev_env("V1T_DQ2_DEEP") && !atoi(dev_env("V1T_DQ2_DEEP")));  // dev (A/B): 0 = the one 3-deep ring
