@@ -110,4 +110,9 @@ def test_bench_line_contract_on_the_gpu():
     assert rf["bound"] in ("mfma", "hbm") and rf["unit"] in ("TFLOP/s", "GB/s")
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.05 < rf["frac"] < 1.0
     assert rf["launches"] >= 3 * 4  # four blocks per step, every launch of the timed steps measured (hipEvents on the kernel's stream)
+    rh = d["roofline_hbm"]  # the second-largest kernel family (HBM-bound): the dQ GEMM over the materialised dS', algorithmic bytes / live duration
+    assert rh["bound"] == "hbm" and rh["unit"] == "GB/s" and rh["peak"] == 8000.0 and rh["launches"] >= 3 * 4
+    assert abs(rh["frac"] - rh["achieved"] / rh["peak"]) < 1e-3 and 0.2 < rh["frac"] < 1.0
+    assert abs(rh["achieved"] - rh["bytes_per_launch"] / (rh["avg_ms"] * 1e-3) / 1e9) <= 1e-3 * rh["achieved"]
+    assert rh["traffic"] is None or rh["traffic"] >= 0.9 * rh["bytes_per_launch"]  # counters cannot show less than the algorithmic bytes
     assert 5.0 < d["ms_per_step"] < 200.0
