@@ -17,7 +17,7 @@ import torch.distributed as dist
 
 
 class MouseSharding:
-    PIECE_COST = 1.0  # images; see cost() below
+    PIECE_COST = 0.5  # images (~0.1 ms of a rank's 0.84 ms + 0.179 ms per image, round-6 fit); see cost() below
 
     def __init__(self, mouse_ids: t.Sequence[str], rank: int = 0, world: int = 1, batch_size: int = 16, make_groups: bool = True):
         self.mouse_ids = list(mouse_ids)
@@ -49,12 +49,11 @@ class MouseSharding:
                 return plan_
 
             def cost(plan_, g):
-                # step time of the most loaded rank in image-equivalents. A rank runs the shared core ONCE over all its
-                # pieces (Trainer / Model.forward_mice), so its time is ~1.2 ms + 0.245 ms per image whatever the cut
-                # (tools/sim_scaling.py: 16 images 5.1 ms, 32: 9.0, 56: 15.1, 112: 28.7; a rank with two 8-image pieces
-                # of different mice fits the same line); a piece adds its readout launches and, for a cut mouse, one small
-                # all-reduce: ~0.25 ms = PIECE_COST of one image. (Before the core was batched over a rank's pieces
-                # every piece paid ~6.6 images of fixed work and whole mice won on 4 ranks.)
+                # step time of the most loaded rank in image-equivalents. A rank runs the shared core ONCE over all its pieces (Trainer /
+                # Model.forward_mice), so its time is a line in its images whatever the cut - round 6 (tools/sim_scaling.py,
+                # profiles/r06_sim_scaling.txt): 14 images 3.35 ms, 28: 5.9, 56: 11.1, 112: 20.9 = 0.84 ms + 0.179 ms per image (round 1, when this
+                # model was written: 1.2 + 0.245) - and a piece adds its slice of the one-launch-per-stage tails and, for a cut mouse, one small
+                # all-reduce: ~0.1 ms = PIECE_COST of about half an image (round 1: 0.25 ms = one image, a chain of ~11 launches per piece).
                 per = batch_size // g
                 load = [0.0] * world
                 for m in self.mouse_ids:
