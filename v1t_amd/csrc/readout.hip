@@ -49,45 +49,24 @@ DEVFN void readout_fwd_body(const ReadoutArgs& a, int bx) {
         f[i] = (c < a.C) ? a.feat[(size_t)n * a.FS + c] : 0.f;
     }
     const float bias = a.bias ? a.bias[n] : 0.f;
-    // RB images at a time (round 6): the sample position -> four row reads -> reduction chain of ONE image is two dependent memory latencies, and the
-    // kernel was bound by exactly that (16 serial images per wave: 196 us per step at 0.94 TB/s); with the positions of RB images loaded first
-    // and their 4 x RB row reads issued together the latencies overlap. Images beyond B repeat the last one and are not stored.
-    constexpr int RB = 4;
-    for (int b0 = 0; b0 < a.B; b0 += RB) {
-        float gx[RB], gy[RB];
+    for (int b = 0; b < a.B; ++b) {
+        const float gx = a.grid[((size_t)b * a.N + n) * 2 + 0];
+        const float gy = a.grid[((size_t)b * a.N + n) * 2 + 1];
+        const Taps t = make_taps(gx, gy, a.W, a.H);
+        const float* zb = a.z + (size_t)b * a.zsb;
+        float acc = 0.f;
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int b = min(b0 + u, a.B - 1);
-            gx[u] = a.grid[((size_t)b * a.N + n) * 2 + 0];
-            gy[u] = a.grid[((size_t)b * a.N + n) * 2 + 1];
-        }
-        Taps t[RB];
-        float zv[RB][4][NE];
+        for (int k = 0; k < 4; ++k) {
+            const float* zr = zb + (size_t)t.cell[k] * a.zsc;
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int b = min(b0 + u, a.B - 1);
-            t[u] = make_taps(gx[u], gy[u], a.W, a.H);
-            const float* zb = a.z + (size_t)b * a.zsb;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float* zr = zb + (size_t)t[u].cell[k] * a.zsc;
-#pragma unroll
-                for (int i = 0; i < NE; ++i) {
-                    const int c = lane + 64 * i;
-                    zv[u][k][i] = (c < a.C) ? zr[c] : 0.f;
-                }
+            for (int i = 0; i < NE; ++i) {
+                const int c = lane + 64 * i;
+                const float zv = (c < a.C) ? zr[c] : 0.f;
+                acc += t.w[k] * f[i] * zv;
             }
         }
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int i = 0; i < NE; ++i) acc += t[u].w[k] * f[i] * zv[u][k][i];
-            acc = wave_sum(acc);
-            if (lane == 0 && b0 + u < a.B) a.out[(size_t)(b0 + u) * a.N + n] = acc + bias;
-        }
+        acc = wave_sum(acc);
+        if (lane == 0) a.out[(size_t)b * a.N + n] = acc + bias;
     }
 }
 
@@ -110,58 +89,37 @@ DEVFN void readout_bwd_body(const ReadoutArgs& a, int bx) {
         df[i] = 0.f;
     }
     float gsum = 0.f;
-    constexpr int RB = 4;  // images whose positions and row reads are in flight together (see readout_fwd_body)
-    for (int b0 = 0; b0 < a.B; b0 += RB) {
-        float gx[RB], gy[RB], Gs[RB];
+    for (int b = 0; b < a.B; ++b) {
+        const float gx = a.grid[((size_t)b * a.N + n) * 2 + 0];
+        const float gy = a.grid[((size_t)b * a.N + n) * 2 + 1];
+        const float G = a.gout[(size_t)b * a.N + n];
+        gsum += G;
+        const Taps t = make_taps(gx, gy, a.W, a.H);
+        const float* zb = a.z + (size_t)b * a.zsb;
+        float* dzb = a.dz ? a.dz + (size_t)b * a.dzsb : nullptr;
+        float sx = 0.f, sy = 0.f;
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int b = min(b0 + u, a.B - 1);
-            gx[u] = a.grid[((size_t)b * a.N + n) * 2 + 0];
-            gy[u] = a.grid[((size_t)b * a.N + n) * 2 + 1];
-            Gs[u] = (b0 + u < a.B) ? a.gout[(size_t)b * a.N + n] : 0.f;  // images beyond B: zero weight, nothing stored
-        }
-        Taps t[RB];
-        float zv[RB][NE][4];
+        for (int i = 0; i < NE; ++i) {
+            const int c = lane + 64 * i;
+            float zv[4];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int b = min(b0 + u, a.B - 1);
-            t[u] = make_taps(gx[u], gy[u], a.W, a.H);
-            const float* zb = a.z + (size_t)b * a.zsb;
+            for (int k = 0; k < 4; ++k) zv[k] = (c < a.C && t.in[k]) ? zb[(size_t)t.cell[k] * a.zsc + c] : 0.f;
+            df[i] += G * (t.w[0] * zv[0] + t.w[1] * zv[1] + t.w[2] * zv[2] + t.w[3] * zv[3]);
+            sx += f[i] * ((1.f - t.ay) * (zv[1] - zv[0]) + t.ay * (zv[3] - zv[2]));
+            sy += f[i] * ((1.f - t.ax) * (zv[2] - zv[0]) + t.ax * (zv[3] - zv[1]));
+            if (dzb && c < a.C) {  // no-scratch form only (launch_readout_bwd without ws)
+                const float gf = G * f[i];
 #pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int c = lane + 64 * i;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) zv[u][i][k] = (c < a.C && t[u].in[k]) ? zb[(size_t)t[u].cell[k] * a.zsc + c] : 0.f;
+                for (int k = 0; k < 4; ++k)
+                    if (t.in[k]) atomicAdd(&dzb[(size_t)t.cell[k] * a.dzsc + c], gf * t.w[k]);
             }
         }
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int b = b0 + u;
-            const float G = Gs[u];
-            gsum += G;
-            float* dzb = (a.dz && b < a.B) ? a.dz + (size_t)b * a.dzsb : nullptr;
-            float sx = 0.f, sy = 0.f;
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int c = lane + 64 * i;
-                const float* z4 = zv[u][i];
-                df[i] += G * (t[u].w[0] * z4[0] + t[u].w[1] * z4[1] + t[u].w[2] * z4[2] + t[u].w[3] * z4[3]);
-                sx += f[i] * ((1.f - t[u].ay) * (z4[1] - z4[0]) + t[u].ay * (z4[3] - z4[2]));
-                sy += f[i] * ((1.f - t[u].ax) * (z4[2] - z4[0]) + t[u].ax * (z4[3] - z4[1]));
-                if (dzb && c < a.C) {  // no-scratch form only (launch_readout_bwd without ws)
-                    const float gf = G * f[i];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (t[u].in[k]) atomicAdd(&dzb[(size_t)t[u].cell[k] * a.dzsc + c], gf * t[u].w[k]);
-                }
-            }
-            if (a.dgrid) {
-                sx = wave_sum(sx);
-                sy = wave_sum(sy);
-                if (lane == 0 && b < a.B) {
-                    a.dgrid[((size_t)b * a.N + n) * 2 + 0] = G * sx * 0.5f * (float)(a.W - 1);
-                    a.dgrid[((size_t)b * a.N + n) * 2 + 1] = G * sy * 0.5f * (float)(a.H - 1);
-                }
+        if (a.dgrid) {
+            sx = wave_sum(sx);
+            sy = wave_sum(sy);
+            if (lane == 0) {
+                a.dgrid[((size_t)b * a.N + n) * 2 + 0] = G * sx * 0.5f * (float)(a.W - 1);
+                a.dgrid[((size_t)b * a.N + n) * 2 + 1] = G * sy * 0.5f * (float)(a.H - 1);
             }
         }
     }
