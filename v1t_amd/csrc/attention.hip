@@ -1732,11 +1732,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     }
     const int toff = tr_lane_off_perm(lane, G::RSTR);
     const int nkb = a.ldds / 32;  // 32-key blocks per query block
-    // dS' layout (attention.h): 2-KB blocks [32 queries x 32 keys]; round 6: KEY-block-major [bh][key block][query block] - a wave's stores of consecutive
-    // steps are one contiguous stream, and the dQ GEMM finds the 16 query blocks of a workgroup's stage as ONE contiguous 32 KB instead of sixteen 2-KB
-    // pieces 104 KB apart. ds_kmajor = 0 (dev, A/B): the query-block-major layout of rounds 2-5.
-    const size_t ds_step = a.ds_kmajor ? (size_t)1024 : (size_t)nkb * 1024;  // elements between consecutive query blocks
-    bf16_t* ds_wave = a.ds + (a.ds_kmajor ? (bh * nkb + (size_t)(rb * 4 + pw)) * nq : (bh * nq) * nkb + (size_t)(rb * 4 + pw)) * 1024 + lane * 8;
+    bf16_t* ds_wave = a.ds + ((bh * nq) * nkb + (size_t)(rb * 4 + pw)) * 1024 + lane * 8;
     const unsigned kmask = kok ? 0xFFFFFFFFu : 0u;  // keys beyond T: zeros (the dQ GEMM multiplies them with clamped K rows)
     const bool ktail = rb * 128 + 32 * pw + 32 > a.T;
     store_kv();
@@ -1788,7 +1784,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         bf16x8 fr[NSLOT];
 #pragma unroll
         for (int m = 0; m < LA; ++m) fr[m] = frag(m);
-        bf16_t* dst = ds_wave + (size_t)j * ds_step;
+        bf16_t* dst = ds_wave + (size_t)j * nkb * 1024;
         u32x4 m0 = s0, m1 = s1;
         if (ktail) {  // wave-uniform: only the last key block of an (image, head) has keys beyond T
 #pragma unroll
@@ -1922,9 +1918,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq2_kernel(AttnArgs a) {
     for (int u = 0; u < QPW; ++u) {
         qb[u] = rb * 8 * QPW + wave + 8 * u;
         if (qb[u] < nq) nact = u + 1;  // wave-uniform; blocks are active in order of u
-        sbase[u] = (const char*)(a.ds + (a.ds_kmajor ? bh * nkb * nq + (size_t)min(qb[u], nq - 1) : (bh * nq + min(qb[u], nq - 1)) * nkb) * 1024);
+        sbase[u] = (const char*)(a.ds + ((bh * nq + min(qb[u], nq - 1)) * nkb) * 1024);
     }
-    const size_t st_bytes = a.ds_kmajor ? (size_t)nq * 2048 : (size_t)2048;  // bytes between a query block's consecutive 32-key stages
     // a block is 2 KB contiguous ([k-step 2][half 2][key 32][8]): the instruction offset advances source and LDS alike. The LDS image
     // keeps the upper half of each k-step ROTATED by 4 keys (slot j <- key (j + 4) & 31, by the lane's source offset): a transposed
     // read takes 4 keys x 16 B from both halves, which sit 512 B = a whole number of bank rounds apart - 2-way conflicts on every
@@ -1959,9 +1954,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq2_kernel(AttnArgs a) {
                 // dS' is read exactly once: the non-temporal policy (streams past the L2's / Infinity Cache's LRU; tools/microbench/hbm_stream: LDS-DMA reads
                 // 7.1 against 6.4 TB/s) - round 6; V1T_DQ2_NT=0 (dev, A/B): the plain policy of rounds 2-5
                 if (ds_nt) {
-                    TileDma<DP, G::RSTR>::template group<2, true>(sbase[u] + (size_t)st * st_bytes, l0, svoff, svoff, 0, 0);
+                    TileDma<DP, G::RSTR>::template group<2, true>(sbase[u] + (size_t)st * 2048, l0, svoff, svoff, 0, 0);
                 } else {
-                    TileDma<DP, G::RSTR>::template group<2>(sbase[u] + (size_t)st * st_bytes, l0, svoff, svoff, 0, 0);
+                    TileDma<DP, G::RSTR>::template group<2>(sbase[u] + (size_t)st * 2048, l0, svoff, svoff, 0, 0);
                 }
             }
     };
@@ -2041,18 +2036,14 @@ int launch_bwd_t(const AttnArgs& a_in, hipStream_t s) {
     if constexpr (DP == 160 && !DIAG) {
         if (a.ds) {
             if (a.ldds != attn_ds_ld(a.T)) return V1T_ERR_ARG;
-            static const bool ds_kmajor = !(dev_env("V1T_DS_KMAJOR") && !atoi(dev_env("V1T_DS_KMAJOR")));
-            AttnArgs ak = a_in;
-            ak.ds_kmajor = ds_kmajor ? 1 : 0;
             prof_begin(PROF_ATTN_DKV, s);
-            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, ak);
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
             static const bool dq_deep = !(dev_env("V1T_DQ2_DEEP") && !atoi(dev_env("V1T_DQ2_DEEP")));  // dev (A/B): 0 = the one 3-deep ring
             static const bool dq_nt = !(dev_env("V1T_DQ2_NT") && !atoi(dev_env("V1T_DQ2_NT")));
             AttnArgs a = a_in;
             a.ds_nt = dq_nt ? 1 : 0;
-            a.ds_kmajor = ds_kmajor ? 1 : 0;
             if (dq_deep) hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP, true>), dim3(((a.T + 511) / 512) * a.H * a.B), dim3(512), 0, s, a);
             else hipLaunchKernelGGL((attn_bwd_dq2_kernel<DP, false>), dim3(((a.T + 511) / 512) * a.H * a.B), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DQ, s);
