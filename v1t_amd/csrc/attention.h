@@ -36,18 +36,12 @@ struct AttnArgs {
     // nlse = -1e30, so P = 0 there), written by attn_delta2_kernel.
     bf16_t* ds; int ldds;
     int ds_nt;  // dQ GEMM: read dS' with the non-temporal policy (set by the launcher)
-    int dkv_units, dkv_full, dkv_split;  // dK/dV kernel's tail split (set by the launcher): units of the launch, whole units, parts per tail unit (<= 1: none)
 };
 __host__ __device__ inline int attn_ds_ld(int T) { return (T + 127) / 128 * 128; }             // key columns covered (128-key workgroups)
 __host__ __device__ inline int attn_ds_tpq(int T) { return (T + 31) / 32 * 32; }               // query rows covered (32-query blocks)
 __host__ __device__ inline size_t attn_ds_elems(int B, int H, int T) { return (size_t)B * H * attn_ds_tpq(T) * attn_ds_ld(T); }
 __host__ __device__ inline size_t attn_rc_floats(int B, int H, int T) { return (size_t)B * H * attn_ds_tpq(T); }
-// Behind the row constants: the bf16 partial dK / dV of a small launch's tail units (attn_bwd_dkv2_kernel's tail split): at most ATTN_TAIL_PARTS workgroups,
-// each [K, V][128 keys][160], 16-B aligned.
-constexpr int ATTN_TAIL_PARTS = 256;
-__host__ __device__ inline size_t attn_dkv_part_off(int B, int H, int T) { return (attn_ds_elems(B, H, T) * 2 + 2 * attn_rc_floats(B, H, T) * 4 + 255) / 256 * 256; }
-__host__ __device__ inline bf16_t* attn_dkv_part_base(bf16_t* ds, int B, int H, int T) { return (bf16_t*)((char*)ds + attn_dkv_part_off(B, H, T)); }
-inline size_t attn_ds_bytes(int B, int H, int T) { return attn_dkv_part_off(B, H, T) + (size_t)ATTN_TAIL_PARTS * 2 * 128 * 160 * 2; }
+inline size_t attn_ds_bytes(int B, int H, int T) { return attn_ds_elems(B, H, T) * 2 + 2 * attn_rc_floats(B, H, T) * 4; }
 
 int launch_attn_fwd(const AttnArgs& a, int DP, hipStream_t s);
 int launch_attn_delta(const AttnArgs& a, int DP, float* delta, hipStream_t s);

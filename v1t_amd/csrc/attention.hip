@@ -1419,25 +1419,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     KS_DECL;
     const int pw = wave & 3;  // pair: producer pw and consumer pw + 4 own keys [32 pw, 32 pw + 32) of the 128-key block
     int rb, h, b;
-    // Tail split (round 6, small launches): the workgroups of a launch's LAST, at most half-filled round are cut S ways by QUERY range - a launch of 3.25
-    // rounds (16 images: the per-mouse loop) ran as 4 - each part writing bf16 partial dK / dV that attn_dkv_tail_sum_kernel adds (deterministic, no
-    // atomics). blockIdx < dkv_full: a whole unit; behind them S consecutive workgroups per tail unit. Everything below indexes query tiles LOCALLY
-    // (tile t = query block tq0 + t): tile sources, row constants, dS' blocks and the dropout coordinates are shifted by tq0.
-    const int nq_all = (a.T + 31) / 32;    // 32-query blocks of an (image, head)
-    int ubid = blockIdx.x, tq0 = 0, nq = nq_all, part = -1;
-    if (a.dkv_split > 1 && (int)blockIdx.x >= a.dkv_full) {  // workgroup-uniform
-        part = (int)blockIdx.x - a.dkv_full;
-        ubid = a.dkv_full + part / a.dkv_split;
-        const int pi = part % a.dkv_split;
-        tq0 = pi * nq_all / a.dkv_split;
-        nq = (pi + 1) * nq_all / a.dkv_split - tq0;
-    }
-    decode_block(a, ubid, a.dkv_units, rb, h, b);
+    decode_block(a, blockIdx.x, gridDim.x, rb, h, b);
     const int key = rb * 128 + 32 * pw + (lane & 31);
     const int h2 = lane >> 5;
     const int HD = a.H * DP;
     const bool kok = key < a.T;
-    const int TPQ = 32 * nq_all;
+    const int nq = (a.T + 31) / 32;        // 32-query blocks
+    const int TPQ = 32 * nq;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.T * a.ldqkv;
     const size_t bh = (size_t)b * a.H + h;
 
@@ -1452,12 +1440,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         const int r = min(perm_row(min(p / Dma::CPR, 31)), max_row), cc = min(p % Dma::CPR, DP / 8 - 1);  // LDS position -> the row it holds
         return (unsigned)((r * ld + 8 * cc) * 2);
     };
+    const bf16_t* const img = wave < 4 ? a.dO + (size_t)b * a.T * a.lddo + h * DP : qkv_b + h * DP;  // this wave's tile source
     const int ld = wave < 4 ? a.lddo : a.ldqkv;
-    const bf16_t* const img = (wave < 4 ? a.dO + (size_t)b * a.T * a.lddo + h * DP : qkv_b + h * DP) + (size_t)32 * tq0 * ld;  // this wave's tile source
     unsigned voff[3];  // (biased: see stage())
 #pragma unroll
     for (int i = 0; i < 3; ++i) voff[i] = lane_off(i, ld, 31) + 2048u - 1024u * i;
-    const float* rcg = (const float*)(a.ds + attn_ds_elems(a.B, a.H, a.T)) + bh * TPQ + 32 * tq0;  // nlse; ndelta B*H*TPQ floats behind it
+    const float* rcg = (const float*)(a.ds + attn_ds_elems(a.B, a.H, a.T)) + bh * TPQ;  // nlse; ndelta B*H*TPQ floats behind it
     const unsigned rc_voff = (unsigned)(((lane & 31) + (h2 ? attn_rc_floats(a.B, a.H, a.T) : 0)) * 4);
     // LDS destinations as 32-bit byte addresses computed from one base (a generic-pointer form costs a null check and 64-bit arithmetic per
     // operation - for lds.rc[slot] even a 64-bit division - in scalar instructions, which take the wave's issue slots like vector ones); the
@@ -1472,10 +1460,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         const unsigned m0v = __builtin_amdgcn_readfirstlane(tile0 + slot * SLOT_BYTES);
         const char* src = (const char*)(img + (size_t)32 * t * ld) - DBIAS;
         unsigned v[3] = {voff[0], voff[1], voff[2]};
-        if (32 * (tq0 + t) + 32 > a.T) {
+        if (32 * t + 32 > a.T) {
             asm volatile("; ragged tile: rows beyond T are clamped to T - 1 (finite data; P = 0 there)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 3; ++i) v[i] = lane_off(i, ld, a.T - 1 - 32 * (tq0 + t)) + DBIAS - 1024u * i;
+            for (int i = 0; i < 3; ++i) v[i] = lane_off(i, ld, a.T - 1 - 32 * t) + DBIAS - 1024u * i;
         }
         unsigned keep;
         if (!last) {
@@ -1539,8 +1527,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     // (v_cmp_ge_u32_sdwa): compare + select per element. (Rounds 2-3: a 9-bit SWAR preparation per word - and / or / sub - then a 1-bit v_bfe_i32
     // and a v_and per element; same decisions bit for bit, 24 vector instructions fewer per 32 x 32 block: backward pair 2519 / 2530 -> 2480 / 2484 us,
     // profiles/r04_attn_experiments.txt #6.)
-    const uint32_t tile_nqb = (uint32_t)nq_all, tile_kb = (uint32_t)(rb * 4 + pw);  // per-tile byte threshold (common.h): wave-uniform, scalar arithmetic
-    auto keep_word = [&](int blk, int wi) { return mix1(dbase + (uint32_t)(16 * (tq0 + blk) + 4 * (wi >> 1) + (wi & 1)) * ADROP_K1) >> dshift; };
+    const uint32_t tile_nqb = (uint32_t)nq, tile_kb = (uint32_t)(rb * 4 + pw);  // per-tile byte threshold (common.h): wave-uniform, scalar arithmetic
+    auto keep_word = [&](int blk, int wi) { return mix1(dbase + (uint32_t)(16 * blk + 4 * (wi >> 1) + (wi & 1)) * ADROP_K1) >> dshift; };
 
     if (wave < 4) {
         // ------------------------------------------------------------------ producer
@@ -1631,7 +1619,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
             for (int m = 0; m < LA; ++m) fr[m] = frag(m);
             u32x4 kw[2] = {};
             uint32_t dthr8 = 0;
-            if constexpr (DROP) dthr8 = attn_tile_thresh(a.adrop, (uint32_t)bh, tile_nqb, (uint32_t)(tq0 + i), tile_kb);
+            if constexpr (DROP) dthr8 = attn_tile_thresh(a.adrop, (uint32_t)bh, tile_nqb, (uint32_t)i, tile_kb);
             u32x4* hb = lds.hand[i & 1][pw][0];
             KP_STAMP(1);
             KS_MARK(2);
@@ -1744,7 +1732,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
     }
     const int toff = tr_lane_off_perm(lane, G::RSTR);
     const int nkb = a.ldds / 32;  // 32-key blocks per query block
-    bf16_t* ds_wave = a.ds + ((bh * nq_all + tq0) * nkb + (size_t)(rb * 4 + pw)) * 1024 + lane * 8;
+    bf16_t* ds_wave = a.ds + ((bh * nq) * nkb + (size_t)(rb * 4 + pw)) * 1024 + lane * 8;
     const unsigned kmask = kok ? 0xFFFFFFFFu : 0u;  // keys beyond T: zeros (the dQ GEMM multiplies them with clamped K rows)
     const bool ktail = rb * 128 + 32 * pw + 32 > a.T;
     store_kv();
@@ -1873,10 +1861,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
         constexpr int CPRD = DP / 8;  // 16-B chunks per row
         const int key0 = rb * 128 + 32 * pw;
-        // a whole unit writes its rows of dqkv; a part of a tail unit its bf16 partial: [part][K, V][128 keys][DP] behind the row constants
-        bf16_t* const obase = part < 0 ? a.dqkv + ((size_t)b * a.T + key0) * a.lddqkv + h * DP + HD
-                                       : attn_dkv_part_base(a.ds, a.B, a.H, a.T) + ((size_t)part * 2 * 128 + 32 * pw) * DP;
-        const size_t orow = part < 0 ? (size_t)a.lddqkv : (size_t)DP, okv = part < 0 ? (size_t)HD : (size_t)128 * DP;
+        bf16_t* const obase = a.dqkv + ((size_t)b * a.T + key0) * a.lddqkv + h * DP;
 #pragma unroll
         for (int it = 0; it < (32 * CPRD + 63) / 64; ++it) {
             const int pch = 64 * it + lane;
@@ -1884,41 +1869,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
             if (pch < 32 * CPRD && key0 + row < a.T) {
                 const u32x4 xk = *(const u32x4*)(tk + row * G::RSTR + 8 * ch);
                 const u32x4 xv = *(const u32x4*)(tv + row * G::RSTR + 8 * ch);
-                bf16_t* o = obase + (size_t)row * orow + 8 * ch;
-                *(u32x4*)(o) = xk;
-                *(u32x4*)(o + okv) = xv;
+                bf16_t* o = obase + (size_t)row * a.lddqkv + 8 * ch;
+                *(u32x4*)(o + HD) = xk;
+                *(u32x4*)(o + 2 * HD) = xv;
             }
         }
     }
     KSP_MARK(7);
     KS_MARK(7);
     KS_END(gridDim.x / 2 + 88, wave, lane);
-}
-
-// Sums the S bf16 partials of every tail unit of attn_bwd_dkv2_kernel's split (fp32) into its rows of dqkv. One workgroup per (tail unit, K / V): thread =
-// one 16-B chunk of one key row at a time.
-template <int DP>
-__global__ __launch_bounds__(256) void attn_dkv_tail_sum_kernel(AttnArgs a) {
-    const int u = blockIdx.x >> 1, kv = blockIdx.x & 1, S = a.dkv_split;
-    int rb, h, b;
-    decode_block(a, a.dkv_full + u, a.dkv_units, rb, h, b);
-    const bf16_t* pb = attn_dkv_part_base(a.ds, a.B, a.H, a.T) + ((size_t)u * S * 2 + kv) * 128 * DP;
-    bf16_t* ob = a.dqkv + ((size_t)b * a.T + rb * 128) * a.lddqkv + (size_t)(1 + kv) * a.H * DP + h * DP;
-    constexpr int CPR = DP / 8;
-    for (int c = threadIdx.x; c < 128 * CPR; c += 256) {
-        const int row = c / CPR, ch = c - row * CPR;
-        if (rb * 128 + row >= a.T) continue;
-        float acc[8] = {};
-        for (int p_ = 0; p_ < S; ++p_) {
-            const bf16x8 x = *(const bf16x8*)(pb + (size_t)p_ * 2 * 128 * DP + (size_t)row * DP + 8 * ch);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += (float)x[e];
-        }
-        bf16x8 y;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = (bf16_t)acc[e];
-        *(bf16x8*)(ob + (size_t)row * a.lddqkv + 8 * ch) = y;
-    }
 }
 
 // dQ = dS' . K over the materialised dS' (layout: attention.h). Workgroup = 8 waves = 8 query blocks (256 queries) of one
@@ -2077,20 +2036,8 @@ int launch_bwd_t(const AttnArgs& a_in, hipStream_t s) {
     if constexpr (DP == 160 && !DIAG) {
         if (a.ds) {
             if (a.ldds != attn_ds_ld(a.T)) return V1T_ERR_ARG;
-            // tail split (attn_bwd_dkv2_kernel): a launch whose last round is at most half full (16 images: 832 units = 3.25 rounds of 256 CUs, run as 4)
-            // cuts that round's units 2-4 ways by query range: 3 + 1/4 rounds. V1T_DKV_SPLIT=0 (dev, A/B): whole units only, as in rounds 2-5.
-            static const bool tail_split = !(dev_env("V1T_DKV_SPLIT") && !atoi(dev_env("V1T_DKV_SPLIT")));
-            static const int ncu = [] { int dev = 0, v = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
-            AttnArgs ak = a_in;
-            ak.dkv_units = n; ak.dkv_full = n; ak.dkv_split = 1;
-            const int tail = n % ncu, nq_all = (a.T + 31) / 32;
-            if (tail_split && n > ncu && tail > 0 && 2 * tail <= ncu) {
-                const int S = std::min(std::min(4, ncu / tail), nq_all);
-                if (S >= 2 && tail * S <= ATTN_TAIL_PARTS) { ak.dkv_full = n - tail; ak.dkv_split = S; }
-            }
             prof_begin(PROF_ATTN_DKV, s);
-            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(ak.dkv_full + (n - ak.dkv_full) * ak.dkv_split), dim3(512), 0, s, ak);
-            if (ak.dkv_split > 1) hipLaunchKernelGGL((attn_dkv_tail_sum_kernel<DP>), dim3(2 * (n - ak.dkv_full)), dim3(256), 0, s, ak);
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
             static const bool dq_deep = !(dev_env("V1T_DQ2_DEEP") && !atoi(dev_env("V1T_DQ2_DEEP")));  // dev (A/B): 0 = the one 3-deep ring
