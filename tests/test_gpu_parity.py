@@ -563,6 +563,7 @@ def test_train_mode_dropout_replayed_in_oracle(dev, shape):
     model, _ = build_native_model(cfg, sd, dev)
     model.train(True)
     bd = {k: v.to(dev) for k, v in batch.items()}
+    bd["image"].requires_grad_(True)  # also: d loss / d image through the patch dropout (v1t_vit_backward_input in train mode)
     core = model.core
     z = core(bd["image"], mouse_id="A", behaviors=bd["behavior"], pupil_centers=bd["pupil_center"])
     seed = core._seed_state  # the seed the forward just used
@@ -573,9 +574,11 @@ def test_train_mode_dropout_replayed_in_oracle(dev, shape):
         assert core.num_tokens == 1654 and core.padded_dim == 160
     masks = replay_dropout_masks(core, cfg, B, seed, dev)
     sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
-    ol, _, oy = O.total_loss(cfg, sdd, batch, "A", 4500.0, eps=eps, masks=masks)
+    obatch = dict(batch, image=batch["image"].clone().requires_grad_(True))
+    ol, _, oy = O.total_loss(cfg, sdd, obatch, "A", 4500.0, eps=eps, masks=masks)
     ol.backward()
     assert_close(f"drop[{shape}].y", y.cpu().numpy(), oy.detach().numpy(), Y_RTOL, Y_ATOL)
+    check_grad(f"test_train_mode_dropout_replayed_in_oracle[{shape}]: input gradient", bd["image"].grad.cpu().numpy(), obatch["image"].grad.numpy(), G_TOL)
     n = 0
     for k, p in model.named_parameters():
         ref = sdd[k].grad
