@@ -36,7 +36,6 @@ struct AttnArgs {
     // nlse = -1e30, so P = 0 there), written by attn_delta2_kernel.
     bf16_t* ds; int ldds;
     int ds_nt;  // dQ GEMM: read dS' with the non-temporal policy (set by the launcher)
-    int kv_nt;  // dK/dV kernel: its own K / V rows through non-temporal loads (set by the launcher)
 };
 __host__ __device__ inline int attn_ds_ld(int T) { return (T + 127) / 128 * 128; }             // key columns covered (128-key workgroups)
 __host__ __device__ inline int attn_ds_tpq(int T) { return (T + 31) / 32 * 32; }               // query rows covered (32-query blocks)

@@ -1499,10 +1499,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs a) {
         for (int it = 0; it < KV_IT; ++it) {
             const int p = min(64 * it + lane, 32 * (DP / 8) - 1);
             const int r = min(rb * 128 + 32 * pw + p / (DP / 8), a.T - 1), cc = p % (DP / 8);
-            // a workgroup's K / V rows are read by it alone (whole lines): non-temporal, so that they do not displace the Q / dO tiles every key block of
-            // this (image, head) re-reads from the L2. kv_nt = 0 (dev, A/B): the plain loads of rounds 2-5
-            const u32x4* kp = (const u32x4*)(src + (size_t)r * a.ldqkv + 8 * cc);
-            kvreg[it] = a.kv_nt ? __builtin_nontemporal_load(kp) : *kp;
+            kvreg[it] = *(const u32x4*)(src + (size_t)r * a.ldqkv + 8 * cc);
         }
     };
     static_assert(sizeof(lds.hand) >= 2 * 32 * G::RSTR * sizeof(bf16_t), "two tile images fit the hand-off area");
@@ -2039,11 +2036,8 @@ int launch_bwd_t(const AttnArgs& a_in, hipStream_t s) {
     if constexpr (DP == 160 && !DIAG) {
         if (a.ds) {
             if (a.ldds != attn_ds_ld(a.T)) return V1T_ERR_ARG;
-            static const bool kv_nt = !(dev_env("V1T_DKV_KV_NT") && !atoi(dev_env("V1T_DKV_KV_NT")));
-            AttnArgs ak = a_in;
-            ak.kv_nt = kv_nt ? 1 : 0;
             prof_begin(PROF_ATTN_DKV, s);
-            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, ak);
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<DP, DROP>), dim3(n), dim3(512), 0, s, a);
             prof_end(PROF_ATTN_DKV, s);
             prof_begin(PROF_ATTN_DQ, s);
             static const bool dq_deep = !(dev_env("V1T_DQ2_DEEP") && !atoi(dev_env("V1T_DQ2_DEEP")));  // dev (A/B): 0 = the one 3-deep ring
