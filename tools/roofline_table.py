@@ -35,8 +35,9 @@ MODEL = {
     "gemm_lnbwd_kernel<5, true, 0>": ("dX GEMM + LayerNorm backward + residual (4 x dFC1 form, 3 x dQKV form per step)", "hbm",
                                       (4 * (h512 + 3 * x32 + p160) + 3 * (qkv + 3 * x32 + p160)) // 7, (4 * 2 * R * D * M + 3 * 2 * R * D * 3 * H * D) // 7, "dY, x, G in; G out, dy of the next branch"),
     "gemm_lnbwd_kernel<5, false, 0>": ("dQKV form of block 0 (no next branch)", "hbm", qkv + 3 * x32, 2 * R * D * 3 * H * D, "dqkv, x, G in; G out"),
-    "gemm_tn2_kernel<1, 5, false>": ("dWqkv = dqkv^T z1, dW1 = dh^T z2 (one of each per block)", "hbm", (qkv + p160 + h512 + p160) // 2, (2 * R * D * 3 * H * D + 2 * R * D * M) // 2, "dY, X (both read once)"),
-    "gemm_tn2_kernel<5, 1, true>": ("dWo = dA^T O, dW2 = dY^T hact", "hbm", (p160 + o640 + p160 + h512) // 2, (2 * R * D * H * D + 2 * R * D * M) // 2, "dY, X fp16 plane"),
+    "gemm_tn2_kernel<1, 5, false, 2>": ("dWqkv = dqkv^T z1, dW1 = dh^T z2 (one of each per block)", "hbm", (qkv + p160 + h512 + p160) // 2, (2 * R * D * 3 * H * D + 2 * R * D * M) // 2, "dY, X (both read once)"),
+    "gemm_tn2_kernel<5, 1, true, 2>": ("dWo = dA^T O (320 workgroups: double buffer, two per CU)", "hbm", p160 + o640, 2 * R * D * H * D, "dA, O fp16 plane"),
+    "gemm_tn2_kernel<5, 1, true, 3>": ("dW2 = dY^T hact (256 workgroups: 3-stage ring)", "hbm", p160 + h512, 2 * R * D * M, "dY, activation fp16 plane"),
     "readout_fwd_multi_kernel<3>": ("bilinear taps . features + bias, 7 mice (gaussian2d.py:270-276)", "hbm", readout_alg, MICE * 16 * N_NEUR * D * 10, "z, features, grid, bias, out (SURVEY 8d)"),
     "readout_bwd_multi_kernel<3>": ("d features / d bias / d grid", "hbm", readout_alg + MICE * 155 * N_NEUR * 4, MICE * 16 * N_NEUR * D * 12, "z, features, gout; d features"),
     "readout_dz_gather_multi_kernel<3>": ("dz by sorted taps", "hbm", x32 + MICE * (155 * N_NEUR * 4 + 16 * N_NEUR * 4 * 6), MICE * 16 * N_NEUR * D * 8, "features, taps; dz fp32"),
@@ -50,7 +51,22 @@ MODEL = {
     "pack_kernel": ("bf16 / fp16 weight shadow refresh", "hbm", core_floats * 4 + core_floats * 2 * 3, 0, "fp32 arena; 16-bit planes + transposes"),
 }
 ks = d["kernels"]
+# SQ counters (tools/pmc_sq_all.sh), if collected: MFMA-pipe busy fraction, calibrated on the bench's own back-to-back MFMA probe kernel in the same pass
+# (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of a kernel over the same ratio of mfma_peak_kernel, whose pipes are busy every cycle)
+sq = {}
+sqp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_sq_all{tag}.json")
+if os.path.exists(sqp):
+    sk = json.load(open(sqp))["kernels"]
+    ref = sk.get("mfma_peak_kernel")
+    if ref and ref.get("SQ_BUSY_CYCLES"):
+        r0 = ref["SQ_VALU_MFMA_BUSY_CYCLES"] / ref["SQ_BUSY_CYCLES"]
+        for k_, e_ in sk.items():
+            if e_.get("SQ_BUSY_CYCLES"):
+                sq[k_] = {"mfma_busy": e_["SQ_VALU_MFMA_BUSY_CYCLES"] / e_["SQ_BUSY_CYCLES"] / r0, "wait": e_["wait_any_frac"], "stall": e_["wait_inst_frac"], "valu": e_["active_valu_frac"]}
 steps = d.get("bench_alone", {}).get("steps", 3) + d.get("bench_alone", {}).get("warmup", 2)
+fw = next((e for k_, e in ks.items() if k_.startswith("attn_fwd_kernel") and e.get("calls_alone")), None)
+if fw:  # bench.py also runs un-timed steps (the roofline_hbm window): count the steps of the pass by the forward attention's 4 launches per step
+    steps = fw["calls_alone"] / 4.0
 step_ms_alone = sum(e.get("total_ms_alone", 0.0) for k, e in ks.items() if "mfma_peak" not in k) / steps
 rows = []
 for k, e in ks.items():
@@ -70,8 +86,10 @@ out = [f"# Counter-backed roofline of every kernel of the C2 training step ({rnd
        "whose 2 x 113 MiB for a 113-MiB residual stream is a real second fabric fetch of half of every line (8 waves x 20 KB of rows in flight per CU thrash the 16-KB L1 and the XCD's L2).",
        "TB/s = traffic / alone duration; ceilings on this chip (profiles/r04_hbm_stream.txt): read 6.4, write 4.7, copy 5.2 TB/s, nominal 8.",
        f"Kernels below 0.3 % of the step omitted. Kernel time of one step (alone, sum): {step_ms_alone:.2f} ms.", "",
-       "| kernel | what | per step | alone us | live us | read GB | written GB | TB/s | of 8 | of ceiling | alg. GB | traffic / alg. | TFLOP/s | bound |",
-       "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+       "MFMA busy = fraction of cycles the matrix pipes are busy (`profiles/" + rnd + "_pmc_sq_all.json`, calibrated on the back-to-back MFMA probe of the same pass); wait / stall = share of wave",
+       "cycles parked at s_waitcnt / barriers and stalled at issue (SQ_WAIT_ANY, SQ_WAIT_INST_ANY).", "",
+       "| kernel | what | per step | alone us | live us | read GB | written GB | TB/s | of 8 | of ceiling | alg. GB | traffic / alg. | TFLOP/s | MFMA busy | wait / stall | bound |",
+       "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 js = {}
 for ms, k, calls, us, live, rd, wr, traffic, m in rows:
     tbs = traffic / (us * 1e-6) / 1e12
@@ -80,9 +98,9 @@ for ms, k, calls, us, live, rd, wr, traffic, m in rows:
     ratio = traffic / alg if alg else float("nan")
     tf = fl / (us * 1e-6) / 1e12 if fl else 0.0
     out.append(f"| `{k}` | {what} | {calls:.1f} x = {ms:.2f} ms | {us:.0f} | {live:.0f} | {rd / 1e9:.2f} | {wr / 1e9:.2f} | {tbs:.2f} | {tbs / 8:.2f} | {tbs / ceil:.2f} | "
-               f"{alg / 1e9:.2f} | {ratio:.2f} | {tf:.0f} | {bound} |")
+               f"{alg / 1e9:.2f} | {ratio:.2f} | {tf:.0f} | {sq.get(k, {}).get('mfma_busy', float('nan')):.2f} | {sq.get(k, {}).get('wait', float('nan')):.2f} / {sq.get(k, {}).get('stall', float('nan')):.2f} | {bound} |")
     js[k] = {"per_step_ms": ms, "alone_us": us, "live_us": live, "read_bytes": rd, "written_bytes": wr, "tbps": tbs, "frac_of_8": tbs / 8, "frac_of_ceiling": tbs / ceil,
-             "algorithmic_bytes": alg, "traffic_over_algorithmic": ratio, "tflops": tf, "bound": bound, "tensors": tensors}
+             "algorithmic_bytes": alg, "traffic_over_algorithmic": ratio, "tflops": tf, "bound": bound, "tensors": tensors, **{"sq_" + a_: b_ for a_, b_ in sq.get(k, {}).items()}}
 out += ["", "Tensors counted as algorithmic bytes:", ""] + [f"* `{k}`: {v['tensors']}" for k, v in js.items() if v["tensors"]]
 open(os.path.join(ROOT, "profiles", f"{rnd}_roofline_table{tag}.md"), "w").write("\n".join(out) + "\n")
 json.dump(js, open(os.path.join(ROOT, "profiles", f"{rnd}_roofline_table{tag}.json"), "w"), indent=1)
