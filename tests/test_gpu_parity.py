@@ -543,6 +543,10 @@ DROPOUT_SHAPES = {
     # attn_fwd<160, dropout>, attn_bwd_dkv2<160, true>, attn_bwd_dq2<160>, ln_gemm<160, ...> and the DP = 160 / MP = 512 dropout
     # epilogues - the kernel instances bench.py times
     "production": dict(num_blocks=2, emb_dim=155, mlp_dim=488, num_heads=4, patch_stride=1),
+    # the same two in the regime of trained weights (oracle/weights.py::make_sharp_state_dict: peaked attention rows, LayerNorm gains 0.3-3, outlier
+    # channels): the fused recompute backward with LSA's per-head learnable scale and masked diagonal (vit.py:235-261), and the production kernels
+    "lsa_sharp": dict(num_blocks=2, emb_dim=64, mlp_dim=128, num_heads=2, patch_stride=2, use_lsa=True),
+    "production_sharp": dict(num_blocks=2, emb_dim=155, mlp_dim=488, num_heads=4, patch_stride=1),
 }
 
 
@@ -556,7 +560,7 @@ def test_train_mode_dropout_replayed_in_oracle(dev, shape):
 
     cfg = O.Config(mouse_ids=("A",), num_neurons={"A": 300}, **DROPOUT_SHAPES[shape])
     assert cfg.p_dropout > 0 and cfg.t_dropout > 0
-    sd = W.make_state_dict(cfg, 5)
+    sd = (W.make_sharp_state_dict if shape.endswith("_sharp") else W.make_state_dict)(cfg, 5)
     B = 2
     batch = W.make_batch(cfg, "A", B, 5)
     eps = W.make_eps(cfg, "A", B, 5)
@@ -570,7 +574,7 @@ def test_train_mode_dropout_replayed_in_oracle(dev, shape):
     u = model.readouts["A"](z, shifts=model.core_shifter(bd["pupil_center"], mouse_id="A"), eps=eps.to(dev))
     loss, y = elu1_poisson_loss(u, bd["response"], 4500.0, B)
     loss.backward()
-    if shape == "production":
+    if shape.startswith("production"):
         assert core.num_tokens == 1654 and core.padded_dim == 160
     masks = replay_dropout_masks(core, cfg, B, seed, dev)
     sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
