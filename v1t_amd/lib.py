@@ -149,7 +149,9 @@ def load() -> C.CDLL:
             f"v1t_amd: HIP library {LIB_PATH} not found — build it with `python -m v1t_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
-    if os.environ.get("V1T_LIB", "libv1t_amd_exp.so") == "libv1t_amd_exp.so" and not os.environ.get("V1T_ALLOW_STALE_LIB"):  # product + experiment build
+    # the product library and the experiment build are content-checked; any other V1T_LIB (a one-off A/B build) is loaded as it is
+    checked = os.environ.get("V1T_LIB") in (None, "libv1t_amd.so", "libv1t_amd_exp.so")
+    if checked and not os.environ.get("V1T_ALLOW_STALE_LIB"):
         # the git-ignored .so travels with the repo snapshot: refuse one that was built from other sources than the tree holds (content
         # hash over every .hip / .h and the flags, v1t_amd/build.py) instead of silently testing / timing old kernels
         from . import build as _b
