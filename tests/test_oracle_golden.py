@@ -38,7 +38,7 @@ SEEDS = {"g13b": 77, "g13c": 78}
 
 @pytest.mark.parametrize("name,cfg_fn,train", [("g1", W.config_c1, False), ("g4", W.config_c1, True), ("g2b", W.config_c4, False),
                                                ("g13", W.config_cct, False), ("g13b", _cct_b, False), ("g13c", _cct_c, False),
-                                               ("g14t", lambda: W.config_c2({"A": 8000}), True)])
+                                               ("g14", lambda: W.config_c2({"A": 8000}), False), ("g14t", lambda: W.config_c2({"A": 8000}), True)])
 def test_forward_backward_vs_golden(golden, name, cfg_fn, train):
     cfg = cfg_fn()
     if train:
