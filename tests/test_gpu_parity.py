@@ -185,6 +185,16 @@ def test_input_gradient_vs_reference_golden(golden, dev, name):
         # up to ~6e-4 with the outlier channels of the trained-weights regime (g14)
         noise = rel_to_max(grads1[k], grads0[k])
         check_rel_bulk(f"input gradient [{name}]: parameter gradient {k} unchanged", grads[k], grads0[k], max(1e-4, 4 * noise), max(1e-3, 8 * noise))
+    if name == "g1":  # the usual setting of gradient-based analyses (MEIs): every parameter frozen, only the image requires grad
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+        model.core.frozen = True
+        img = bd["image"].clone().requires_grad_(True)
+        u = model(inputs=img, mouse_id="A", behaviors=bd["behavior"], pupil_centers=bd["pupil_center"], activate=False)[0]
+        elu1_poisson_loss(u, bd["response"], 4500.0, 2)[0].backward()
+        # the golden gradient includes the regulariser, which does not depend on the image: same d / d image
+        check_grad("input gradient [g1, frozen model]", img.grad.cpu().numpy(), ref, G_TOL)
+        assert all(p_.grad is None or not p_.requires_grad for p_ in model.parameters())
 
 
 def test_amp_autocast_and_gradscaler_over_native_modules(dev):
